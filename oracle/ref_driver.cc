@@ -1,0 +1,334 @@
+// oracle/ref_driver.cc -- TEST INFRASTRUCTURE, not product code.
+//
+// A small driver of OUR OWN that is compiled against the reference's headers and
+// .cc files *where they lie* under /root/reference/lib/assembly/src (see
+// oracle/build_ref.sh).  Nothing from the reference is copied into this repo.
+//
+// Why a driver and not the reference's own createDict():  the translation unit
+// paths/long/BuildReadQGraph48.cc cannot be compiled unmodified by either
+// compiler in this image (g++ 11: graph/Digraph.h:1450,1461 and
+// kmers/KmerShape.h:566 are ill-formed templates; clang 22: paths/KmerPathInterval.h
+// friend default arguments), and its hot-path functions are file-static.  What DOES
+// compile in place is every component those ~250 lines of glue are built from:
+//   KMer<K> (kmers/KMer.h), KMerContext (kmers/KMerContext.{h,cc}),
+//   CF<K>::getForm (dna/CanonicalForm.h), FNV1a (math/Hash.h),
+//   KDef / KmerDictEntry / KmerDict::recomputeAdjacencies / KmerVec (kmers/ReadPather.h),
+//   HashSet (feudal/HashSet.h), MapReduceEngine (MapReduceEngine.h),
+//   PQVecEncoder/PQVec (feudal/PQVec.{h,cc}), BaseVec / MasterVec / feudal file IO,
+//   BinaryWriter/BinaryReader (feudal/BinaryStream.h).
+// This driver therefore calls the REAL reference classes for all arithmetic, data
+// layout, hashing, sorting/grouping, hash-set lookup and file IO, and restates only
+// the glue (BuildReadQGraph48.cc:63-80 tail finder, :134-190 Kmerizer, :211-318
+// createDict flow) in its own words.  DESIGN.md calls this pin "reference components,
+// restated glue".
+//
+// Sub-commands (all paths are files; see tests/golden/make_golden.py for usage):
+//   kat                                  known-answer prints for KMer<40|48|60>
+//   mkreads  in.raw out_head             raw reads/quals -> out_head.{fastb,qualp} via
+//                                        the reference's BaseVec/PQVecEncoder/feudal writer
+//   rdreads  head out.raw                reference reader -> raw reads/quals
+//   dict K head outdir minQual minFreq minBC useBC nThreads
+//                                        goodlens.u32, kmers.kvec (pre-adjacency, written by
+//                                        the reference's BinaryWriter), solid.bin (post
+//                                        recomputeAdjacencies, sorted), spectrum.txt, times.txt
+//
+// raw format: u64 nReads, then per read: u32 len, len base codes (0..3), len quals.
+
+#include "MapReduceEngine.h"
+#include "Basevector.h"
+#include "Qualvector.h"
+#include "feudal/PQVec.h"
+#include "feudal/BinaryStream.h"
+#include "kmers/ReadPather.h"
+#include "system/System.h"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+double now_s()
+{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- glue restated from BuildReadQGraph48.cc:70-80 (tail finder) ----
+template <unsigned K>
+unsigned goodLenOf( PQVec const& pq, unsigned minQual, qvec& scratch )
+{
+    pq.unpack(&scratch);                       // reference decoder (feudal/PQVec.cc:129)
+    unsigned run = 0;
+    for ( size_t i = scratch.size(); i-- > 0; )
+    {
+        if ( scratch[i] < minQual ) run = 0;
+        else if ( ++run == K ) return unsigned(i) + K;
+    }
+    return 0;
+}
+
+// ---- glue restated from BuildReadQGraph48.cc:134-190 (Kmerizer) ----
+// map(): KMer<K>::kmerizeIntoEater (kmers/KMer.h:257-274) walks a read with exactly the
+// initial/middle/final context rule of Kmerizer::map; the only difference is the
+// len==K case (one context-free k-mer), which Kmerizer::map drops (len < K+1 -> return).
+template <unsigned K>
+struct RefImpl
+{
+    typedef KMer<K> Kmer;
+    typedef KmerDictEntry<K> Entry;
+    typedef KmerVec<K> KVec;
+
+    vecbvec const* reads;
+    std::vector<unsigned> const* goodLens;
+    std::vector<int32_t> const* bc;     // null: no barcode test at all (K=40/60 variants)
+    int64_t ignBcBelow;
+    unsigned minFreq, minBC;
+    KVec* out;
+    std::atomic_size_t* nSolid;
+    size_t mine;
+
+    RefImpl() : reads(0), goodLens(0), bc(0), ignBcBelow(0), minFreq(0), minBC(0),
+                out(0), nSolid(0), mine(0) {}
+    RefImpl( RefImpl const& o ) : reads(o.reads), goodLens(o.goodLens), bc(o.bc),
+        ignBcBelow(o.ignBcBelow), minFreq(o.minFreq), minBC(o.minBC), out(o.out),
+        nSolid(o.nSolid), mine(0) {}
+    ~RefImpl() { if ( nSolid ) *nSolid += mine; }
+
+    template <class OItr>
+    struct Eater
+    {
+        OItr* o; int32_t tag;
+        void operator()( Kmer const& k, KMerContext kc, size_t, size_t )
+        { if ( k.isRev() ) { Kmer r(k); r.rc(); **o = Entry(r,kc.rc(),tag); }
+          else **o = Entry(k,kc,tag);
+          ++*o; }
+    };
+
+    template <class OItr>
+    void map( size_t readId, OItr oItr )
+    {
+        unsigned len = (*goodLens)[readId];
+        if ( len < K+1 ) return;
+        int32_t tag = -1;
+        if ( bc && int64_t(readId) >= ignBcBelow ) tag = (*bc)[readId];
+        auto beg = (*reads)[readId].begin();
+        Eater<OItr> eater{&oItr,tag};
+        Kmer::kmerizeIntoEater(beg,beg+len,eater,readId);
+    }
+
+    static void merge( Entry* first, Entry* last )
+    {
+        KMerContext all; size_t n = 0;
+        for ( Entry* e = first; e != last; ++e )
+        { all |= e->getKDef().getContext();
+          size_t c = e->getKDef().getCount(); n += c ? c : 1; }
+        first->getKDef().setContext(all);
+        first->getKDef().setCount(n);            // saturates at 2^24-1 (ReadPather.h:128)
+    }
+
+    bool barcodesOK( Entry* first, Entry* last ) const
+    {
+        if ( !bc ) return true;
+        std::vector<int32_t> seen;
+        for ( Entry* e = first; e != last; ++e )
+        { int32_t b = e->getTempBC();
+          if ( b == -1 ) return true;
+          if ( b > 0 && std::find(seen.begin(),seen.end(),b) == seen.end() )
+            seen.push_back(b); }
+        return seen.size() >= minBC;
+    }
+
+    void reduce( Entry* first, Entry* last )
+    {
+        bool ok = barcodesOK(first,last);       // before merge; merge does not touch tempBC
+        merge(first,last);
+        if ( ok && first->getKDef().getCount() >= minFreq )
+        { ++mine; if ( out ) out->insertEntry(std::move(*first)); }
+    }
+
+    Entry* overflow( Entry* first, Entry* last )
+    { if ( last-first > 1 ) merge(first,last); return first+1; }
+};
+
+struct Rec { uint64_t w0, w1; uint32_t edge, cc; int32_t bc; uint32_t pad; };
+
+template <unsigned K>
+int runDict( std::string const& head, std::string const& outdir, unsigned minQual,
+             unsigned minFreq, unsigned minBC, bool useBC, unsigned nThreads )
+{
+    typedef RefImpl<K> Impl;
+    typedef typename Impl::Entry Entry;
+    typedef typename Impl::Kmer Kmer;
+    typedef KmerVec<K> KVec;
+    typedef KmerDict<K> Dict;
+    static_assert(sizeof(Entry)==32,"entry size");
+
+    uint nt = nThreads; SetThreads(nt,False);
+    vecbvec reads; reads.ReadAll((head+".fastb").c_str());
+    VecPQVec quals; quals.ReadAll((head+".qualp").c_str());
+    std::vector<int32_t> bc;
+    if ( useBC )
+    {   // DF.cc:447-452: expand bci -> per-read barcode id (0 = unbarcoded)
+        vec<int64_t> bci; BinaryReader::readFile((head+".bci").c_str(),&bci);
+        bc.assign(reads.size(),0);
+        for ( size_t b = 0; b+1 < bci.size(); ++b )
+            for ( int64_t r = bci[b]; r < bci[b+1]; ++r ) bc[r] = int32_t(b);
+    }
+    double t0 = now_s();
+    std::vector<unsigned> goodLens(reads.size());
+    { qvec scratch;
+      for ( size_t r = 0; r != reads.size(); ++r )
+        goodLens[r] = goodLenOf<K>(quals[r],minQual,scratch); }
+    double t1 = now_s();
+    size_t nKeys = 0; for ( unsigned g : goodLens ) nKeys += g;
+    FILE* f = fopen((outdir+"/goodlens.u32").c_str(),"wb");
+    fwrite(goodLens.data(),4,goodLens.size(),f); fclose(f);
+
+    size_t nInst = 0;
+    for ( unsigned g : goodLens ) if ( g >= K+1 ) nInst += g-K+1;
+
+    KVec kv(0);
+    double t2 = t1, t3 = t1;
+    if ( nKeys )
+    {
+        std::atomic_size_t nSolid(0);
+        { Impl impl; impl.reads=&reads; impl.goodLens=&goodLens; impl.bc = useBC?&bc:nullptr;
+          impl.minFreq=minFreq; impl.minBC=minBC; impl.nSolid=&nSolid;
+          MapReduceEngine<Impl,Entry,typename Kmer::Hasher> mre(impl);
+          if ( !mre.run(nKeys,0ul,reads.size()) ) { fprintf(stderr,"mre run1 failed\n"); return 2; } }
+        t2 = now_s();
+        { Impl impl; impl.reads=&reads; impl.goodLens=&goodLens; impl.bc = useBC?&bc:nullptr;
+          impl.minFreq=minFreq; impl.minBC=minBC; impl.out=&kv;
+          typedef MapReduceEngine<Impl,Entry,typename Kmer::Hasher> MRE;
+          MRE mre(impl);
+          if ( !mre.run(nKeys,0ul,reads.size(),MRE::VERBOSITY::NOISY) )
+          { fprintf(stderr,"mre run2 failed\n"); return 2; } }
+        kv.fit();
+        t3 = now_s();
+        if ( kv.size() != nSolid ) { fprintf(stderr,"solid count mismatch\n"); return 3; }
+    }
+    // spectrum (BuildReadQGraph48.cc:192-209 semantics: histogram of counts, trailing zeros pruned)
+    std::vector<int64_t> spec;
+    for ( auto itr = kv.begin(); itr != kv.end(); ++itr )
+    { size_t c = itr->getKDef().getCount();
+      if ( spec.size() <= c ) spec.resize(c+1,0);
+      spec[c]++; }
+    f = fopen((outdir+"/spectrum.txt").c_str(),"w");
+    for ( int64_t v : spec ) fprintf(f,"%ld\n",(long)v);
+    fclose(f);
+    BinaryWriter::writeFile((outdir+"/kmers.kvec").c_str(),kv);   // reference serialisation
+
+    Dict dict(kv.size(),0.9);
+    for ( auto itr = kv.begin(); itr != kv.end(); ++itr ) dict.insertEntry(*itr);
+    double t4 = now_s();
+    if ( minFreq > 1 ) dict.recomputeAdjacencies();               // ReadPather.h:329-364
+    double t5 = now_s();
+
+    std::vector<Rec> recs; recs.reserve(dict.size());
+    for ( auto const& hhs : dict )
+      for ( Entry const& e : hhs )
+      { Rec r; memcpy(&r,&e,32); r.bc = -1; r.pad = 0; recs.push_back(r); }
+    std::sort(recs.begin(),recs.end(),[]( Rec const& a, Rec const& b )
+      { return a.w0 != b.w0 ? a.w0 < b.w0 : a.w1 < b.w1; });
+    f = fopen((outdir+"/solid.bin").c_str(),"wb");
+    if ( !recs.empty() ) fwrite(recs.data(),32,recs.size(),f);
+    fclose(f);
+    f = fopen((outdir+"/times.txt").c_str(),"w");
+    fprintf(f,"reads %zu\ninstances %zu\nsolid %zu\nthreads %u\ngoodlens_s %.6f\nmr1_s %.6f\nmr2_s %.6f\ndict_s %.6f\nadj_s %.6f\n",
+            reads.size(),nInst,recs.size(),nt,t1-t0,t2-t1,t3-t2,t4-t3,t5-t4);
+    fclose(f);
+    return 0;
+}
+
+template <unsigned K>
+void kat( char const* s )
+{
+    KMer<K> k(s);
+    uint64_t w[2]; memcpy(w,&k,16);
+    KMer<K> r(k); r.rc();
+    uint64_t v[2]; memcpy(v,&r,16);
+    printf("K=%u %s w0=%016lx w1=%016lx hash=%016lx isRev=%d isPal=%d rc_w0=%016lx rc_w1=%016lx sizeof=%zu\n",
+           K,s,w[0],w[1],k.hash(),int(k.isRev()),int(k.isPalindrome()),v[0],v[1],sizeof(k));
+}
+
+int mkreads( char const* in, std::string const& head )
+{
+    std::ifstream is(in,std::ios::binary);
+    uint64_t n; is.read((char*)&n,8);
+    vecbvec reads; VecPQVec quals; reads.reserve(n); quals.reserve(n);
+    std::vector<unsigned char> buf;
+    for ( uint64_t i = 0; i != n; ++i )
+    {
+        uint32_t len; is.read((char*)&len,4);
+        buf.resize(2*len); is.read((char*)buf.data(),2*len);
+        bvec b(len); for ( uint32_t j = 0; j != len; ++j ) b.set(j,buf[j]);
+        qvec q(len); for ( uint32_t j = 0; j != len; ++j ) q[j] = buf[len+j];
+        reads.push_back(b); quals.push_back(PQVec(q));      // reference encoder
+    }
+    reads.WriteAll((head+".fastb").c_str());
+    quals.WriteAll((head+".qualp").c_str());
+    return 0;
+}
+
+int rdreads( std::string const& head, char const* out )
+{
+    vecbvec reads; reads.ReadAll((head+".fastb").c_str());
+    VecPQVec quals; quals.ReadAll((head+".qualp").c_str());
+    FILE* f = fopen(out,"wb");
+    uint64_t n = reads.size(); fwrite(&n,8,1,f);
+    qvec q; std::vector<unsigned char> buf;
+    for ( uint64_t i = 0; i != n; ++i )
+    {
+        uint32_t len = reads[i].size(); fwrite(&len,4,1,f);
+        quals[i].unpack(&q);
+        if ( q.size() != len ) { fprintf(stderr,"len mismatch read %lu\n",i); return 2; }
+        buf.resize(2*len);
+        for ( uint32_t j = 0; j != len; ++j ) { buf[j] = reads[i][j]; buf[len+j] = q[j]; }
+        fwrite(buf.data(),1,2*len,f);
+    }
+    fclose(f);
+    return 0;
+}
+
+} // namespace
+
+int main( int argc, char** argv )
+{
+    if ( argc < 2 ) { fprintf(stderr,"usage: refdrv kat|mkreads|rdreads|dict ...\n"); return 1; }
+    std::string cmd = argv[1];
+    if ( cmd == "kat" )
+    {
+        kat<48>("ACGTACGTACGTACGTACGTACGTACGTACGTTTTTTTTTTTTTTTTT");
+        kat<48>("ACGTTGCAACGTTGCAACGTTGCATGCAACGTTGCAACGTTGCAACGT");
+        kat<40>("ACGTACGTACGTACGTACGTACGTACGTACGTTTTTTTTT");
+        kat<60>("ACGTACGTACGTACGTACGTACGTACGTACGTTTTTTTTTTTTTTTTTGGGGGGCCCCCC");
+        printf("sizeof KDef=%zu Entry48=%zu Entry40=%zu Entry60=%zu KMerContext=%zu\n",
+               sizeof(KDef),sizeof(KmerDictEntry<48>),sizeof(KmerDictEntry<40>),
+               sizeof(KmerDictEntry<60>),sizeof(KMerContext));
+        unsigned char all[256];
+        for ( unsigned i = 0; i != 256; ++i )
+        { KMerContext c; memcpy(&c,&(all[i]=i),1); KMerContext r = c.rc(); memcpy(&all[i],&r,1); }
+        printf("ctxrc");
+        for ( unsigned i = 0; i != 256; ++i ) printf(" %02x",all[i]);
+        printf("\n");
+        return 0;
+    }
+    if ( cmd == "mkreads" && argc == 4 ) return mkreads(argv[2],argv[3]);
+    if ( cmd == "rdreads" && argc == 4 ) return rdreads(argv[2],argv[3]);
+    if ( cmd == "dict" && argc == 10 )
+    {
+        unsigned K = atoi(argv[2]);
+        std::string head = argv[3], outdir = argv[4];
+        unsigned minQual = atoi(argv[5]), minFreq = atoi(argv[6]), minBC = atoi(argv[7]);
+        bool useBC = atoi(argv[8]) != 0; unsigned nThreads = atoi(argv[9]);
+        if ( K == 48 ) return runDict<48>(head,outdir,minQual,minFreq,minBC,useBC,nThreads);
+        if ( K == 40 ) return runDict<40>(head,outdir,minQual,minFreq,minBC,useBC,nThreads);
+        if ( K == 60 ) return runDict<60>(head,outdir,minQual,minFreq,minBC,useBC,nThreads);
+        fprintf(stderr,"K must be 40, 48 or 60\n"); return 1;
+    }
+    fprintf(stderr,"bad arguments\n");
+    return 1;
+}
