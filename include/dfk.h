@@ -1,0 +1,166 @@
+/* include/dfk.h -- C ABI of libdfk.so: the MI355X-native replacement for the k-mer counting
+ * hot path that SuperPlus runs as the vendored Supernova `DF` binary.
+ *
+ * The reference has no plugin/FFI seam for this path; the seam it does have is one
+ * file-static C++ call (all reference paths relative to lib/assembly/src):
+ *
+ *   Dict* createDict(String const& work_dir, vecbvec const& reads,
+ *                    ObjectManager<VecPQVec>& quals, unsigned minQual, unsigned minFreq,
+ *                    int64_t ignBcBelow, float mem_frac, unsigned minBC,
+ *                    vec<int32_t> const* bcp)          paths/long/BuildReadQGraph48.cc:211-215
+ *   called from buildReadQGraph48()                    paths/long/BuildReadQGraph48.cc:1626
+ *   called from StageBuildGraph()                      10X/runstages/RunStages.cc:389
+ *
+ * Each entry point below names the part of that call it replaces.  Plain pointers and
+ * sizes only; no exceptions cross the boundary; every function returns 0 on success or a
+ * negative DFK_E_* code, with a message available from dfk_last_error().  One context per
+ * GPU; calls on one context must be serialised by the caller (createDict is likewise
+ * called once, from the main thread: MapReduceEngine.h:423-427).
+ *
+ * There is NO CPU fallback: if no gfx950 device is usable, dfk_create() fails.
+ */
+#ifndef DFK_H
+#define DFK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFK_ABI_VERSION 1
+
+enum {
+    DFK_OK            = 0,
+    DFK_E_ARG         = -1,   /* bad argument / unsupported configuration */
+    DFK_E_NODEVICE    = -2,   /* no usable HIP device (the product has no CPU path) */
+    DFK_E_HIP         = -3,   /* a HIP runtime call failed */
+    DFK_E_NOMEM       = -4,   /* does not fit the HBM budget */
+    DFK_E_INPUT       = -5,   /* malformed input (e.g. PQVec length != read length) */
+    DFK_E_STATE       = -6,   /* call out of order (e.g. fetch before count) */
+    DFK_E_NOGOOD      = -7    /* "almost no good bases": createDict's Scram(1), BuildReadQGraph48.cc:227-230 */
+};
+
+/* Mirrors createDict's scalar arguments.  K: the reference instantiates 40, 48 and 60
+ * (BuildReadQGraph{40,48,60}.cc); DF's CLI only reaches 48 (RunStages.cc:388). */
+typedef struct dfk_config {
+    uint32_t abi_version;       /* DFK_ABI_VERSION */
+    uint32_t K;                 /* 40, 48 or 60 */
+    uint32_t min_qual;          /* MIN_QUAL, default 7   (10X/DF.cc:129-132) */
+    uint32_t min_freq;          /* MIN_FREQ, default 3 */
+    uint32_t min_bc;            /* MIN_BC,   default 2; 0..2 supported on the GPU path */
+    int32_t  device;            /* HIP device ordinal */
+    int64_t  ign_bc_below;      /* createDict ignBcBelow (= bc_start, DF.cc:344-349) */
+    uint64_t hbm_budget_bytes;  /* 0 = 90 % of free HBM (mem_frac analogue, GRAPHMEM=0.9) */
+    uint32_t minimizer_len;     /* 0 = default; 8..16 */
+    uint32_t flags;             /* DFK_F_* */
+    uint64_t inst_per_item;     /* 0 = default; k-mer instances packed into one LDS table pass */
+    uint64_t reserved[4];
+} dfk_config;
+
+#define DFK_F_KEEP_PRE_ADJ   1u   /* also keep contexts before recomputeAdjacencies (kmers.kvec view) */
+
+/* 32-byte image of KmerDictEntry<K> (kmers/ReadPather.h:105-146,169-195):
+ * w0 = bases 0..31 MSB-first, w1 = remaining bases left-aligned (kmers/KMer.h:154-160),
+ * edge_id = 0xFFFFFFFF (null), count in bits 0-23 and KMerContext byte in bits 24-31 of
+ * count_ctx, tempBC = -1, pad = 0. */
+typedef struct dfk_entry32 {
+    uint64_t w0, w1;
+    uint32_t edge_id;
+    uint32_t count_ctx;
+    int32_t  bc;
+    uint32_t pad;
+} dfk_entry32;
+
+typedef struct dfk_stats {
+    uint64_t n_reads;
+    uint64_t n_inst;            /* k-mer instances Kmerizer::map would emit (the metric's unit) */
+    uint64_t n_records;         /* super-k-mer records written by the partition kernel */
+    uint64_t n_buckets;         /* fine minimizer buckets */
+    uint64_t n_items;           /* LDS table passes */
+    uint64_t n_overflow_items;  /* items that had to be split or re-run in the HBM table */
+    uint64_t n_distinct;        /* distinct canonical k-mers seen */
+    uint64_t n_solid;
+    uint64_t adj_probes;        /* neighbour look-ups issued by the adjacency kernel */
+    /* GPU time of each stage of the last dfk_count*, milliseconds, from HIP events on the
+     * context's stream */
+    float ms_upload, ms_trim, ms_part_count, ms_part_scatter, ms_count, ms_fallback, ms_adjacency, ms_total;
+    uint64_t hbm_bytes_peak;    /* peak device bytes held by the context */
+    uint64_t reserved[8];
+} dfk_stats;
+
+typedef struct dfk_ctx dfk_ctx;
+
+/* Construct / destroy.  Replaces nothing in the reference (its state lives on createDict's stack). */
+int         dfk_create(const dfk_config* cfg, dfk_ctx** out);
+void        dfk_destroy(dfk_ctx* ctx);
+const char* dfk_last_error(void);
+int         dfk_abi_version(void);
+
+/* createDict(...) on host buffers laid out exactly as the .fastb/.qualp var data and DF's
+ * expanded barcode vector (DF.cc:447-452):
+ *   packed_bases + base_off[n+1]  BaseVec bytes, 2-bit LSB-first (feudal/FieldVec.h:766-770)
+ *   read_len[n]                   bases per read
+ *   pq_bytes + pq_off[n+1]        PQVec block streams (feudal/PQVec.cc:87-127)
+ *   bc[n] or NULL                 per-read barcode id; NULL = no barcode test at all
+ *                                 (the K=40/60 variants, BuildReadQGraph60.cc:103-151)
+ * Runs: quality-tail trim (:218-225), canonical k-mer extraction with contexts (:148-165),
+ * counting and the MIN_FREQ/MIN_BC solid filter (:167-174), the spectrum (:192-209) and
+ * recomputeAdjacencies (ReadPather.h:329-364, gated by minFreq > 1 as at :313). */
+int dfk_count(dfk_ctx* ctx,
+              const uint8_t* packed_bases, const uint64_t* base_off, const uint32_t* read_len,
+              const uint8_t* pq_bytes, const uint64_t* pq_off, const int32_t* bc,
+              uint64_t n_reads);
+
+/* Same call with every array already resident in this context's device memory (bench.py's
+ * timed region; multi-GPU shards).  packed_bytes / pq_nbytes are the allocation sizes. */
+int dfk_count_device(dfk_ctx* ctx,
+              const void* d_packed_bases, uint64_t packed_bytes, const void* d_base_off,
+              const void* d_read_len, const void* d_pq_bytes, uint64_t pq_nbytes,
+              const void* d_pq_off, const void* d_bc, uint64_t n_reads);
+
+/* goodLens (BuildReadQGraph48.cc:218-225) of the last count, for parity tests. */
+int dfk_good_lens(dfk_ctx* ctx, uint32_t* out, uint64_t cap);
+
+/* WriteKmerSpectrum's vector (BuildReadQGraph48.cc:192-209): hist[c] = #solid k-mers with
+ * count c, c in [0,max]; *nbins = max+1 (0 when there is no solid k-mer).  The pointer
+ * stays valid until the next dfk_count* or dfk_destroy. */
+int dfk_spectrum(dfk_ctx* ctx, const int64_t** hist, uint64_t* nbins);
+/* Exact text of stats/histogram_kmer_count.json (10X/MakeHist.cc:67-92).  Returns bytes
+ * needed (excl. NUL) through *need; writes at most cap bytes. */
+int dfk_spectrum_json(dfk_ctx* ctx, char* out, uint64_t cap, uint64_t* need);
+
+/* The Dict's content: number of solid k-mers, then the entries sorted ascending by
+ * (w0,w1) with contexts AFTER recomputeAdjacencies.  pre_adjacency != 0 returns the
+ * kmers.kvec view (contexts before; needs DFK_F_KEEP_PRE_ADJ). */
+int dfk_solid_count(dfk_ctx* ctx, uint64_t* n);
+int dfk_solid_fetch(dfk_ctx* ctx, dfk_entry32* out, uint64_t cap, int pre_adjacency);
+
+/* kmers.kvec image ("BINWRITE" | u64 n | n x 32-B entries; BuildReadQGraph48.cc:287-288,
+ * feudal/BinaryStream.h:33-46) written straight to a file. */
+int dfk_write_kvec(dfk_ctx* ctx, const char* path, int pre_adjacency);
+
+int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
+
+/* ---- multi-GPU pieces (one process per GPU; the caller owns the RCCL exchange) ----
+ * The MapReduceEngine thread all-to-all ("swizzle", MapReduceEngine.h:345-388) becomes:
+ *   dfk_shard_partition   kmerize this rank's reads into super-k-mer records grouped by
+ *                         destination rank (owner = minimizer bucket % world)
+ *   <caller: all_to_all of counts, then of the record bytes, over RCCL/xGMI>
+ *   dfk_shard_count       count the records this rank owns
+ *   dfk_shard_adj_*       second, small exchange for neighbours owned by other ranks
+ * See INTEGRATION.md; superplus_amd/dist.py drives these with torch.distributed. */
+int dfk_shard_partition(dfk_ctx* ctx,
+              const void* d_packed_bases, uint64_t packed_bytes, const void* d_base_off,
+              const void* d_read_len, const void* d_pq_bytes, uint64_t pq_nbytes,
+              const void* d_pq_off, const void* d_bc, uint64_t n_reads,
+              uint32_t world, const void** d_records, uint64_t* send_counts /* [world], in records */);
+int dfk_shard_count(dfk_ctx* ctx, const void* d_records, uint64_t n_records);
+int dfk_shard_adj_queries(dfk_ctx* ctx, uint32_t world, const void** d_keys,
+              uint64_t* send_counts /* [world], in 16-B keys */);
+int dfk_shard_adj_answer(dfk_ctx* ctx, const void* d_keys, uint64_t n_keys, void* d_present /* u8[n_keys] */);
+int dfk_shard_adj_apply(dfk_ctx* ctx, const void* d_present, uint64_t n_keys);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

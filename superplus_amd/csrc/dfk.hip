@@ -1,0 +1,620 @@
+// superplus_amd/csrc/dfk.hip -- host side of libdfk.so: the C ABI of include/dfk.h over the
+// HIP kernels in dfk_kernels.h.  gfx950 only; there is no CPU path in this library.
+#include "../../include/dfk.h"
+#include "dfk_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace dfk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(DFK_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+};
+
+// LDS table geometry per K (DESIGN.md "count kernel"): slots and waves per workgroup
+template <int K> struct CountCfg;
+template <> struct CountCfg<40> { static constexpr int LOG2S = 12, NWAVES = 16; };
+template <> struct CountCfg<48> { static constexpr int LOG2S = 12, NWAVES = 16; };
+template <> struct CountCfg<60> { static constexpr int LOG2S = 12, NWAVES = 12; };
+
+struct Inputs {           // device pointers
+    const uint8_t* packed; uint64_t packed_bytes;
+    const uint64_t* base_off; const uint32_t* read_len;
+    const uint8_t* pq; uint64_t pq_bytes; const uint64_t* pq_off;
+    const int32_t* bc; uint64_t n_reads;
+};
+
+} // namespace
+
+struct dfk_ctx {
+    dfk_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    uint64_t budget = 0, held = 0, peak = 0;
+    std::vector<void*> owned;                 // everything hipMalloc'd by this context for the current run
+    // results of the last run
+    bool have = false;
+    uint64_t n_reads = 0;
+    DevBuf good_len;                          // u32[n_reads]
+    DevBuf solid, solid_pre;                  // dfk_entry32[n_solid]
+    uint64_t n_solid = 0;
+    std::vector<int64_t> hist;
+    std::vector<dfk_entry32> sorted, sorted_pre;
+    bool sorted_ok = false, sorted_pre_ok = false;
+    dfk_stats st{};
+    // shard state (multi-GPU)
+    DevBuf shard_records; uint64_t shard_n_records = 0;
+    DevBuf adj_keys, adj_src; uint64_t adj_n = 0;
+    DevBuf set; uint64_t set_mask = 0;
+    uint32_t shard_world = 1, shard_log2_nb = 0;
+
+    int alloc(DevBuf& b, size_t bytes, const char* what)
+    {
+        bytes = bytes ? bytes : 16;
+        if (held + bytes > budget)
+            return fail(DFK_E_NOMEM, "HBM budget exceeded allocating %zu bytes for %s (held %llu, budget %llu)",
+                        bytes, what, (unsigned long long)held, (unsigned long long)budget);
+        hipError_t e = hipMalloc(&b.p, bytes);
+        if (e != hipSuccess) return fail(DFK_E_NOMEM, "hipMalloc(%zu) for %s: %s", bytes, what, hipGetErrorString(e));
+        b.bytes = bytes; held += bytes; peak = std::max(peak, held);
+        owned.push_back(b.p);
+        return 0;
+    }
+    void release(DevBuf& b)
+    {
+        if (!b.p) return;
+        auto it = std::find(owned.begin(), owned.end(), b.p);
+        if (it != owned.end()) owned.erase(it);
+        (void)hipFree(b.p); held -= b.bytes; b.p = nullptr; b.bytes = 0;
+    }
+    void release_all()
+    {
+        for (void* p : owned) (void)hipFree(p);
+        owned.clear(); held = 0;
+        good_len = solid = solid_pre = shard_records = adj_keys = adj_src = set = DevBuf{};
+        have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
+        n_solid = 0; shard_n_records = 0; adj_n = 0;
+    }
+};
+
+namespace {
+
+struct Timer {
+    hipEvent_t a{}, b{}; hipStream_t s;
+    explicit Timer(hipStream_t st) : s(st) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    void start() { (void)hipEventRecord(a, s); }
+    float stop() { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+};
+
+uint32_t ceil_log2(uint64_t v) { uint32_t b = 0; while ((1ull << b) < v) ++b; return b; }
+
+// ------------------------------------------------------------------ stage: trim (a1)
+template <int K>
+int stage_trim(dfk_ctx* c, const Inputs& in, uint64_t* n_inst)
+{
+    DevBuf ctr; int rc = c->alloc(ctr, 32, "trim counters"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctr.p, 0, 32, c->stream));
+    rc = c->alloc(c->good_len, sizeof(uint32_t) * in.n_reads, "goodLens"); if (rc) return rc;
+    if (in.n_reads) {
+        unsigned grid = (unsigned)((in.n_reads + 255) / 256);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trim<K>), dim3(grid), dim3(256), 0, c->stream,
+                           in.pq, in.pq_off, in.read_len, in.n_reads, c->cfg.min_qual, (uint32_t*)c->good_len.p,
+                           (unsigned long long*)ctr.p, (unsigned int*)((char*)ctr.p + 8));
+        HIP_TRY(hipGetLastError());
+    }
+    uint64_t h[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h, ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->release(ctr);
+    if ((uint32_t)h[1]) return fail(DFK_E_INPUT, "a PQVec stream is malformed or its length differs from read_len");
+    *n_inst = h[0];
+    return 0;
+}
+
+// ------------------------------------------------------------------ stage: partition (a2, first half)
+struct Partition {
+    DevBuf records; uint64_t n_records = 0;
+    uint32_t log2_nb = 0;
+    std::vector<uint64_t> base;       // [nb+1] first record of each fine bucket (owner-major order)
+    std::vector<uint32_t> inst;       // [nb]   instances per fine bucket
+};
+
+template <int K>
+int stage_partition(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, Partition* P)
+{
+    const uint32_t M = c->cfg.minimizer_len;
+    PartParams pp{M, (uint32_t)K - M + 1, P->log2_nb, log2_world};
+    const uint64_t nb = 1ull << P->log2_nb;
+    DevBuf acc; int rc = c->alloc(acc, nb * 8, "bucket counters"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(acc.p, 0, nb * 8, c->stream));
+    const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
+    const size_t lds_a = sizeof(uint32_t) * pp.W * PART_THREADS;
+    const size_t lds_b = lds_a + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
+    Timer t(c->stream);
+    t.start();
+    if (grid)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
+                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
+                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)acc.p,
+                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint4*)nullptr);
+    HIP_TRY(hipGetLastError());
+    c->st.ms_part_count = t.stop();
+    std::vector<uint64_t> h(nb);
+    HIP_TRY(hipMemcpy(h.data(), acc.p, nb * 8, hipMemcpyDeviceToHost));
+    c->release(acc);
+    P->base.assign(nb + 1, 0); P->inst.assign(nb, 0);
+    uint64_t tot_inst = 0;
+    for (uint64_t b = 0; b < nb; ++b) {
+        P->base[b + 1] = P->base[b] + (h[b] >> 32);
+        P->inst[b] = (uint32_t)h[b]; tot_inst += (uint32_t)h[b];
+    }
+    P->n_records = P->base[nb];
+    if (tot_inst != n_inst)
+        return fail(DFK_E_HIP, "partition count pass saw %llu instances, trim saw %llu",
+                    (unsigned long long)tot_inst, (unsigned long long)n_inst);
+    DevBuf dbase, cur;
+    rc = c->alloc(dbase, (nb + 1) * 8, "bucket bases"); if (rc) return rc;
+    rc = c->alloc(cur, nb * 4, "bucket cursors"); if (rc) return rc;
+    rc = c->alloc(P->records, P->n_records * 32, "super-k-mer records"); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dbase.p, P->base.data(), (nb + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(cur.p, 0, nb * 4, c->stream));
+    t.start();
+    if (grid)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3(grid), dim3(PART_THREADS), lds_b, c->stream,
+                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
+                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr,
+                           (const uint64_t*)dbase.p, (uint32_t*)cur.p, (uint4*)P->records.p);
+    HIP_TRY(hipGetLastError());
+    c->st.ms_part_scatter = t.stop();
+    c->release(dbase); c->release(cur);
+    c->st.n_records = P->n_records; c->st.n_buckets = nb;
+    return 0;
+}
+
+// ------------------------------------------------------------------ stage: count (a2 second half, a3, a4, a5)
+struct ItemRange { uint32_t b0, b1; };     // fine buckets [b0,b1)
+
+void pack_items(const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t budget, std::vector<ItemRange>* out)
+{
+    uint64_t acc = 0; uint32_t start = (uint32_t)b_lo;
+    for (uint64_t b = b_lo; b < b_hi; ++b) {
+        if (P.base[b + 1] == P.base[b]) { if (b == start) start = (uint32_t)b + 1; continue; }
+        if (acc && acc + P.inst[b] > budget) { out->push_back({start, (uint32_t)b}); start = (uint32_t)b; acc = 0; }
+        acc += P.inst[b];
+    }
+    if (acc) out->push_back({start, (uint32_t)b_hi});
+}
+
+template <int K, bool USE_BC>
+int launch_count(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& ranges, const CountParams& cp0,
+                 CountGlobals* d_g, uint4* d_out, unsigned long long* d_hist, std::vector<ItemRange>* overflowed)
+{
+    constexpr int LOG2S = CountCfg<K>::LOG2S, NW = CountCfg<K>::NWAVES;
+    if (ranges.empty()) return 0;
+    std::vector<CountItem> items(ranges.size());
+    for (size_t i = 0; i < ranges.size(); ++i) items[i] = CountItem{P.base[ranges[i].b0], P.base[ranges[i].b1]};
+    DevBuf d_items, d_ovf;
+    int rc = c->alloc(d_items, items.size() * sizeof(CountItem), "count items"); if (rc) return rc;
+    rc = c->alloc(d_ovf, items.size() * 4, "overflow list"); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(CountItem), hipMemcpyHostToDevice, c->stream));
+    // reset next_item / n_overflow, keep the running totals
+    HIP_TRY(hipMemsetAsync(&d_g->next_item, 0, 8, c->stream));
+    CountParams cp = cp0; cp.n_items = (uint32_t)items.size();
+    const size_t lds = count_lds_bytes<K, LOG2S, NW>();
+    auto kern = k_count<K, LOG2S, NW, USE_BC>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned per_cu = std::max<size_t>(1, (size_t)(160 * 1024) / lds);
+    const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)c->prop.multiProcessorCount * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream,
+                       (const uint4*)P.records.p, (const CountItem*)d_items.p, cp, d_g, d_out, d_hist, (uint32_t*)d_ovf.p);
+    HIP_TRY(hipGetLastError());
+    CountGlobals g{};
+    HIP_TRY(hipMemcpyAsync(&g, d_g, sizeof g, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (g.n_overflow) {
+        std::vector<uint32_t> ov(g.n_overflow);
+        HIP_TRY(hipMemcpy(ov.data(), d_ovf.p, 4ull * g.n_overflow, hipMemcpyDeviceToHost));
+        for (uint32_t i : ov) overflowed->push_back(ranges[i]);
+    }
+    c->release(d_items); c->release(d_ovf);
+    return 0;
+}
+
+template <int K, bool USE_BC>
+int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& singles, const CountParams& cp,
+                     CountGlobals* d_g, uint4* d_out, unsigned long long* d_hist)
+{
+    constexpr int KW = KTraits<K>::KW, NW = 8;
+    // tables sized to >= 2x the item's instances (an upper bound on its distinct k-mers)
+    std::vector<BigItem> items; uint64_t words = 0;
+    for (const ItemRange& r : singles) {
+        uint64_t inst = 0; for (uint32_t b = r.b0; b < r.b1; ++b) inst += P.inst[b];
+        uint32_t l2 = std::max<uint32_t>(13, ceil_log2(2 * inst + 64));
+        items.push_back(BigItem{P.base[r.b0], P.base[r.b1], words, l2, 0});
+        words += (uint64_t)(KW + 3) << l2;
+    }
+    DevBuf pool, d_items, d_fail;
+    int rc = c->alloc(pool, words * 4, "HBM fallback tables"); if (rc) return rc;
+    rc = c->alloc(d_items, items.size() * sizeof(BigItem), "fallback items"); if (rc) return rc;
+    rc = c->alloc(d_fail, 16, "fallback flag"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(pool.p, 0, words * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(d_fail.p, 0, 16, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_big<K, NW, USE_BC>), dim3((unsigned)items.size()), dim3(NW * 64), 0, c->stream,
+                       (const uint4*)P.records.p, (const BigItem*)d_items.p, cp, d_g, d_out, d_hist,
+                       (uint32_t*)pool.p, (uint32_t*)d_fail.p);
+    HIP_TRY(hipGetLastError());
+    uint32_t failed = 0;
+    HIP_TRY(hipMemcpyAsync(&failed, d_fail.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->release(pool); c->release(d_items); c->release(d_fail);
+    if (failed) return fail(DFK_E_HIP, "HBM fallback table overflowed (should be impossible at load <= 0.5)");
+    return 0;
+}
+
+template <int K, bool USE_BC>
+int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t n_inst)
+{
+    constexpr int LOG2S = CountCfg<K>::LOG2S;
+    const uint64_t budget = c->cfg.inst_per_item ? c->cfg.inst_per_item : (3ull << LOG2S) / 2;
+    std::vector<ItemRange> ranges;
+    pack_items(P, b_lo, b_hi, budget, &ranges);
+
+    // every solid k-mer has >= min_freq instances
+    uint64_t cap = n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
+    const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
+    const uint64_t fixed = (uint64_t)HIST_GLOBAL_BINS * 8 + (64ull << 20);
+    if (cap * 32 + fixed > room) cap = room > fixed ? (room - fixed) / 32 : 0;
+    DevBuf d_hist, d_g;
+    int rc = c->alloc(c->solid, cap * 32, "solid k-mer entries"); if (rc) return rc;
+    rc = c->alloc(d_hist, (uint64_t)HIST_GLOBAL_BINS * 8, "spectrum bins"); if (rc) return rc;
+    rc = c->alloc(d_g, sizeof(CountGlobals), "count globals"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(d_g.p, 0, sizeof(CountGlobals), c->stream));
+    CountParams cp{c->cfg.min_freq, c->cfg.min_bc, USE_BC ? 1u : 0u, 0, cap, COUNT_HIST_BINS};
+    CountGlobals* g = (CountGlobals*)d_g.p;
+    uint4* out = (uint4*)c->solid.p;
+    unsigned long long* hist = (unsigned long long*)d_hist.p;
+
+    Timer t(c->stream);
+    t.start();
+    std::vector<ItemRange> overflowed;
+    c->st.n_items = ranges.size();
+    rc = launch_count<K, USE_BC>(c, P, ranges, cp, g, out, hist, &overflowed); if (rc) return rc;
+    c->st.ms_count = t.stop();
+    t.start();
+    // items that overflowed their LDS table: split at fine-bucket boundaries and retry; a single
+    // fine bucket that still overflows is counted in an HBM table
+    c->st.n_overflow_items = overflowed.size();
+    std::vector<ItemRange> singles;
+    while (!overflowed.empty()) {
+        std::vector<ItemRange> next;
+        for (const ItemRange& r : overflowed) {
+            std::vector<uint32_t> nz;
+            for (uint32_t b = r.b0; b < r.b1; ++b) if (P.base[b + 1] != P.base[b]) nz.push_back(b);
+            if (nz.size() <= 1) { singles.push_back(r); continue; }
+            uint32_t mid = nz[nz.size() / 2];
+            next.push_back({r.b0, mid}); next.push_back({mid, r.b1});
+        }
+        overflowed.clear();
+        rc = launch_count<K, USE_BC>(c, P, next, cp, g, out, hist, &overflowed); if (rc) return rc;
+    }
+    if (!singles.empty()) { rc = launch_count_big<K, USE_BC>(c, P, singles, cp, g, out, hist); if (rc) return rc; }
+    c->st.ms_fallback = t.stop();
+
+    CountGlobals hg{};
+    HIP_TRY(hipMemcpy(&hg, d_g.p, sizeof hg, hipMemcpyDeviceToHost));
+    if (hg.solid_overflow || hg.n_solid > cap)
+        return fail(DFK_E_NOMEM, "solid k-mer output (%llu entries) exceeds the HBM budget (room for %llu)",
+                    (unsigned long long)hg.n_solid, (unsigned long long)cap);
+    c->n_solid = hg.n_solid; c->st.n_solid = hg.n_solid; c->st.n_distinct = hg.n_distinct;
+
+    // spectrum (a5): bins 0..max count
+    DevBuf d_max; rc = c->alloc(d_max, 16, "max bin"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_max.p, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_hist_max, dim3(1024), dim3(256), 0, c->stream, (const unsigned long long*)d_hist.p, HIST_GLOBAL_BINS,
+                       (unsigned int*)d_max.p);
+    uint32_t nb = 0;
+    HIP_TRY(hipMemcpyAsync(&nb, d_max.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->hist.assign(nb, 0);
+    if (nb) HIP_TRY(hipMemcpy(c->hist.data(), d_hist.p, 8ull * nb, hipMemcpyDeviceToHost));
+    c->release(d_max); c->release(d_hist); c->release(d_g);
+    return 0;
+}
+
+// ------------------------------------------------------------------ stage: adjacency (a6)
+int build_set(dfk_ctx* c)
+{
+    uint64_t slots = 1ull << std::max<uint32_t>(10, ceil_log2(2 * c->n_solid + 2));
+    int rc = c->alloc(c->set, slots * sizeof(SetSlot), "solid k-mer set"); if (rc) return rc;
+    c->set_mask = slots - 1;
+    hipLaunchKernelGGL(k_fill_u64, dim3(2048), dim3(256), 0, c->stream, (uint64_t*)c->set.p, slots * 2, ~0ull);
+    if (c->n_solid)
+        hipLaunchKernelGGL(k_set_insert, dim3((unsigned)((c->n_solid + 255) / 256)), dim3(256), 0, c->stream,
+                           (const uint4*)c->solid.p, c->n_solid, (SetSlot*)c->set.p, c->set_mask);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int K>
+int stage_adjacency(dfk_ctx* c)
+{
+    Timer t(c->stream);
+    t.start();
+    if (c->cfg.flags & DFK_F_KEEP_PRE_ADJ) {
+        int rc = c->alloc(c->solid_pre, c->n_solid * 32, "pre-adjacency copy"); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->solid_pre.p, c->solid.p, c->n_solid * 32, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (c->cfg.min_freq > 1 && c->n_solid) {                       // BuildReadQGraph48.cc:313
+        int rc = build_set(c); if (rc) return rc;
+        DevBuf d_n; rc = c->alloc(d_n, 16, "probe counter"); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adjacency<K>), dim3((unsigned)((c->n_solid + 255) / 256)), dim3(256), 0, c->stream,
+                           (uint4*)c->solid.p, c->n_solid, (const SetSlot*)c->set.p, c->set_mask, (unsigned long long*)d_n.p);
+        HIP_TRY(hipGetLastError());
+        uint64_t np = 0;
+        HIP_TRY(hipMemcpyAsync(&np, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->st.adj_probes = np;
+        c->release(d_n); c->release(c->set);
+    }
+    c->st.ms_adjacency = t.stop();
+    return 0;
+}
+
+uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
+{
+    // fine buckets of ~512-1024 instances; items pack several of them
+    uint32_t l = ceil_log2(n_inst / 1024 + 1);
+    l = std::max<uint32_t>(l, 4 + log2_world);
+    return std::min<uint32_t>(l, 23);
+}
+
+template <int K>
+int run_typed(dfk_ctx* c, const Inputs& in)
+{
+    Timer total(c->stream);
+    total.start();
+    Timer t(c->stream);
+    uint64_t n_inst = 0;
+    t.start();
+    int rc = stage_trim<K>(c, in, &n_inst); if (rc) return rc;
+    c->st.ms_trim = t.stop();
+    c->st.n_reads = in.n_reads; c->st.n_inst = n_inst; c->n_reads = in.n_reads;
+    Partition P; P.log2_nb = pick_log2_nb(n_inst, 0);
+    rc = stage_partition<K>(c, in, n_inst, 0, &P); if (rc) return rc;
+    const uint64_t nb = 1ull << P.log2_nb;
+    rc = in.bc ? stage_count<K, true>(c, P, 0, nb, n_inst) : stage_count<K, false>(c, P, 0, nb, n_inst);
+    if (rc) return rc;
+    c->release(P.records);
+    rc = stage_adjacency<K>(c); if (rc) return rc;
+    c->st.ms_total = total.stop();
+    c->st.hbm_bytes_peak = c->peak;
+    c->have = true;
+    return 0;
+}
+
+int run(dfk_ctx* c, const Inputs& in)
+{
+    switch (c->cfg.K) {
+    case 40: return run_typed<40>(c, in);
+    case 48: return run_typed<48>(c, in);
+    case 60: return run_typed<60>(c, in);
+    }
+    return fail(DFK_E_ARG, "K must be 40, 48 or 60");
+}
+
+int fetch_sorted(dfk_ctx* c, bool pre, std::vector<dfk_entry32>** out)
+{
+    std::vector<dfk_entry32>& v = pre ? c->sorted_pre : c->sorted;
+    bool& ok = pre ? c->sorted_pre_ok : c->sorted_ok;
+    if (!ok) {
+        const DevBuf& src = pre ? c->solid_pre : c->solid;
+        if (pre && !src.p) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
+        v.resize(c->n_solid);
+        if (c->n_solid) HIP_TRY(hipMemcpy(v.data(), src.p, c->n_solid * 32, hipMemcpyDeviceToHost));
+        std::sort(v.begin(), v.end(), [](const dfk_entry32& a, const dfk_entry32& b) {
+            return a.w0 != b.w0 ? a.w0 < b.w0 : a.w1 < b.w1; });
+        ok = true;
+    }
+    *out = &v;
+    return 0;
+}
+
+} // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+const char* dfk_last_error(void) { return g_err.c_str(); }
+int dfk_abi_version(void) { return DFK_ABI_VERSION; }
+
+int dfk_create(const dfk_config* cfg, dfk_ctx** out)
+{
+    if (!cfg || !out) return fail(DFK_E_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != DFK_ABI_VERSION) return fail(DFK_E_ARG, "dfk_config.abi_version %u != %d", cfg->abi_version, DFK_ABI_VERSION);
+    if (cfg->K != 40 && cfg->K != 48 && cfg->K != 60) return fail(DFK_E_ARG, "K=%u: the reference instantiates 40, 48 and 60 only", cfg->K);
+    if (cfg->min_bc > 2) return fail(DFK_E_ARG, "MIN_BC=%u: the GPU path tracks at most 2 distinct barcodes per k-mer", cfg->min_bc);
+    if (cfg->min_freq == 0 || cfg->min_freq > 0xFFFFFFu) return fail(DFK_E_ARG, "MIN_FREQ out of range");
+    uint32_t M = cfg->minimizer_len ? cfg->minimizer_len : 14;
+    if (M < 8 || M > 16 || M >= cfg->K) return fail(DFK_E_ARG, "minimizer_len must be in 8..16");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DFK_E_NODEVICE, "no HIP device: libdfk has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(DFK_E_ARG, "device %d out of range (%d devices)", cfg->device, ndev);
+    dfk_ctx* c = new dfk_ctx;
+    c->cfg = *cfg; c->cfg.minimizer_len = M; c->device = cfg->device;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipGetDeviceProperties(&c->prop, c->device));
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0 && !getenv("DFK_ALLOW_OTHER_ARCH")) {
+        std::string a = c->prop.gcnArchName; delete c;
+        return fail(DFK_E_NODEVICE, "device is %s; libdfk is built for gfx950 (MI355X) only", a.c_str());
+    }
+    HIP_TRY(hipStreamCreate(&c->stream));
+    size_t fr = 0, tot = 0;
+    HIP_TRY(hipMemGetInfo(&fr, &tot));
+    c->budget = cfg->hbm_budget_bytes ? cfg->hbm_budget_bytes : (uint64_t)(0.9 * (double)fr);
+    *out = c;
+    return 0;
+}
+
+void dfk_destroy(dfk_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    c->release_all();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dfk_count_device(dfk_ctx* c, const void* d_packed, uint64_t packed_bytes, const void* d_base_off,
+                     const void* d_read_len, const void* d_pq, uint64_t pq_nbytes, const void* d_pq_off,
+                     const void* d_bc, uint64_t n_reads)
+{
+    if (!c) return fail(DFK_E_ARG, "null context");
+    if (n_reads && (!d_packed || !d_base_off || !d_read_len || !d_pq || !d_pq_off)) return fail(DFK_E_ARG, "null input array");
+    if (n_reads >= (1ull << 32)) return fail(DFK_E_ARG, "more than 2^32-1 reads in one shard");
+    HIP_TRY(hipSetDevice(c->device));
+    c->release_all();
+    c->st = dfk_stats{}; c->peak = 0;
+    Inputs in{(const uint8_t*)d_packed, packed_bytes, (const uint64_t*)d_base_off, (const uint32_t*)d_read_len,
+              (const uint8_t*)d_pq, pq_nbytes, (const uint64_t*)d_pq_off, (const int32_t*)d_bc, n_reads};
+    int rc = run(c, in);
+    if (rc) c->release_all();
+    return rc;
+}
+
+int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const uint32_t* read_len,
+              const uint8_t* pq, const uint64_t* pq_off, const int32_t* bc, uint64_t n_reads)
+{
+    if (!c) return fail(DFK_E_ARG, "null context");
+    if (n_reads && (!packed || !base_off || !read_len || !pq || !pq_off)) return fail(DFK_E_ARG, "null input array");
+    HIP_TRY(hipSetDevice(c->device));
+    c->release_all();
+    const uint64_t pb = n_reads ? base_off[n_reads] : 0, qb = n_reads ? pq_off[n_reads] : 0;
+    // staging copies live outside the context's run allocations (release_all() at the start of a run)
+    void *d_packed = nullptr, *d_boff = nullptr, *d_len = nullptr, *d_pq = nullptr, *d_poff = nullptr, *d_bc = nullptr;
+    Timer t(c->stream);
+    t.start();
+    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes + 64); if (e != hipSuccess) return e;
+        return bytes ? hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    };
+    hipError_t e = up(&d_packed, packed, pb);
+    if (e == hipSuccess) e = up(&d_boff, base_off, (n_reads + 1) * 8);
+    if (e == hipSuccess) e = up(&d_len, read_len, n_reads * 4);
+    if (e == hipSuccess) e = up(&d_pq, pq, qb);
+    if (e == hipSuccess) e = up(&d_poff, pq_off, (n_reads + 1) * 8);
+    if (e == hipSuccess && bc) e = up(&d_bc, bc, n_reads * 4);
+    int rc = 0;
+    if (e != hipSuccess) rc = fail(DFK_E_NOMEM, "uploading inputs: %s", hipGetErrorString(e));
+    float ms_up = t.stop();
+    if (!rc) {
+        uint64_t staged = pb + qb + (n_reads + 1) * 16 + n_reads * 8 + 6 * 64;
+        uint64_t saved = c->budget;
+        c->budget = c->budget > staged ? c->budget - staged : 0;
+        rc = dfk_count_device(c, d_packed, pb, d_boff, d_len, d_pq, qb, d_poff, d_bc, n_reads);
+        c->budget = saved;
+        c->st.ms_upload = ms_up;
+    }
+    (void)hipFree(d_packed); (void)hipFree(d_boff); (void)hipFree(d_len); (void)hipFree(d_pq); (void)hipFree(d_poff); (void)hipFree(d_bc);
+    return rc;
+}
+
+int dfk_good_lens(dfk_ctx* c, uint32_t* out, uint64_t cap)
+{
+    if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    if (cap < c->n_reads) return fail(DFK_E_ARG, "buffer too small");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_reads) HIP_TRY(hipMemcpy(out, c->good_len.p, c->n_reads * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dfk_spectrum(dfk_ctx* c, const int64_t** hist, uint64_t* nbins)
+{
+    if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    *hist = c->hist.data(); *nbins = c->hist.size();
+    return 0;
+}
+
+int dfk_spectrum_json(dfk_ctx* c, char* out, uint64_t cap, uint64_t* need)
+{
+    if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    // WriteHistToJson<int64_t> (10X/MakeHist.cc:67-92) as called from WriteKmerSpectrum
+    std::string s = "{\n\t\"description\": \"kmer_count\",\n\t\"stage\": \"DF\",\n\t\"binsize\": 1,\n\t\"min\": 0,\n";
+    s += "\t\"max\": " + std::to_string((long long)c->hist.size() - 1) + ",\n";
+    s += "\t\"numbins\": " + std::to_string(c->hist.size()) + ",\n\t\"vals\": [";
+    for (size_t i = 0; i < c->hist.size(); ++i) { s += std::to_string(c->hist[i]); if (i + 1 != c->hist.size()) s += ","; }
+    s += "]\n}\n";
+    if (need) *need = s.size();
+    if (out && cap) { size_t n = std::min<size_t>(cap, s.size()); memcpy(out, s.data(), n); if (n < cap) out[n] = 0; }
+    return 0;
+}
+
+int dfk_solid_count(dfk_ctx* c, uint64_t* n)
+{
+    if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    *n = c->n_solid;
+    return 0;
+}
+
+int dfk_solid_fetch(dfk_ctx* c, dfk_entry32* out, uint64_t cap, int pre)
+{
+    if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    if (cap < c->n_solid) return fail(DFK_E_ARG, "buffer too small: %llu < %llu", (unsigned long long)cap, (unsigned long long)c->n_solid);
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<dfk_entry32>* v = nullptr;
+    int rc = fetch_sorted(c, pre != 0, &v); if (rc) return rc;
+    if (!v->empty()) memcpy(out, v->data(), v->size() * 32);
+    return 0;
+}
+
+int dfk_write_kvec(dfk_ctx* c, const char* path, int pre)
+{
+    if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<dfk_entry32>* v = nullptr;
+    int rc = fetch_sorted(c, pre != 0, &v); if (rc) return rc;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(DFK_E_ARG, "cannot open %s", path);
+    uint64_t n = v->size();
+    bool ok = fwrite("BINWRITE", 1, 8, f) == 8 && fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v->data(), 32, n, f) == n);
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : fail(DFK_E_ARG, "short write to %s", path);
+}
+
+int dfk_get_stats(dfk_ctx* c, dfk_stats* out)
+{
+    if (!c || !out) return fail(DFK_E_ARG, "null argument");
+    *out = c->st;
+    return 0;
+}
+
+} // extern "C"
+
+#include "dfk_shard.inc"

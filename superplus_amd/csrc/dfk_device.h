@@ -1,0 +1,100 @@
+// superplus_amd/csrc/dfk_device.h -- device-side helpers shared by the dfk kernels (gfx950).
+//
+// Vocabulary:
+//   instance      one k-mer occurrence emitted by Kmerizer::map (BuildReadQGraph48.cc:148-165)
+//   record        32-byte super-k-mer: a run of <= nk_max consecutive k-mers of one read that
+//                 share a minimizer bucket, with one flanking base each side for contexts
+//   fine bucket   hash of the run's minimum canonical m-mer hash
+//   item          a contiguous range of records (>= 1 fine buckets) counted in one LDS table
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfk {
+
+struct u128 { uint64_t lo, hi; };
+
+__device__ __forceinline__ u128 shr128(u128 x, unsigned s)   // 0 < s < 64
+{ return u128{(x.lo >> s) | (x.hi << (64 - s)), x.hi >> s}; }
+__device__ __forceinline__ u128 shl128(u128 x, unsigned s)   // 0 < s < 64
+{ return u128{x.lo << s, (x.hi << s) | (x.lo >> (64 - s))}; }
+__device__ __forceinline__ bool lt128(u128 a, u128 b)
+{ return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; }
+
+// reverse the order of the 64 two-bit groups of x (bit reversal, then swap bits in each pair)
+__device__ __forceinline__ uint64_t rev2_64(uint64_t x)
+{
+    x = __brevll(x);
+    return ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+}
+
+template <int K> struct KTraits {
+    static constexpr int BITS = 2 * K;                  // 80 / 96 / 120
+    static constexpr int KW = (BITS + 31) / 32;         // key words in the tables: 3 / 3 / 4
+    static constexpr int NK_MAX = 95 - K;               // k-mers per record so that nk+K+1 <= 96 bases
+    __device__ static __forceinline__ u128 mask()
+    { return u128{~0ull, BITS >= 128 ? ~0ull : ((1ull << (BITS - 64)) - 1)}; }
+};
+
+// Canonical form of the k-mer whose bases sit, in read order, in the low 2K bits of `ks`
+// as little-endian 2-bit fields (base i at bits [2i,2i+2)) -- i.e. exactly as the .fastb
+// byte stream stores them (feudal/FieldVec.h:766-770).
+//   F = the k-mer as a 2K-bit big-endian number (base 0 most significant; this is KMer<K>'s
+//       own order, kmers/KMer.h:154-160) = the 2-bit-group reversal of ks
+//   R = its reverse complement in the same order = ~ks (complementing every field of the
+//       little-endian stream IS the reverse complement read big-endian)
+// CF<K>::getForm for even K (dna/CanonicalForm.h:58-67) walks outside-in and decides at the
+// first i with kmer[i] != 3-kmer[K-1-i] = rc[i]; so REV <=> R < F, and a palindrome (R==F)
+// is not REV.  Returns min(F,R); *is_rev = R < F.
+template <int K>
+__device__ __forceinline__ u128 canonical(u128 ks, bool* is_rev)
+{
+    const u128 m = KTraits<K>::mask();
+    u128 R{~ks.lo & m.lo, ~ks.hi & m.hi};
+    u128 rv{rev2_64(ks.hi), rev2_64(ks.lo)};            // 128-bit group reversal: fields now top-aligned
+    u128 F = shr128(rv, 128 - KTraits<K>::BITS);
+    bool rev = lt128(R, F);
+    *is_rev = rev;
+    return rev ? R : F;
+}
+
+// KMerContext::rc (kmers/KMerContext.cc:19-37) = bit reversal of the byte
+__device__ __forceinline__ uint32_t ctx_rc(uint32_t c) { return __brev(c) >> 24; }
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+    return x;
+}
+
+// slot hash of a canonical k-mer (2K-bit value) for the LDS / HBM tables
+__device__ __forceinline__ uint32_t key_hash(u128 c)
+{
+    uint32_t a = (uint32_t)c.lo, b = (uint32_t)(c.lo >> 32), d = (uint32_t)c.hi, e = (uint32_t)(c.hi >> 32);
+    uint32_t h = a ^ __builtin_rotateleft32(b, 11) ^ __builtin_rotateleft32(d, 22) ^ __builtin_rotateleft32(e, 5);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
+    return h;
+}
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)   // ((hi:lo) >> sh) low 32, sh in 0..31
+{ return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
+// wave64 inclusive scan (Hillis-Steele over ds_bpermute shuffles)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// record header (word 0): nk in bits 0-5, has_pred bit 6, has_succ bit 7, fine bucket id in bits 8-31
+__device__ __forceinline__ uint32_t rec_header(uint32_t nk, bool hp, bool hs, uint32_t bucket)
+{ return nk | (hp ? 64u : 0u) | (hs ? 128u : 0u) | (bucket << 8); }
+
+constexpr uint32_t BCW_MULTI = 0x80000000u;   // barcode word: first barcode seen | MULTI once a second distinct one arrives
+constexpr uint32_t CNT_LOCK  = 0x80000000u;   // count word: slot being initialised
+
+} // namespace dfk

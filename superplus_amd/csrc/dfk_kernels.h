@@ -1,0 +1,647 @@
+// superplus_amd/csrc/dfk_kernels.h -- the dfk HIP kernels (gfx950 / CDNA4, wave64).
+// Integer/hash work only: no MFMA anywhere.  See DESIGN.md for the data layout in HBM and
+// the roofline of each kernel.
+#pragma once
+#include "dfk_device.h"
+
+namespace dfk {
+
+// ============================================================================ a1: quality-tail trim
+// One lane per read.  Streams the PQVec blocks forward (feudal/PQVec.cc:87-127 layout) and
+// keeps the end of the right-most run of >= K quals >= min_qual, which is what
+// GoodLenTailFinder finds scanning from the 3' end (BuildReadQGraph48.cc:70-80).
+// Also accumulates the instance total  sum max(0, goodLen-K+1 | goodLen >= K+1)  and
+// flags reads whose PQVec length disagrees with read_len.
+template <int K>
+__global__ void __launch_bounds__(256)
+k_trim(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, const uint32_t* __restrict__ read_len,
+       uint64_t n_reads, uint32_t min_qual, uint32_t* __restrict__ good_len,
+       unsigned long long* __restrict__ n_inst, unsigned int* __restrict__ bad)
+{
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t gl = 0;
+    if (r < n_reads) {
+        uint64_t p = pq_off[r], end = pq_off[r + 1];
+        uint32_t idx = 0, run = 0;
+        bool ok = true;
+        while (p < end) {
+            uint32_t nQs = pq[p];
+            if (!nQs) break;
+            if (p + 3 > end) { ok = false; break; }
+            uint32_t hdr = pq[p + 1] | ((uint32_t)pq[p + 2] << 8);
+            uint32_t nBits = hdr & 7u, minQ = (hdr >> 3) & 63u;
+            uint64_t blk = ((uint64_t)nQs * nBits + 24) >> 3;
+            if (p + blk > end) { ok = false; break; }
+            if (nBits == 0) {
+                if (minQ >= min_qual) { run += nQs; if (run >= (uint32_t)K) gl = idx + nQs; }
+                else run = 0;
+                idx += nQs;
+            } else {
+                uint64_t bit = 8 * (p + 1) + 9;
+                for (uint32_t i = 0; i < nQs; ++i, bit += nBits) {
+                    uint64_t by = bit >> 3;
+                    uint32_t w = pq[by] | ((by + 1 < end) ? ((uint32_t)pq[by + 1] << 8) : 0u);
+                    uint32_t q = minQ + ((w >> (bit & 7)) & ((1u << nBits) - 1));
+                    if (q < min_qual) run = 0;
+                    else if (++run >= (uint32_t)K) gl = idx + 1;
+                    ++idx;
+                }
+            }
+            p += blk;
+        }
+        uint32_t rl = read_len[r];
+        if (!ok || idx != rl) { atomicOr(bad, 1u); gl = 0; }
+        if (gl > rl) gl = rl;
+        good_len[r] = gl;
+    }
+    // instance total: wave reduce, one atomic per wave
+    unsigned long long mine = gl >= (uint32_t)K + 1 ? (unsigned long long)(gl - K + 1) : 0ull;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_inst, mine);
+}
+
+// ============================================================================ a2 (first half): super-k-mer partition
+// One lane per read.  For every k-mer position s the fine bucket is a hash of the minimum
+// canonical-m-mer hash over the k-mer's W = K-M+1 m-mers (a property of the canonical k-mer:
+// a k-mer and its reverse complement hold the same canonical m-mers).  The sliding minimum
+// uses the block prefix/suffix scheme so every lane does the same work per base (no
+// data-dependent rescans, which a wave would pay for on every step): m-mer positions are cut
+// into blocks of W; `arr` (LDS, W words per lane, lane-minor so it is conflict-free) holds
+// the suffix minima of the previous block and is overwritten in place with the hashes of the
+// current one.
+//   WRITE == false: add (1<<32 | nk) to bucket_acc[bucket] per record (records and instances
+//                   per fine bucket).
+//   WRITE == true : records are queued per lane (LDS) and written after the scan: 32 bytes =
+//                   {header, barcode, 192 bits of the read's own 2-bit stream starting one base
+//                   before the run}.
+struct PartParams {
+    uint32_t M;            // minimizer length (<= 16)
+    uint32_t W;            // K - M + 1
+    uint32_t log2_nb;      // fine buckets = 1 << log2_nb
+    uint32_t log2_world;   // fine buckets are laid out owner-major: owner rank = bucket & (world-1)
+};
+
+constexpr int PART_THREADS = 256;
+constexpr int PART_QCAP = 8;          // queued records per lane before an early flush
+
+template <int K>
+__device__ __forceinline__ void emit_record(const uint32_t* __restrict__ words, uint64_t n_words, uint64_t bit0,
+                                            uint32_t s0, uint32_t nk, uint32_t bucket, uint32_t gl, int32_t tag,
+                                            uint64_t dst_index, uint4* __restrict__ records)
+{
+    const bool hp = s0 > 0;
+    const bool hs = s0 + nk + (uint32_t)K <= gl;
+    // bases [s0-1, s0+nk+K) of the read (slot 0 is a dummy when the run starts the read)
+    uint64_t bo = bit0 + 2ull * (hp ? s0 - 1 : 0);
+    uint64_t wi = bo >> 5; uint32_t sh = (uint32_t)bo & 31u;
+    uint32_t w[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) w[i] = (wi + i < n_words) ? words[wi + i] : 0u;
+    uint32_t o[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = alignbit(w[i + 1], w[i], sh);
+    if (!hp) {   // shift the stream up one base; dummy predecessor = 0
+#pragma unroll
+        for (int i = 5; i > 0; --i) o[i] = (o[i] << 2) | (o[i - 1] >> 30);
+        o[0] <<= 2;
+    }
+    uint32_t nbits = 2u * (1u + nk + (uint32_t)K - 1u + (hs ? 1u : 0u));   // <= 192
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        uint32_t lo = 32u * i;
+        if (nbits <= lo) o[i] = 0;
+        else if (nbits < lo + 32u) o[i] &= (1u << (nbits - lo)) - 1u;
+    }
+    uint4 a{rec_header(nk, hp, hs, bucket), (uint32_t)tag, o[0], o[1]};
+    uint4 b{o[2], o[3], o[4], o[5]};
+    records[2 * dst_index] = a;
+    records[2 * dst_index + 1] = b;
+}
+
+template <int K, bool WRITE>
+__global__ void __launch_bounds__(PART_THREADS)
+k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
+            const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
+            uint64_t n_reads, PartParams pp,
+            unsigned long long* __restrict__ bucket_acc,      // !WRITE: per fine bucket (records<<32 | instances)
+            const uint64_t* __restrict__ bucket_base,         // WRITE: first record index of each fine bucket
+            uint32_t* __restrict__ bucket_cur,                // WRITE: append cursors
+            uint4* __restrict__ records)
+{
+    extern __shared__ uint32_t smem[];
+    uint32_t* arr = smem;                                        // [W][PART_THREADS]
+    uint32_t* queue = smem + pp.W * PART_THREADS;                // WRITE: [PART_QCAP][2][PART_THREADS]
+    const int tid = threadIdx.x;
+    const uint64_t r = (uint64_t)blockIdx.x * PART_THREADS + tid;
+    const uint32_t M = pp.M, W = pp.W;
+    const uint32_t gl = r < n_reads ? good_len[r] : 0;
+    if (gl < (uint32_t)K + 1) return;                            // Kmerizer::map: len < K+1 emits nothing (:153)
+
+    const uint64_t byte0 = base_off[r];
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);   // hipMalloc'd: 4-byte aligned base
+    const uint64_t n_words = (packed_bytes + 3) >> 2;
+    const uint64_t bit0 = byte0 * 8;                             // bit offset of base 0 in the word stream
+    int32_t tag = -1;                                            // :150-151
+    if (bc && (int64_t)r >= ign_bc_below) tag = bc[r];
+
+    const uint32_t mmask = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * M)) - 1u);
+    const uint32_t rsh = 2 * (M - 1);
+    const uint32_t bshift = 32 - pp.log2_nb;
+    uint32_t f = 0, rc = 0;                 // forward / reverse-complement m-mer, big-endian
+    uint32_t P = 0;                          // prefix minimum inside the current block
+    uint32_t bi = 0;                         // index inside the current block of m-mer positions
+    uint32_t cur_b = 0, cur_s0 = 0, cur_nk = 0;
+    uint32_t qn = 0;
+
+    uint64_t wi = bit0 >> 5;
+    uint32_t wbits = wi < n_words ? words[wi] : 0u;
+    uint32_t wpos = (uint32_t)bit0 & 31u;
+
+    auto close_run = [&]() {
+        if (!WRITE) {
+            atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
+        } else {
+            if (qn == PART_QCAP) {        // rare: flush early
+                for (uint32_t e = 0; e < qn; ++e) {
+                    uint32_t a = queue[(2 * e) * PART_THREADS + tid], b = queue[(2 * e + 1) * PART_THREADS + tid];
+                    uint32_t slot = atomicAdd(&bucket_cur[b], 1u);
+                    emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, bucket_base[b] + slot, records);
+                }
+                qn = 0;
+            }
+            queue[(2 * qn) * PART_THREADS + tid] = cur_s0 | (cur_nk << 16);
+            queue[(2 * qn + 1) * PART_THREADS + tid] = cur_b;
+            ++qn;
+        }
+    };
+
+    for (uint32_t j = 0; j < gl; ++j) {
+        uint32_t b = (wbits >> wpos) & 3u;
+        wpos += 2;
+        if (wpos == 32) { wpos = 0; ++wi; wbits = wi < n_words ? words[wi] : 0u; }
+        f = ((f << 2) | b) & mmask;
+        rc = (rc >> 2) | ((3u - b) << rsh);
+        if (j + 1 < M) continue;
+        uint32_t h = mix32(f < rc ? f : rc);
+        P = bi == 0 ? h : (h < P ? h : P);
+        const uint32_t t = j + 1 - M;                           // m-mer position
+        if (t + 1 >= W) {                                        // k-mer s = t-W+1 is complete
+            uint32_t mv = P;
+            if (bi != W - 1) { uint32_t sfx = arr[(bi + 1) * PART_THREADS + tid]; mv = sfx < mv ? sfx : mv; }
+            const uint32_t s = t + 1 - W;
+            uint32_t bucket = (mv * 0x9E3779B1u) >> bshift;
+            // owner-major position: all fine buckets of one owner rank are contiguous
+            bucket = ((bucket & ((1u << pp.log2_world) - 1u)) << (pp.log2_nb - pp.log2_world)) | (bucket >> pp.log2_world);
+            if (s == 0) { cur_b = bucket; cur_s0 = 0; cur_nk = 1; }
+            else if (bucket != cur_b || cur_nk == (uint32_t)KTraits<K>::NK_MAX) {
+                close_run();
+                cur_b = bucket; cur_s0 = s; cur_nk = 1;
+            } else ++cur_nk;
+        }
+        arr[bi * PART_THREADS + tid] = h;
+        if (++bi == W) {                                         // block complete: turn it into suffix minima
+            uint32_t run = h;
+            for (int i = (int)W - 2; i >= 0; --i) {
+                uint32_t v = arr[i * PART_THREADS + tid];
+                run = v < run ? v : run;
+                arr[i * PART_THREADS + tid] = run;
+            }
+            bi = 0;
+        }
+    }
+    close_run();
+    if (WRITE) {
+        for (uint32_t e = 0; e < qn; ++e) {
+            uint32_t a = queue[(2 * e) * PART_THREADS + tid], b = queue[(2 * e + 1) * PART_THREADS + tid];
+            uint32_t slot = atomicAdd(&bucket_cur[b], 1u);
+            emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, bucket_base[b] + slot, records);
+        }
+    }
+}
+
+// ============================================================================ a2 (second half) + a3 + a4 + a5: count
+// A work item is a contiguous range of records.  One workgroup counts one item at a time in
+// an open-addressing table: KW key words + count + context + barcode word per slot, SoA.
+// Each wave takes 64 records at a time, stages them in its private LDS area, maps the
+// item's k-mer instances densely onto lanes (bitmask of run starts + popcount rank), rebuilds
+// each instance's canonical k-mer and context from the staged 2-bit stream and inserts it.
+// After the item, solid slots are compacted to the output and the spectrum is updated.
+
+struct CountItem { uint64_t rec_begin; uint64_t rec_end; };
+
+struct CountParams {
+    uint32_t min_freq, min_bc;
+    uint32_t use_bc;                 // 0: no barcode test at all
+    uint32_t n_items;
+    uint64_t solid_cap;              // entries
+    uint32_t hist_lds_bins;          // = COUNT_HIST_BINS
+};
+
+struct CountGlobals {                // device-resident counters
+    unsigned long long n_solid;      // entries written
+    unsigned long long n_distinct;
+    unsigned int next_item;
+    unsigned int n_overflow;         // items that overflowed their table
+    unsigned int solid_overflow;     // output capacity exceeded
+    unsigned int pad;
+};
+
+constexpr int COUNT_HIST_BINS = 1024;
+constexpr uint32_t COUNT_MAX_PROBE = 96;
+constexpr uint32_t HIST_GLOBAL_BINS = 1u << 24;   // KDef count saturates at 2^24-1 (ReadPather.h:128-129)
+
+template <int K> struct WaveStage {               // per-wave private LDS
+    uint32_t rec[64 * 8 + 8];                     // staged records (+ pad for the 5-word window read)
+    uint32_t starts[64];                          // first instance index of each record
+    uint32_t msk[128];                            // bit t set <=> instance t starts a record
+    uint32_t pc[128];                             // exclusive popcount prefix of msk words
+};
+
+// Table words are read and written with relaxed agent-scope atomics: for the LDS table these
+// are plain ds_read/ds_write; for the HBM fallback table they bypass the CU's L1, which other
+// waves' stores and atomics do not update (MI355X_MICROARCH.md, inter-workgroup visibility).
+__device__ __forceinline__ uint32_t tld(const uint32_t* p)
+{ return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tst(uint32_t* p, uint32_t v)
+{ __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One insertion.  `c` = canonical 2K-bit value, ctx = context byte, tag = barcode.
+// Returns false if the table is (nearly) full.
+template <int KW, bool USE_BC>
+__device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
+                                             uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw,
+                                             uint32_t S, u128 c, uint32_t ctx, int32_t tag, uint32_t* n_fill)
+{
+    const uint32_t k0 = (uint32_t)c.lo, k1 = (uint32_t)(c.lo >> 32), k2 = (uint32_t)c.hi, k3 = (uint32_t)(c.hi >> 32);
+    uint32_t slot = key_hash(c) & (S - 1);
+    uint32_t probes = 0;
+    bool done = false, ok = true;
+    while (!done) {
+        uint32_t expect = 0;
+        bool won = __hip_atomic_compare_exchange_strong(&cnt[slot], &expect, CNT_LOCK, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+        if (won) {
+            tst(&keys[slot], k0); tst(&keys[S + slot], k1); tst(&keys[2 * S + slot], k2);
+            if (KW == 4) tst(&keys[3 * S + slot], k3);
+            tst(&ctxs[slot], ctx);
+            if (USE_BC) tst(&bcw[slot], tag > 0 ? (uint32_t)tag : (tag == -1 ? BCW_MULTI : 0u));
+            __hip_atomic_store(&cnt[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(n_fill, 1u);
+            done = true;
+        } else if (expect != CNT_LOCK) {
+            bool same = tld(&keys[slot]) == k0 && tld(&keys[S + slot]) == k1 && tld(&keys[2 * S + slot]) == k2;
+            if (KW == 4) same = same && tld(&keys[3 * S + slot]) == k3;
+            if (same) {
+                atomicAdd(&cnt[slot], 1u);
+                if ((tld(&ctxs[slot]) & ctx) != ctx) atomicOr(&ctxs[slot], ctx);
+                if (USE_BC) {
+                    uint32_t v = tld(&bcw[slot]);
+                    if (!(v & BCW_MULTI)) {
+                        if (tag == -1) atomicOr(&bcw[slot], BCW_MULTI);
+                        else if (tag > 0) {
+                            uint32_t old = atomicCAS(&bcw[slot], 0u, (uint32_t)tag);
+                            if (old != 0u && old != (uint32_t)tag && !(old & BCW_MULTI)) atomicOr(&bcw[slot], BCW_MULTI);
+                        }
+                    }
+                }
+                done = true;
+            } else {
+                slot = (slot + 1) & (S - 1);
+                if (++probes > COUNT_MAX_PROBE) { ok = false; done = true; }
+            }
+        }
+        // expect == CNT_LOCK: another lane is initialising this slot; it finishes inside its own
+        // iteration of this same loop, so simply try the slot again.
+    }
+    return ok;
+}
+
+// Rebuild instance q of a staged record and insert it.
+template <int K, bool USE_BC>
+__device__ __forceinline__ bool insert_instance(const uint32_t* __restrict__ rec /* 8 words of the record */, uint32_t q,
+                                                uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
+                                                uint32_t S, uint32_t* n_fill)
+{
+    const uint32_t hdr = rec[0];
+    const int32_t tag = (int32_t)rec[1];
+    const uint32_t nk = hdr & 63u;
+    // bits [2q, 2q + 2(K+2)) of the payload: pred, K bases, succ
+    const uint32_t wi = q >> 4, sh = (2u * q) & 31u;
+    const uint32_t* p = rec + 2 + wi;
+    uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
+    uint32_t x0 = alignbit(p1, p0, sh), x1 = alignbit(p2, p1, sh), x2 = alignbit(p3, p2, sh), x3 = alignbit(p4, p3, sh);
+    u128 X{(uint64_t)x0 | ((uint64_t)x1 << 32), (uint64_t)x2 | ((uint64_t)x3 << 32)};
+    const uint32_t pred = x0 & 3u;
+    u128 ks = shr128(X, 2);
+    constexpr int SB = 2 * K + 2;                                   // bit position of the successor base
+    const uint32_t succ = (uint32_t)(SB >= 64 ? (X.hi >> (SB - 64)) : (X.lo >> SB)) & 3u;
+    bool rev;
+    u128 c = canonical<K>(ks, &rev);
+    // KMerContext(pred,succ) / initialContext / finalContext (kmers/KMerContext.h:27-28,91-95)
+    uint32_t ctx = 0;
+    if (q > 0 || (hdr & 64u)) ctx |= 0x10u << pred;
+    if (q + 1 < nk || (hdr & 128u)) ctx |= 1u << succ;
+    if (rev) ctx = ctx_rc(ctx);
+    return table_insert<KTraits<K>::KW, USE_BC>(keys, cnt, ctxs, bcw, S, c, ctx, tag, n_fill);
+}
+
+// Count all records [rb,re) with the calling wave (wave-synchronous; no block barriers).
+template <int K, bool USE_BC>
+__device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
+                                                 WaveStage<K>* __restrict__ st, int lane,
+                                                 uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
+                                                 uint32_t S, uint32_t* n_fill, uint32_t* overflow)
+{
+    const uint64_t ridx = rb + lane;
+    const bool valid = ridx < re;
+    uint4 a{0, 0, 0, 0}, b{0, 0, 0, 0};
+    if (valid) { a = records[2 * ridx]; b = records[2 * ridx + 1]; }
+    const uint32_t nk = a.x & 63u;
+    reinterpret_cast<uint4*>(st->rec)[2 * lane] = a;
+    reinterpret_cast<uint4*>(st->rec)[2 * lane + 1] = b;
+    const uint32_t incl = wave_incl_scan(nk, lane);
+    const uint32_t start = incl - nk;
+    const uint32_t total = __shfl(incl, 63, 64);
+    st->starts[lane] = start;
+    st->msk[lane] = 0; st->msk[lane + 64] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (nk) atomicOr(&st->msk[start >> 5], 1u << (start & 31u));
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t c0 = __popc(st->msk[2 * lane]), c1 = __popc(st->msk[2 * lane + 1]);
+    const uint32_t ex = wave_incl_scan(c0 + c1, lane) - (c0 + c1);
+    st->pc[2 * lane] = ex; st->pc[2 * lane + 1] = ex + c0;
+    __builtin_amdgcn_wave_barrier();
+    bool ok = true;
+    for (uint32_t t = lane; t < total; t += 64) {
+        const uint32_t w = t >> 5;
+        const uint32_t bits = st->msk[w] & (0xFFFFFFFFu >> (31u - (t & 31u)));
+        const uint32_t r = st->pc[w] + __popc(bits) - 1u;
+        const uint32_t q = t - st->starts[r];
+        ok = insert_instance<K, USE_BC>(st->rec + 8 * r, q, keys, cnt, ctxs, bcw, S, n_fill) && ok;
+    }
+    if (!ok) atomicOr(overflow, 1u);
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool USE_BC>
+__device__ __forceinline__ bool bc_pass(uint32_t v, uint32_t min_bc)
+{
+    if (!USE_BC || min_bc == 0) return true;
+    if (min_bc == 1) return v != 0;
+    return (v & BCW_MULTI) != 0;                                     // >= 2 distinct barcodes > 0, or an ignored (-1) one
+}
+
+// Emit the solid slots of a finished table: entries to `out`, counts to the spectrum.
+template <int K, bool USE_BC, bool LDS_HIST>
+__device__ __forceinline__ void table_emit(const uint32_t* keys, const uint32_t* cnt, const uint32_t* ctxs, const uint32_t* bcw,
+                                           uint32_t S, const CountParams& cp, CountGlobals* g, uint4* __restrict__ out,
+                                           uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
+                                           int tid, int nthreads)
+{
+    const int lane = tid & 63;
+    for (uint32_t base = 0; base < S; base += nthreads) {
+        const uint32_t slot = base + tid;
+        uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
+        uint32_t count = c > 0xFFFFFFu ? 0xFFFFFFu : c;               // KDef::setCount saturation (ReadPather.h:128-129)
+        bool solid = c != 0 && count >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&bcw[slot]) : 0u, cp.min_bc);
+        unsigned long long occ = __ballot(c != 0);
+        unsigned long long m = __ballot(solid);
+        uint32_t n = __popcll(m);
+        unsigned long long wbase = 0;
+        if (lane == 0) {
+            if (occ) atomicAdd(&g->n_distinct, (unsigned long long)__popcll(occ));
+            if (n) wbase = atomicAdd(&g->n_solid, (unsigned long long)n);
+        }
+        wbase = __shfl(wbase, 0, 64);
+        if (solid) {
+            unsigned long long idx = wbase + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < cp.solid_cap) {
+                u128 v{(uint64_t)tld(&keys[slot]) | ((uint64_t)tld(&keys[S + slot]) << 32),
+                       (uint64_t)tld(&keys[2 * S + slot]) | (KTraits<K>::KW == 4 ? ((uint64_t)tld(&keys[3 * S + slot]) << 32) : 0ull)};
+                u128 kw = shl128(v, 128 - KTraits<K>::BITS);           // left-align: KMer<K> storage
+                uint32_t cc = count | (tld(&ctxs[slot]) << 24);
+                out[2 * idx] = uint4{(uint32_t)kw.hi, (uint32_t)(kw.hi >> 32), (uint32_t)kw.lo, (uint32_t)(kw.lo >> 32)};
+                out[2 * idx + 1] = uint4{0xFFFFFFFFu, cc, 0xFFFFFFFFu, 0u};
+            } else atomicOr(&g->solid_overflow, 1u);
+            if (LDS_HIST && count < (uint32_t)COUNT_HIST_BINS) atomicAdd(&hist_lds[count], 1u);
+            else atomicAdd(&hist_global[count], 1ull);
+        }
+    }
+}
+
+template <int K, int LOG2S, int NWAVES, bool USE_BC>
+__global__ void __launch_bounds__(NWAVES * 64)
+k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, CountParams cp,
+        CountGlobals* __restrict__ g, uint4* __restrict__ out, unsigned long long* __restrict__ hist_global,
+        uint32_t* __restrict__ overflow_items)
+{
+    constexpr uint32_t S = 1u << LOG2S;
+    constexpr int KW = KTraits<K>::KW;
+    constexpr int NT = NWAVES * 64;
+    extern __shared__ __align__(16) uint32_t smem[];
+    uint32_t* keys = smem;                          // [KW][S]
+    uint32_t* cnt = keys + KW * S;                  // [S]
+    uint32_t* ctxs = cnt + S;                       // [S]
+    uint32_t* bcw = ctxs + S;                       // [S]
+    uint32_t* hist = bcw + S;                       // [COUNT_HIST_BINS]
+    uint32_t* ctl = hist + COUNT_HIST_BINS;         // [4]: item, overflow, n_fill
+    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(ctl + 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WaveStage<K>* st = stages + wave;
+
+    for (int i = tid; i < COUNT_HIST_BINS; i += NT) hist[i] = 0;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) { ctl[0] = atomicAdd(&g->next_item, 1u); ctl[1] = 0; ctl[2] = 0; }
+        for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;         // cnt, ctxs, bcw are contiguous
+        __syncthreads();
+        const uint32_t item = ctl[0];
+        if (item >= cp.n_items) break;
+        const uint64_t rb = items[item].rec_begin, re = items[item].rec_end;
+        for (uint64_t c = rb + 64ull * wave; c < re; c += 64ull * NWAVES) {
+            if (tld(&ctl[1])) break;
+            wave_count_chunk<K, USE_BC>(records, c, re, st, lane, keys, cnt, ctxs, bcw, S, &ctl[2], &ctl[1]);
+            if (lane == 0 && tld(&ctl[2]) > (S / 4) * 3) tst(&ctl[1], 1u);   // stop early when the table is 3/4 full
+        }
+        __syncthreads();
+        if (ctl[1]) {
+            if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = item;
+        } else {
+            table_emit<K, USE_BC, true>(keys, cnt, ctxs, bcw, S, cp, g, out, hist, hist_global, tid, NT);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < COUNT_HIST_BINS; i += NT) if (hist[i]) atomicAdd(&hist_global[i], (unsigned long long)hist[i]);
+}
+
+template <int K, int LOG2S, int NWAVES>
+constexpr size_t count_lds_bytes()
+{
+    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + 4) + sizeof(WaveStage<K>) * NWAVES;
+}
+
+// Fallback: one workgroup per overflowed item, table in HBM (tab = [KW+3][S] words, zeroed by
+// the host), staging still in LDS.  Same insertion code; atomics resolve to global memory.
+struct BigItem { uint64_t rec_begin, rec_end; uint64_t tab_off; uint32_t log2s; uint32_t pad; };
+
+template <int K, int NWAVES, bool USE_BC>
+__global__ void __launch_bounds__(NWAVES * 64)
+k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items, CountParams cp,
+            CountGlobals* __restrict__ g, uint4* __restrict__ out, unsigned long long* __restrict__ hist_global,
+            uint32_t* __restrict__ tab_pool, uint32_t* __restrict__ failed)
+{
+    constexpr int KW = KTraits<K>::KW;
+    constexpr int NT = NWAVES * 64;
+    __shared__ WaveStage<K> stages[NWAVES];
+    __shared__ uint32_t ctl[4];
+    const BigItem it = items[blockIdx.x];
+    const uint32_t S = 1u << it.log2s;
+    uint32_t* keys = tab_pool + it.tab_off;
+    uint32_t* cnt = keys + (size_t)KW * S;
+    uint32_t* ctxs = cnt + S;
+    uint32_t* bcw = ctxs + S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { ctl[1] = 0; ctl[2] = 0; }
+    __syncthreads();
+    for (uint64_t c = it.rec_begin + 64ull * wave; c < it.rec_end; c += 64ull * NWAVES)
+        wave_count_chunk<K, USE_BC>(records, c, it.rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[2], &ctl[1]);
+    __threadfence();
+    __syncthreads();
+    if (ctl[1]) { if (tid == 0) atomicOr(failed, 1u); return; }
+    table_emit<K, USE_BC, false>(keys, cnt, ctxs, bcw, S, cp, g, out, nullptr, hist_global, tid, NT);
+}
+
+// ============================================================================ a6: adjacency clean-up
+// KmerDict::recomputeAdjacencies (ReadPather.h:329-364): a context bit survives only if the
+// neighbouring canonical k-mer is itself solid.  The solid set is put in an HBM open-addressing
+// set (16-byte keys, empty = w0 all ones, which no canonical k-mer can have), then every solid
+// entry probes its <= 8 neighbours.
+struct SetSlot { uint64_t w0, w1; };
+
+__device__ __forceinline__ uint64_t set_hash(uint64_t w0, uint64_t w1)
+{
+    uint64_t h = w0 * 0x9E3779B97F4A7C15ull ^ (w1 + 0x7F4A7C159E3779B9ull) * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29;
+    return h;
+}
+
+__global__ void __launch_bounds__(256)
+k_set_insert(const uint4* __restrict__ entries, uint64_t n, SetSlot* __restrict__ set, uint64_t mask)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 a = entries[2 * i];
+    uint64_t w0 = (uint64_t)a.x | ((uint64_t)a.y << 32), w1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    uint64_t s = set_hash(w0, w1) & mask;
+    for (;;) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&set[s].w0), ~0ull, (unsigned long long)w0);
+        if (old == ~0ull) { set[s].w1 = w1; return; }
+        s = (s + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ bool set_has(const SetSlot* __restrict__ set, uint64_t mask, uint64_t w0, uint64_t w1)
+{
+    uint64_t s = set_hash(w0, w1) & mask;
+    for (;;) {
+        SetSlot v = set[s];
+        if (v.w0 == ~0ull) return false;
+        if (v.w0 == w0 && v.w1 == w1) return true;
+        s = (s + 1) & mask;
+    }
+}
+
+// canonical left-aligned (w0,w1) of a k-mer given as a 2K-bit big-endian value
+template <int K>
+__device__ __forceinline__ void canon_words(u128 F, uint64_t* w0, uint64_t* w1)
+{
+    // reverse complement of a big-endian value: group-reverse the complement
+    const u128 m = KTraits<K>::mask();
+    u128 nf{~F.lo & m.lo, ~F.hi & m.hi};
+    u128 top = shl128(nf, 128 - KTraits<K>::BITS);
+    u128 R{rev2_64(top.hi), rev2_64(top.lo)};
+    u128 c = lt128(R, F) ? R : F;
+    u128 kw = shl128(c, 128 - KTraits<K>::BITS);
+    *w0 = kw.hi; *w1 = kw.lo;
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_adjacency(uint4* __restrict__ entries, uint64_t n, const SetSlot* __restrict__ set, uint64_t mask,
+            unsigned long long* __restrict__ n_probes)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long probes = 0;
+    if (i < n) {
+        uint4 a = entries[2 * i], b = entries[2 * i + 1];
+        u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
+        u128 F = shr128(kw, 128 - KTraits<K>::BITS);                  // 2K-bit big-endian value
+        const u128 m = KTraits<K>::mask();
+        uint32_t ctx = b.y >> 24;
+        if (ctx & 0x0Fu) {
+            u128 sx = shl128(F, 2); sx.lo &= m.lo; sx.hi &= m.hi;     // kmer.toSuccessor(0)
+            for (uint32_t c = 0; c < 4; ++c) if (ctx & (1u << c)) {
+                uint64_t w0, w1; canon_words<K>(u128{sx.lo | c, sx.hi}, &w0, &w1);
+                ++probes;
+                if (!set_has(set, mask, w0, w1)) ctx &= ~(1u << c);
+            }
+        }
+        if (ctx & 0xF0u) {
+            u128 px = shr128(F, 2);                                   // kmer.toPredecessor(0)
+            constexpr int TOP = KTraits<K>::BITS - 2;
+            for (uint32_t c = 0; c < 4; ++c) if (ctx & (0x10u << c)) {
+                u128 v = px;
+                if (TOP >= 64) v.hi |= (uint64_t)c << (TOP - 64); else v.lo |= (uint64_t)c << TOP;
+                uint64_t w0, w1; canon_words<K>(v, &w0, &w1);
+                ++probes;
+                if (!set_has(set, mask, w0, w1)) ctx &= ~(0x10u << c);
+            }
+        }
+        b.y = (b.y & 0xFFFFFFu) | (ctx << 24);
+        entries[2 * i + 1] = b;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) probes += __shfl_down(probes, d, 64);
+    if ((threadIdx.x & 63) == 0 && probes) atomicAdd(n_probes, probes);
+}
+
+// ============================================================================ multi-GPU: regroup received records
+// After the all-to-all a rank holds the records it owns from every peer, in arrival order.
+// Items must be ranges of whole fine buckets, so scatter them once more by the fine bucket id
+// kept in the header (pure 32-byte record moves).
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_regroup(const uint4* __restrict__ in, uint64_t n, uint32_t local_mask, unsigned long long* __restrict__ bucket_acc,
+          const uint64_t* __restrict__ bucket_base, uint32_t* __restrict__ bucket_cur, uint4* __restrict__ out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 a = in[2 * i];
+    uint32_t b = (a.x >> 8) & local_mask;
+    if (!WRITE) atomicAdd(&bucket_acc[b], (1ull << 32) | (a.x & 63u));
+    else {
+        uint64_t dst = bucket_base[b] + atomicAdd(&bucket_cur[b], 1u);
+        out[2 * dst] = a; out[2 * dst + 1] = in[2 * i + 1];
+    }
+}
+
+// ============================================================================ small utilities
+__global__ void k_fill_u64(uint64_t* p, uint64_t n, uint64_t v)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// highest non-zero bin of the spectrum
+__global__ void k_hist_max(const unsigned long long* __restrict__ hist, uint32_t n, unsigned int* __restrict__ maxbin)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t best = 0;
+    for (; i < n; i += stride) if (hist[i]) best = i + 1;
+    if (best) atomicMax(maxbin, best);
+}
+
+} // namespace dfk

@@ -1,0 +1,163 @@
+"""ctypes binding of libdfk.so (include/dfk.h) -- the host-side mirror used by tests, bench.py
+and the multi-GPU driver.  The library is HIP-only: if it cannot be loaded, or no gfx950
+device is usable, everything here raises; there is no CPU fallback.
+
+Reference interface mirrored: createDict(work_dir, reads, quals, minQual, minFreq,
+ignBcBelow, mem_frac, minBC, bcp) -- lib/assembly/src/paths/long/BuildReadQGraph48.cc:211-215.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfk.so")
+ABI_VERSION = 1
+F_KEEP_PRE_ADJ = 1
+
+ENTRY_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("edge_id", "<u4"), ("count_ctx", "<u4"),
+                        ("bc", "<i4"), ("pad", "<u4")])
+
+EXPORTS = [
+    "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_device",
+    "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch",
+    "dfk_write_kvec", "dfk_get_stats", "dfk_shard_partition", "dfk_shard_count", "dfk_shard_adj_queries",
+    "dfk_shard_adj_answer", "dfk_shard_adj_apply",
+]
+
+
+class DfkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dfk error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("K", C.c_uint32), ("min_qual", C.c_uint32), ("min_freq", C.c_uint32),
+                ("min_bc", C.c_uint32), ("device", C.c_int32), ("ign_bc_below", C.c_int64),
+                ("hbm_budget_bytes", C.c_uint64), ("minimizer_len", C.c_uint32), ("flags", C.c_uint32),
+                ("inst_per_item", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_inst", C.c_uint64), ("n_records", C.c_uint64), ("n_buckets", C.c_uint64),
+                ("n_items", C.c_uint64), ("n_overflow_items", C.c_uint64), ("n_distinct", C.c_uint64),
+                ("n_solid", C.c_uint64), ("adj_probes", C.c_uint64),
+                ("ms_upload", C.c_float), ("ms_trim", C.c_float), ("ms_part_count", C.c_float),
+                ("ms_part_scatter", C.c_float), ("ms_count", C.c_float), ("ms_fallback", C.c_float),
+                ("ms_adjacency", C.c_float), ("ms_total", C.c_float),
+                ("hbm_bytes_peak", C.c_uint64), ("reserved", C.c_uint64 * 8)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_lib = None
+
+
+def build():
+    """Compile libdfk.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DfkError(-2, f"{LIB_PATH} is missing: run `make -C superplus_amd/csrc` (hipcc, gfx950). "
+                               "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.dfk_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise DfkError(rc, lib().dfk_last_error().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Dfk:
+    """One context on one GPU.  count(...) takes numpy host arrays; count_device(...) takes
+    torch tensors already on this context's device."""
+
+    def __init__(self, K=48, min_qual=7, min_freq=3, min_bc=2, ign_bc_below=0, device=0, hbm_budget_bytes=0,
+                 minimizer_len=0, keep_pre_adjacency=False, inst_per_item=0):
+        cfg = Config(abi_version=ABI_VERSION, K=K, min_qual=min_qual, min_freq=min_freq, min_bc=min_bc, device=device,
+                     ign_bc_below=ign_bc_below, hbm_budget_bytes=hbm_budget_bytes, minimizer_len=minimizer_len,
+                     flags=F_KEEP_PRE_ADJ if keep_pre_adjacency else 0, inst_per_item=inst_per_item)
+        self._ctx = C.c_void_p()
+        _check(lib().dfk_create(C.byref(cfg), C.byref(self._ctx)))
+        self.K = K
+
+    def close(self):
+        if self._ctx:
+            lib().dfk_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def count(self, packed, base_off, read_len, pq_bytes, pq_off, bc):
+        packed = np.ascontiguousarray(packed, np.uint8); base_off = np.ascontiguousarray(base_off, np.uint64)
+        read_len = np.ascontiguousarray(read_len, np.uint32); pq_bytes = np.ascontiguousarray(pq_bytes, np.uint8)
+        pq_off = np.ascontiguousarray(pq_off, np.uint64)
+        bc = None if bc is None else np.ascontiguousarray(bc, np.int32)
+        _check(lib().dfk_count(self._ctx, _p(packed), _p(base_off), _p(read_len), _p(pq_bytes), _p(pq_off), _p(bc),
+                               C.c_uint64(len(read_len))))
+
+    def count_device(self, packed, base_off, read_len, pq_bytes, pq_off, bc):
+        """torch tensors on the GPU: packed u8, base_off i64[n+1], read_len i32[n], pq_bytes u8,
+        pq_off i64[n+1], bc i32[n] or None."""
+        def dp(t):
+            return C.c_void_p(0 if t is None else t.data_ptr())
+        for t in (packed, base_off, read_len, pq_bytes, pq_off):
+            assert t.is_cuda and t.is_contiguous()
+        _check(lib().dfk_count_device(self._ctx, dp(packed), C.c_uint64(packed.numel()), dp(base_off), dp(read_len),
+                                      dp(pq_bytes), C.c_uint64(pq_bytes.numel()), dp(pq_off), dp(bc),
+                                      C.c_uint64(read_len.numel())))
+
+    def good_lens(self):
+        n = self.stats()["n_reads"]
+        out = np.zeros(n, np.uint32)
+        _check(lib().dfk_good_lens(self._ctx, _p(out), C.c_uint64(n)))
+        return out
+
+    def spectrum(self):
+        h = C.POINTER(C.c_int64)(); n = C.c_uint64()
+        _check(lib().dfk_spectrum(self._ctx, C.byref(h), C.byref(n)))
+        return np.ctypeslib.as_array(h, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64)
+
+    def spectrum_json(self):
+        need = C.c_uint64()
+        _check(lib().dfk_spectrum_json(self._ctx, None, C.c_uint64(0), C.byref(need)))
+        buf = C.create_string_buffer(need.value + 1)
+        _check(lib().dfk_spectrum_json(self._ctx, buf, C.c_uint64(need.value + 1), C.byref(need)))
+        return buf.raw[: need.value].decode()
+
+    def solid_count(self):
+        n = C.c_uint64()
+        _check(lib().dfk_solid_count(self._ctx, C.byref(n)))
+        return n.value
+
+    def solid(self, pre_adjacency=False):
+        n = self.solid_count()
+        out = np.zeros(n, dtype=ENTRY_DTYPE)
+        _check(lib().dfk_solid_fetch(self._ctx, _p(out), C.c_uint64(n), C.c_int(1 if pre_adjacency else 0)))
+        return out
+
+    def write_kvec(self, path, pre_adjacency=False):
+        _check(lib().dfk_write_kvec(self._ctx, path.encode(), C.c_int(1 if pre_adjacency else 0)))
+
+    def stats(self):
+        s = Stats()
+        _check(lib().dfk_get_stats(self._ctx, C.byref(s)))
+        return s.asdict()
