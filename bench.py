@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/s of the DF createDict hot path on MI355X.
+
+A "step" is one full pass of the hot path (quality-tail trim, canonical k-mer extraction,
+count, MIN_FREQ/MIN_BC solid filter, spectrum, adjacency clean-up) over one synthetic stLFR
+read set that is already resident in HBM when the timed region starts.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload: BASELINE.json configs[1] is 30x human (~900 M pairs).  This round's pipeline keeps
+all super-k-mer records and the solid-set bound resident, which caps one GPU well below that;
+the default is therefore a SLICE of that configuration -- same read length, coverage, error
+rate, barcode structure and K, on a genome of --genome-mb (default 100 Mb, 1/31 of human) --
+and `config.workload` says so.  With N GPUs the genome and the read set grow N-fold (weak
+scaling): every rank samples the same number of pairs from the N-times larger genome.
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel (k_count): algorithmic bytes
+= 64 B per k-mer instance (one 32-B sector read + one 32-B sector write of the
+owning table slot) divided by the kernel's duration from HIP events on the library's stream.
+`cpu_baseline` times the reference's own MapReduceEngine/KmerDict (oracle/_ref/refdrv, kind
+"reference") or, if that binary is absent, the C restatement (kind "port") on a bounded
+sample of the same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from superplus_amd import synth  # noqa: E402
+from superplus_amd.dfk import Dfk  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+B_INST = 64                    # algorithmic bytes per k-mer instance in the count kernel
+
+
+def cpu_baseline(rs_np, K, sample_reads):
+    """Reference components (or the port) on the first `sample_reads` reads, all host cores."""
+    from superplus_amd import feudal
+    n = min(sample_reads, rs_np["n_reads"]) & ~1
+    sub = dict(packed=rs_np["packed"][: int(rs_np["base_off"][n])], base_off=rs_np["base_off"][: n + 1],
+               read_len=rs_np["read_len"][:n], pq_bytes=rs_np["pq_bytes"][: int(rs_np["pq_off"][n])],
+               pq_off=rs_np["pq_off"][: n + 1], bc=rs_np["bc"][:n])
+    cores = os.cpu_count() or 1
+    refdrv = os.path.join(ROOT, "oracle", "_ref", "refdrv")
+    if os.path.exists(refdrv):
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                feudal.write_fastb(d + "/s.fastb", sub["packed"], sub["base_off"], sub["read_len"])
+                feudal.write_qualp(d + "/s.qualp", sub["pq_bytes"], sub["pq_off"])
+                bc = sub["bc"].astype(np.int64)
+                nb = int(bc.max()) + 1 if n else 1
+                bci = np.concatenate([[0], np.cumsum(np.bincount(bc, minlength=nb))]).astype(np.int64)
+                feudal.write_bci(d + "/s.bci", bci)
+                os.makedirs(d + "/o")
+                threads = min(cores, 32)
+                subprocess.run([refdrv, "dict", str(K), d + "/s", d + "/o", "7", "3", "2", "1", str(threads)],
+                               check=True, stdout=subprocess.DEVNULL, timeout=600)
+                t = dict(line.split() for line in open(d + "/o/times.txt"))
+                secs = sum(float(t[k]) for k in ("goodlens_s", "mr1_s", "mr2_s", "dict_s", "adj_s"))
+                return {"value": float(t["instances"]) / secs, "unit": "k-mers/s", "cores": threads, "kind": "reference",
+                        "sample": f"first {n} reads of the workload ({t['instances']} k-mer instances); "
+                                  "createDict-equivalent = tail scan + 2 MapReduceEngine runs + Dict build + "
+                                  f"recomputeAdjacencies, {secs:.2f} s"}
+        except Exception as e:  # fall through to the port
+            print(f"[bench] refdrv baseline failed ({e}); using the C port", file=sys.stderr)
+    from oracle import pyoracle
+    t0 = time.time()
+    r = pyoracle.run(sub["packed"], sub["base_off"], sub["read_len"], sub["pq_bytes"], sub["pq_off"], sub["bc"], K=K,
+                     threads=cores)
+    secs = time.time() - t0
+    return {"value": r["n_inst"] / secs, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} reads of the workload ({r['n_inst']} k-mer instances), {secs:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=float, default=100.0, help="genome size per GPU, Mb")
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--K", type=int, default=48)
+    ap.add_argument("--minimizer", type=int, default=0)
+    ap.add_argument("--inst-per-item", type=int, default=0)
+    ap.add_argument("--cpu-sample-reads", type=int, default=600000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libdfk has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    G = int(args.genome_mb * 1e6) * world
+    pairs = int(args.coverage * args.genome_mb * 1e6 / 200.0)      # per GPU
+    genome = synth.make_genome(G, 20261004, device=dev)
+    rs = synth.make_reads(genome, pairs, 20261004 + 17 * (rank + 1))
+    del genome
+    torch.cuda.synchronize()
+
+    if world == 1:
+        d = Dfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item)
+        def step():
+            d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc)
+            return d.stats()
+    else:
+        from superplus_amd.dist import DistDfk
+        d = DistDfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item)
+        def step():
+            d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc)
+            return d.stats()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    st = None
+    for _ in range(args.steps):
+        st = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_inst = st["n_inst"]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([n_inst], dtype=torch.int64, device=dev)
+        dist.all_reduce(c)
+        n_inst = int(c.item())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        value = n_inst * args.steps / elapsed
+        k_ms = st["ms_count"]
+        achieved = B_INST * st["n_inst"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "k-mers/s (DF createDict stage: trim + canonical k-mer count + solid filter + spectrum + adjacency)",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"slice of BASELINE configs[1] (30x human stLFR): {args.coverage:g}x synthetic stLFR, "
+                                   f"genome {args.genome_mb:g} Mb per GPU, {pairs} pairs 2x100 bp per GPU, 0.5% subst., "
+                                   f"10% unbarcoded, K={args.K}, MIN_FREQ=3, MIN_BC=2, MIN_QUAL=7",
+                       "reads_per_gpu": rs.n_reads, "kmer_instances_total": n_inst, "K": args.K,
+                       "parallelism": "single GPU" if world == 1 else f"read shards x{world}, all-to-all by minimizer bucket"},
+            "df_stage_wall_s": elapsed / args.steps,
+            "stage_ms": {k: round(st[k], 3) for k in ("ms_trim", "ms_part_count", "ms_part_scatter", "ms_count",
+                                                     "ms_fallback", "ms_adjacency", "ms_total")},
+            "counts": {k: st[k] for k in ("n_reads", "n_inst", "n_records", "n_buckets", "n_items", "n_overflow_items",
+                                          "n_distinct", "n_solid", "adj_probes", "hbm_bytes_peak")},
+            "roofline": {"bound": "hbm", "kernel": "k_count", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": B_INST * st["n_inst"], "kernel_ms": k_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rs.numpy(), args.K, args.cpu_sample_reads)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,9 @@ struct Timer {
     float stop() { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 };
 
+bool g_trace = getenv("DFK_TRACE") != nullptr;
+#define TRACE(...) do { if (g_trace) { fprintf(stderr, "[dfk] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
 uint32_t ceil_log2(uint64_t v) { uint32_t b = 0; while ((1ull << b) < v) ++b; return b; }
 
 // ------------------------------------------------------------------ stage: trim (a1)
@@ -162,6 +165,7 @@ int stage_partition(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
                            (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint4*)nullptr);
     HIP_TRY(hipGetLastError());
     c->st.ms_part_count = t.stop();
+    TRACE("partition count pass done (%llu buckets)", (unsigned long long)nb);
     std::vector<uint64_t> h(nb);
     HIP_TRY(hipMemcpy(h.data(), acc.p, nb * 8, hipMemcpyDeviceToHost));
     c->release(acc);
@@ -189,6 +193,7 @@ int stage_partition(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
                            (const uint64_t*)dbase.p, (uint32_t*)cur.p, (uint4*)P->records.p);
     HIP_TRY(hipGetLastError());
     c->st.ms_part_scatter = t.stop();
+    TRACE("partition scatter done (%llu records)", (unsigned long long)P->n_records);
     c->release(dbase); c->release(cur);
     c->st.n_records = P->n_records; c->st.n_buckets = nb;
     return 0;
@@ -208,9 +213,22 @@ void pack_items(const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t budge
     if (acc) out->push_back({start, (uint32_t)b_hi});
 }
 
+struct CountRun {                     // device state shared by the count launches of one run
+    CountGlobals* g; uint4* seg; uint32_t* seg_count; unsigned long long* hist;
+    CountParams cp; unsigned grid;
+};
+
+template <int K> unsigned count_grid(const dfk_ctx* c)
+{
+    constexpr int LOG2S = CountCfg<K>::LOG2S, NW = CountCfg<K>::NWAVES;
+    const size_t lds = count_lds_bytes<K, LOG2S, NW>();
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / lds);
+    return (unsigned)c->prop.multiProcessorCount * per_cu;
+}
+
 template <int K, bool USE_BC>
-int launch_count(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& ranges, const CountParams& cp0,
-                 CountGlobals* d_g, uint4* d_out, unsigned long long* d_hist, std::vector<ItemRange>* overflowed)
+int launch_count(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& ranges, const CountRun& R,
+                 std::vector<ItemRange>* overflowed, float* kernel_ms)
 {
     constexpr int LOG2S = CountCfg<K>::LOG2S, NW = CountCfg<K>::NWAVES;
     if (ranges.empty()) return 0;
@@ -220,19 +238,22 @@ int launch_count(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& r
     int rc = c->alloc(d_items, items.size() * sizeof(CountItem), "count items"); if (rc) return rc;
     rc = c->alloc(d_ovf, items.size() * 4, "overflow list"); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(CountItem), hipMemcpyHostToDevice, c->stream));
-    // reset next_item / n_overflow, keep the running totals
-    HIP_TRY(hipMemsetAsync(&d_g->next_item, 0, 8, c->stream));
-    CountParams cp = cp0; cp.n_items = (uint32_t)items.size();
+    HIP_TRY(hipMemsetAsync(&R.g->next_item, 0, 8, c->stream));      // next_item, n_overflow
+    CountParams cp = R.cp; cp.n_items = (uint32_t)items.size();
     const size_t lds = count_lds_bytes<K, LOG2S, NW>();
     auto kern = k_count<K, LOG2S, NW, USE_BC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned per_cu = std::max<size_t>(1, (size_t)(160 * 1024) / lds);
-    const unsigned grid = (unsigned)std::min<size_t>(items.size(), (size_t)c->prop.multiProcessorCount * per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream,
-                       (const uint4*)P.records.p, (const CountItem*)d_items.p, cp, d_g, d_out, d_hist, (uint32_t*)d_ovf.p);
+    TRACE("k_count: %zu items, grid %u, lds %zu, seg_cap %llu", items.size(), R.grid, lds, (unsigned long long)R.cp.seg_cap);
+    Timer tk(c->stream);
+    tk.start();
+    hipLaunchKernelGGL(kern, dim3(R.grid), dim3(NW * 64), lds, c->stream,
+                       (const uint4*)P.records.p, (const CountItem*)d_items.p, cp, R.g, R.seg, R.seg_count, R.hist,
+                       (uint32_t*)d_ovf.p);
     HIP_TRY(hipGetLastError());
+    *kernel_ms += tk.stop();
+    TRACE("k_count done");
     CountGlobals g{};
-    HIP_TRY(hipMemcpyAsync(&g, d_g, sizeof g, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&g, R.g, sizeof g, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (g.n_overflow) {
         std::vector<uint32_t> ov(g.n_overflow);
@@ -244,8 +265,7 @@ int launch_count(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& r
 }
 
 template <int K, bool USE_BC>
-int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& singles, const CountParams& cp,
-                     CountGlobals* d_g, uint4* d_out, unsigned long long* d_hist)
+int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& singles, const CountRun& R)
 {
     constexpr int KW = KTraits<K>::KW, NW = 8;
     // tables sized to >= 2x the item's instances (an upper bound on its distinct k-mers)
@@ -264,7 +284,7 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     HIP_TRY(hipMemsetAsync(d_fail.p, 0, 16, c->stream));
     HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_big<K, NW, USE_BC>), dim3((unsigned)items.size()), dim3(NW * 64), 0, c->stream,
-                       (const uint4*)P.records.p, (const BigItem*)d_items.p, cp, d_g, d_out, d_hist,
+                       (const uint4*)P.records.p, (const BigItem*)d_items.p, R.cp, R.g, R.seg, R.hist,
                        (uint32_t*)pool.p, (uint32_t*)d_fail.p);
     HIP_TRY(hipGetLastError());
     uint32_t failed = 0;
@@ -283,28 +303,34 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     std::vector<ItemRange> ranges;
     pack_items(P, b_lo, b_hi, budget, &ranges);
 
-    // every solid k-mer has >= min_freq instances
+    // Output: one segment per persistent workgroup (+1 for the HBM fallback), filled through an
+    // LDS cursor.  Every solid k-mer has >= min_freq instances, which bounds the total.
+    CountRun R{};
+    R.grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ranges.size(), count_grid<K>(c)));
+    const uint32_t nseg = R.grid + 1;
     uint64_t cap = n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
     const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
     const uint64_t fixed = (uint64_t)HIST_GLOBAL_BINS * 8 + (64ull << 20);
-    if (cap * 32 + fixed > room) cap = room > fixed ? (room - fixed) / 32 : 0;
-    DevBuf d_hist, d_g;
-    int rc = c->alloc(c->solid, cap * 32, "solid k-mer entries"); if (rc) return rc;
+    // the dense copy made afterwards needs room too: leave a third of what is left for it
+    if (cap * 32 + fixed > room / 3 * 2) cap = room / 3 * 2 > fixed ? (room / 3 * 2 - fixed) / 32 : 0;
+    const uint64_t seg_cap = std::min<uint64_t>(cap / nseg + 1024, 0xFFFFFFF0ull);
+    DevBuf d_seg, d_segcnt, d_hist, d_g;
+    int rc = c->alloc(d_seg, seg_cap * nseg * 32, "solid k-mer segments"); if (rc) return rc;
+    rc = c->alloc(d_segcnt, 4ull * nseg, "segment counts"); if (rc) return rc;
     rc = c->alloc(d_hist, (uint64_t)HIST_GLOBAL_BINS * 8, "spectrum bins"); if (rc) return rc;
     rc = c->alloc(d_g, sizeof(CountGlobals), "count globals"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_segcnt.p, 0, 4ull * nseg, c->stream));
     HIP_TRY(hipMemsetAsync(d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
     HIP_TRY(hipMemsetAsync(d_g.p, 0, sizeof(CountGlobals), c->stream));
-    CountParams cp{c->cfg.min_freq, c->cfg.min_bc, USE_BC ? 1u : 0u, 0, cap, COUNT_HIST_BINS};
-    CountGlobals* g = (CountGlobals*)d_g.p;
-    uint4* out = (uint4*)c->solid.p;
-    unsigned long long* hist = (unsigned long long*)d_hist.p;
+    R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, nseg, seg_cap};
+    R.g = (CountGlobals*)d_g.p; R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p;
+    R.hist = (unsigned long long*)d_hist.p;
 
     Timer t(c->stream);
-    t.start();
     std::vector<ItemRange> overflowed;
     c->st.n_items = ranges.size();
-    rc = launch_count<K, USE_BC>(c, P, ranges, cp, g, out, hist, &overflowed); if (rc) return rc;
-    c->st.ms_count = t.stop();
+    c->st.ms_count = 0;
+    rc = launch_count<K, USE_BC>(c, P, ranges, R, &overflowed, &c->st.ms_count); if (rc) return rc;
     t.start();
     // items that overflowed their LDS table: split at fine-bucket boundaries and retry; a single
     // fine bucket that still overflows is counted in an HBM table
@@ -320,17 +346,35 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
             next.push_back({r.b0, mid}); next.push_back({mid, r.b1});
         }
         overflowed.clear();
-        rc = launch_count<K, USE_BC>(c, P, next, cp, g, out, hist, &overflowed); if (rc) return rc;
+        TRACE("retrying %zu split items", next.size());
+        float ignored = 0;
+        rc = launch_count<K, USE_BC>(c, P, next, R, &overflowed, &ignored); if (rc) return rc;
     }
-    if (!singles.empty()) { rc = launch_count_big<K, USE_BC>(c, P, singles, cp, g, out, hist); if (rc) return rc; }
+    TRACE("fallback: %zu single-bucket items", singles.size());
+    if (!singles.empty()) { rc = launch_count_big<K, USE_BC>(c, P, singles, R); if (rc) return rc; }
     c->st.ms_fallback = t.stop();
+    TRACE("count stage kernels done");
 
     CountGlobals hg{};
+    std::vector<uint32_t> segcnt(nseg);
     HIP_TRY(hipMemcpy(&hg, d_g.p, sizeof hg, hipMemcpyDeviceToHost));
-    if (hg.solid_overflow || hg.n_solid > cap)
-        return fail(DFK_E_NOMEM, "solid k-mer output (%llu entries) exceeds the HBM budget (room for %llu)",
-                    (unsigned long long)hg.n_solid, (unsigned long long)cap);
-    c->n_solid = hg.n_solid; c->st.n_solid = hg.n_solid; c->st.n_distinct = hg.n_distinct;
+    HIP_TRY(hipMemcpy(segcnt.data(), d_segcnt.p, 4ull * nseg, hipMemcpyDeviceToHost));
+    segcnt[nseg - 1] = (uint32_t)std::min<uint64_t>(hg.big_cursor, seg_cap);
+    if (hg.solid_overflow || hg.big_cursor > seg_cap)
+        return fail(DFK_E_NOMEM, "a solid k-mer output segment (%llu entries) is full; raise hbm_budget_bytes",
+                    (unsigned long long)seg_cap);
+    std::vector<uint64_t> prefix(nseg + 1, 0);
+    for (uint32_t s = 0; s < nseg; ++s) prefix[s + 1] = prefix[s] + segcnt[s];
+    c->n_solid = prefix[nseg]; c->st.n_solid = c->n_solid; c->st.n_distinct = hg.n_distinct;
+
+    // dense solid array
+    DevBuf d_prefix;
+    rc = c->alloc(c->solid, c->n_solid * 32, "solid k-mer entries"); if (rc) return rc;
+    rc = c->alloc(d_prefix, 8ull * (nseg + 1), "segment prefix"); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_prefix.p, prefix.data(), 8ull * (nseg + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_compact, dim3(8, nseg), dim3(256), 0, c->stream, (const uint4*)d_seg.p, seg_cap,
+                       (const uint64_t*)d_prefix.p, (uint4*)c->solid.p);
+    HIP_TRY(hipGetLastError());
 
     // spectrum (a5): bins 0..max count
     DevBuf d_max; rc = c->alloc(d_max, 16, "max bin"); if (rc) return rc;
@@ -342,7 +386,8 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->hist.assign(nb, 0);
     if (nb) HIP_TRY(hipMemcpy(c->hist.data(), d_hist.p, 8ull * nb, hipMemcpyDeviceToHost));
-    c->release(d_max); c->release(d_hist); c->release(d_g);
+    TRACE("spectrum read back: %u bins, %llu solid", nb, (unsigned long long)c->n_solid);
+    c->release(d_max); c->release(d_hist); c->release(d_g); c->release(d_seg); c->release(d_segcnt); c->release(d_prefix);
     return 0;
 }
 
@@ -383,6 +428,7 @@ int stage_adjacency(dfk_ctx* c)
         c->release(d_n); c->release(c->set);
     }
     c->st.ms_adjacency = t.stop();
+    TRACE("adjacency done");
     return 0;
 }
 

@@ -232,30 +232,30 @@ struct CountItem { uint64_t rec_begin; uint64_t rec_end; };
 
 struct CountParams {
     uint32_t min_freq, min_bc;
-    uint32_t use_bc;                 // 0: no barcode test at all
     uint32_t n_items;
-    uint64_t solid_cap;              // entries
-    uint32_t hist_lds_bins;          // = COUNT_HIST_BINS
+    uint32_t n_segments;             // output segments (one per persistent workgroup) + 1 for the HBM fallback
+    uint64_t seg_cap;                // entries per segment
 };
 
 struct CountGlobals {                // device-resident counters
-    unsigned long long n_solid;      // entries written
     unsigned long long n_distinct;
+    unsigned long long big_cursor;   // entries written to the last segment by k_count_big
     unsigned int next_item;
     unsigned int n_overflow;         // items that overflowed their table
-    unsigned int solid_overflow;     // output capacity exceeded
+    unsigned int solid_overflow;     // an output segment ran out of room
     unsigned int pad;
 };
 
 constexpr int COUNT_HIST_BINS = 1024;
 constexpr uint32_t COUNT_MAX_PROBE = 96;
 constexpr uint32_t HIST_GLOBAL_BINS = 1u << 24;   // KDef count saturates at 2^24-1 (ReadPather.h:128-129)
+constexpr int COUNT_CHUNK = 32;                   // records a wave stages at a time
 
 template <int K> struct WaveStage {               // per-wave private LDS
-    uint32_t rec[64 * 8 + 8];                     // staged records (+ pad for the 5-word window read)
-    uint32_t starts[64];                          // first instance index of each record
-    uint32_t msk[128];                            // bit t set <=> instance t starts a record
-    uint32_t pc[128];                             // exclusive popcount prefix of msk words
+    uint32_t rec[COUNT_CHUNK * 8 + 8];            // staged records (+ pad for the 5-word window read)
+    uint32_t starts[COUNT_CHUNK];                 // first instance index of each record
+    uint32_t msk[64];                             // bit t set <=> instance t starts a record (<= 32*55 bits)
+    uint32_t pc[64];                              // exclusive popcount prefix of msk words
 };
 
 // Table words are read and written with relaxed agent-scope atomics: for the LDS table these
@@ -267,7 +267,8 @@ __device__ __forceinline__ void tst(uint32_t* p, uint32_t v)
 { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One insertion.  `c` = canonical 2K-bit value, ctx = context byte, tag = barcode.
-// Returns false if the table is (nearly) full.
+// Slot state lives in the count word: 0 = empty, CNT_LOCK = being initialised, else the count.
+// Returns false if the probe sequence got too long (table nearly full).
 template <int KW, bool USE_BC>
 __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
                                              uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw,
@@ -277,7 +278,14 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
     uint32_t slot = key_hash(c) & (S - 1);
     uint32_t probes = 0;
     bool done = false, ok = true;
-    while (!done) {
+    uint32_t spins = 0;
+    // The loop condition is wave-uniform (ballot) on purpose.  A lane that finds CNT_LOCK waits for
+    // the lane initialising the slot, which may sit in the same wave.  With a per-lane `while (!done)`
+    // the compiler may turn the winner's branch (it ends in the loop exit) into an exit block; the
+    // wave then runs it only after every lane has left the loop and the waiters spin forever.  With
+    // the exit decided only at the header, the winner's stores are inside the loop body.
+    do {
+      if (!done) {
         uint32_t expect = 0;
         bool won = __hip_atomic_compare_exchange_strong(&cnt[slot], &expect, CNT_LOCK, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
                                                         __HIP_MEMORY_SCOPE_AGENT);
@@ -312,8 +320,11 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
             }
         }
         // expect == CNT_LOCK: another lane is initialising this slot; it finishes inside its own
-        // iteration of this same loop, so simply try the slot again.
-    }
+        // iteration of this same loop, so simply try the slot again -- a bounded number of times,
+        // so that every wave reaches the end of the kernel whatever happens.
+        else if (++spins > (1u << 20)) { ok = false; done = true; }
+      }
+    } while (__ballot(!done) != 0ull);
     return ok;
 }
 
@@ -346,31 +357,30 @@ __device__ __forceinline__ bool insert_instance(const uint32_t* __restrict__ rec
     return table_insert<KTraits<K>::KW, USE_BC>(keys, cnt, ctxs, bcw, S, c, ctx, tag, n_fill);
 }
 
-// Count all records [rb,re) with the calling wave (wave-synchronous; no block barriers).
+// Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
+// block barriers).  Lanes load half a record each (1 KiB per wave, coalesced).
 template <int K, bool USE_BC>
 __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
                                                  WaveStage<K>* __restrict__ st, int lane,
                                                  uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
                                                  uint32_t S, uint32_t* n_fill, uint32_t* overflow)
 {
-    const uint64_t ridx = rb + lane;
-    const bool valid = ridx < re;
-    uint4 a{0, 0, 0, 0}, b{0, 0, 0, 0};
-    if (valid) { a = records[2 * ridx]; b = records[2 * ridx + 1]; }
-    const uint32_t nk = a.x & 63u;
-    reinterpret_cast<uint4*>(st->rec)[2 * lane] = a;
-    reinterpret_cast<uint4*>(st->rec)[2 * lane + 1] = b;
+    static_assert(COUNT_CHUNK == 32, "one uint4 per lane");
+    const uint64_t hidx = 2 * rb + lane;
+    uint4 v{0, 0, 0, 0};
+    if (hidx < 2 * re) v = records[hidx];
+    reinterpret_cast<uint4*>(st->rec)[lane] = v;
+    st->msk[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nk = lane < COUNT_CHUNK ? (st->rec[8 * lane] & 63u) : 0u;
     const uint32_t incl = wave_incl_scan(nk, lane);
     const uint32_t start = incl - nk;
     const uint32_t total = __shfl(incl, 63, 64);
-    st->starts[lane] = start;
-    st->msk[lane] = 0; st->msk[lane + 64] = 0;
-    __builtin_amdgcn_wave_barrier();
+    if (lane < COUNT_CHUNK) st->starts[lane] = start;
     if (nk) atomicOr(&st->msk[start >> 5], 1u << (start & 31u));
     __builtin_amdgcn_wave_barrier();
-    const uint32_t c0 = __popc(st->msk[2 * lane]), c1 = __popc(st->msk[2 * lane + 1]);
-    const uint32_t ex = wave_incl_scan(c0 + c1, lane) - (c0 + c1);
-    st->pc[2 * lane] = ex; st->pc[2 * lane + 1] = ex + c0;
+    const uint32_t c0 = __popc(st->msk[lane]);
+    st->pc[lane] = wave_incl_scan(c0, lane) - c0;
     __builtin_amdgcn_wave_barrier();
     bool ok = true;
     for (uint32_t t = lane; t < total; t += 64) {
@@ -392,49 +402,55 @@ __device__ __forceinline__ bool bc_pass(uint32_t v, uint32_t min_bc)
     return (v & BCW_MULTI) != 0;                                     // >= 2 distinct barcodes > 0, or an ignored (-1) one
 }
 
-// Emit the solid slots of a finished table: entries to `out`, counts to the spectrum.
+// Emit the solid slots of a finished table into this workgroup's output segment and the
+// spectrum.  `cursor` is the segment's fill count: an LDS word for k_count (no global atomics,
+// no barriers), a global word for the HBM fallback.
 template <int K, bool USE_BC, bool LDS_HIST>
-__device__ __forceinline__ void table_emit(const uint32_t* keys, const uint32_t* cnt, const uint32_t* ctxs, const uint32_t* bcw,
-                                           uint32_t S, const CountParams& cp, CountGlobals* g, uint4* __restrict__ out,
-                                           uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
-                                           int tid, int nthreads)
+__device__ __forceinline__ uint32_t table_emit(const uint32_t* keys, const uint32_t* cnt, const uint32_t* ctxs, const uint32_t* bcw,
+                                               uint32_t S, const CountParams& cp, uint4* __restrict__ seg_out,
+                                               unsigned long long* cursor64, uint32_t* cursor32, unsigned int* seg_overflow,
+                                               uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
+                                               int tid, int nthreads)
 {
     const int lane = tid & 63;
+    uint32_t n_occ = 0;
     for (uint32_t base = 0; base < S; base += nthreads) {
         const uint32_t slot = base + tid;
         uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
         uint32_t count = c > 0xFFFFFFu ? 0xFFFFFFu : c;               // KDef::setCount saturation (ReadPather.h:128-129)
         bool solid = c != 0 && count >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&bcw[slot]) : 0u, cp.min_bc);
-        unsigned long long occ = __ballot(c != 0);
+        n_occ += c != 0;
         unsigned long long m = __ballot(solid);
+        if (!m) continue;
         uint32_t n = __popcll(m);
         unsigned long long wbase = 0;
-        if (lane == 0) {
-            if (occ) atomicAdd(&g->n_distinct, (unsigned long long)__popcll(occ));
-            if (n) wbase = atomicAdd(&g->n_solid, (unsigned long long)n);
-        }
+        if (lane == 0) wbase = cursor32 ? (unsigned long long)atomicAdd(cursor32, n) : atomicAdd(cursor64, (unsigned long long)n);
         wbase = __shfl(wbase, 0, 64);
         if (solid) {
             unsigned long long idx = wbase + __popcll(m & ((1ull << lane) - 1ull));
-            if (idx < cp.solid_cap) {
+            if (idx < cp.seg_cap) {
                 u128 v{(uint64_t)tld(&keys[slot]) | ((uint64_t)tld(&keys[S + slot]) << 32),
                        (uint64_t)tld(&keys[2 * S + slot]) | (KTraits<K>::KW == 4 ? ((uint64_t)tld(&keys[3 * S + slot]) << 32) : 0ull)};
                 u128 kw = shl128(v, 128 - KTraits<K>::BITS);           // left-align: KMer<K> storage
                 uint32_t cc = count | (tld(&ctxs[slot]) << 24);
-                out[2 * idx] = uint4{(uint32_t)kw.hi, (uint32_t)(kw.hi >> 32), (uint32_t)kw.lo, (uint32_t)(kw.lo >> 32)};
-                out[2 * idx + 1] = uint4{0xFFFFFFFFu, cc, 0xFFFFFFFFu, 0u};
-            } else atomicOr(&g->solid_overflow, 1u);
+                seg_out[2 * idx] = uint4{(uint32_t)kw.hi, (uint32_t)(kw.hi >> 32), (uint32_t)kw.lo, (uint32_t)(kw.lo >> 32)};
+                seg_out[2 * idx + 1] = uint4{0xFFFFFFFFu, cc, 0xFFFFFFFFu, 0u};
+            } else atomicOr(seg_overflow, 1u);
             if (LDS_HIST && count < (uint32_t)COUNT_HIST_BINS) atomicAdd(&hist_lds[count], 1u);
             else atomicAdd(&hist_global[count], 1ull);
         }
     }
+    return n_occ;
 }
+
+// ctl words (LDS)
+enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_CURSOR = 4, CTL_DISTINCT = 5, CTL_N = 8 };
 
 template <int K, int LOG2S, int NWAVES, bool USE_BC>
 __global__ void __launch_bounds__(NWAVES * 64)
 k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, CountParams cp,
-        CountGlobals* __restrict__ g, uint4* __restrict__ out, unsigned long long* __restrict__ hist_global,
-        uint32_t* __restrict__ overflow_items)
+        CountGlobals* __restrict__ g, uint4* __restrict__ out, uint32_t* __restrict__ seg_count,
+        unsigned long long* __restrict__ hist_global, uint32_t* __restrict__ overflow_items)
 {
     constexpr uint32_t S = 1u << LOG2S;
     constexpr int KW = KTraits<K>::KW;
@@ -445,44 +461,64 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
     uint32_t* ctxs = cnt + S;                       // [S]
     uint32_t* bcw = ctxs + S;                       // [S]
     uint32_t* hist = bcw + S;                       // [COUNT_HIST_BINS]
-    uint32_t* ctl = hist + COUNT_HIST_BINS;         // [4]: item, overflow, n_fill
-    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(ctl + 4);
+    uint32_t* ctl = hist + COUNT_HIST_BINS;         // [CTL_N]
+    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(ctl + CTL_N);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WaveStage<K>* st = stages + wave;
+    uint4* seg_out = out + 2ull * cp.seg_cap * blockIdx.x;
 
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) hist[i] = 0;
+    if (tid == 0) { ctl[CTL_CURSOR] = seg_count[blockIdx.x]; ctl[CTL_DISTINCT] = 0; }
     for (;;) {
         __syncthreads();
-        if (tid == 0) { ctl[0] = atomicAdd(&g->next_item, 1u); ctl[1] = 0; ctl[2] = 0; }
-        for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;         // cnt, ctxs, bcw are contiguous
+        if (tid == 0) { ctl[CTL_ITEM] = atomicAdd(&g->next_item, 1u); ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; }
+        for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;             // slot state; the other words are written on claim
         __syncthreads();
-        const uint32_t item = ctl[0];
+        const uint32_t item = __builtin_amdgcn_readfirstlane(ctl[CTL_ITEM]);
         if (item >= cp.n_items) break;
         const uint64_t rb = items[item].rec_begin, re = items[item].rec_end;
-        for (uint64_t c = rb + 64ull * wave; c < re; c += 64ull * NWAVES) {
-            if (tld(&ctl[1])) break;
-            wave_count_chunk<K, USE_BC>(records, c, re, st, lane, keys, cnt, ctxs, bcw, S, &ctl[2], &ctl[1]);
-            if (lane == 0 && tld(&ctl[2]) > (S / 4) * 3) tst(&ctl[1], 1u);   // stop early when the table is 3/4 full
+        // Waves pull chunks of the item from an LDS ticket.  All loop control is made scalar
+        // (readfirstlane) so the compiler emits uniform branches, and the trip count is bounded.
+        const uint32_t n_chunks = (uint32_t)((re - rb + COUNT_CHUNK - 1) / COUNT_CHUNK);
+        for (uint32_t guard = 0; guard < n_chunks; ++guard) {
+            uint32_t ci = 0;
+            if (lane == 0) ci = atomicAdd(&ctl[CTL_CHUNK], 1u);
+            ci = __builtin_amdgcn_readfirstlane(ci);
+            if (ci >= n_chunks) break;
+            if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
+            wave_count_chunk<K, USE_BC>(records, rb + (uint64_t)ci * COUNT_CHUNK, re, st, lane, keys, cnt, ctxs, bcw, S,
+                                        &ctl[CTL_FILL], &ctl[CTL_OVF]);
+            if (lane == 0 && tld(&ctl[CTL_FILL]) > (S / 4) * 3) tst(&ctl[CTL_OVF], 1u);   // stop when 3/4 full
         }
         __syncthreads();
-        if (ctl[1]) {
+        if (__builtin_amdgcn_readfirstlane(ctl[CTL_OVF])) {
             if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = item;
         } else {
-            table_emit<K, USE_BC, true>(keys, cnt, ctxs, bcw, S, cp, g, out, hist, hist_global, tid, NT);
+            uint32_t occ = table_emit<K, USE_BC, true>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
+                                                       &g->solid_overflow, hist, hist_global, tid, NT);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
+            if (lane == 0 && occ) atomicAdd(&ctl[CTL_DISTINCT], occ);
         }
     }
     __syncthreads();
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) if (hist[i]) atomicAdd(&hist_global[i], (unsigned long long)hist[i]);
+    if (tid == 0) {
+        uint32_t cur = ctl[CTL_CURSOR];
+        seg_count[blockIdx.x] = cur > cp.seg_cap ? (uint32_t)cp.seg_cap : cur;
+        if (ctl[CTL_DISTINCT]) atomicAdd(&g->n_distinct, (unsigned long long)ctl[CTL_DISTINCT]);
+    }
 }
 
 template <int K, int LOG2S, int NWAVES>
 constexpr size_t count_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + 4) + sizeof(WaveStage<K>) * NWAVES;
+    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N) + sizeof(WaveStage<K>) * NWAVES;
 }
 
 // Fallback: one workgroup per overflowed item, table in HBM (tab = [KW+3][S] words, zeroed by
 // the host), staging still in LDS.  Same insertion code; atomics resolve to global memory.
+// Output goes to the last segment through a global cursor.
 struct BigItem { uint64_t rec_begin, rec_end; uint64_t tab_off; uint32_t log2s; uint32_t pad; };
 
 template <int K, int NWAVES, bool USE_BC>
@@ -494,7 +530,7 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     constexpr int KW = KTraits<K>::KW;
     constexpr int NT = NWAVES * 64;
     __shared__ WaveStage<K> stages[NWAVES];
-    __shared__ uint32_t ctl[4];
+    __shared__ uint32_t ctl[CTL_N];
     const BigItem it = items[blockIdx.x];
     const uint32_t S = 1u << it.log2s;
     uint32_t* keys = tab_pool + it.tab_off;
@@ -502,14 +538,31 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     uint32_t* ctxs = cnt + S;
     uint32_t* bcw = ctxs + S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { ctl[1] = 0; ctl[2] = 0; }
+    if (tid == 0) { ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; }
     __syncthreads();
-    for (uint64_t c = it.rec_begin + 64ull * wave; c < it.rec_end; c += 64ull * NWAVES)
-        wave_count_chunk<K, USE_BC>(records, c, it.rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[2], &ctl[1]);
+    for (uint64_t c = it.rec_begin + (uint64_t)COUNT_CHUNK * wave; c < it.rec_end; c += (uint64_t)COUNT_CHUNK * NWAVES)
+        wave_count_chunk<K, USE_BC>(records, c, it.rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[CTL_FILL], &ctl[CTL_OVF]);
     __threadfence();
     __syncthreads();
-    if (ctl[1]) { if (tid == 0) atomicOr(failed, 1u); return; }
-    table_emit<K, USE_BC, false>(keys, cnt, ctxs, bcw, S, cp, g, out, nullptr, hist_global, tid, NT);
+    if (ctl[CTL_OVF]) { if (tid == 0) atomicOr(failed, 1u); return; }
+    uint4* seg_out = out + 2ull * cp.seg_cap * (cp.n_segments - 1);
+    uint32_t occ = table_emit<K, USE_BC, false>(keys, cnt, ctxs, bcw, S, cp, seg_out, &g->big_cursor, nullptr,
+                                                &g->solid_overflow, nullptr, hist_global, tid, NT);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
+    if (lane == 0 && occ) atomicAdd(&g->n_distinct, (unsigned long long)occ);
+}
+
+// Gather the output segments into one dense array: block b copies a slice of segment blockIdx.y.
+__global__ void __launch_bounds__(256)
+k_compact(const uint4* __restrict__ seg, uint64_t seg_cap, const uint64_t* __restrict__ seg_prefix, uint4* __restrict__ dense)
+{
+    const uint32_t s = blockIdx.y;
+    const uint64_t n = seg_prefix[s + 1] - seg_prefix[s];
+    const uint4* src = seg + 2ull * seg_cap * s;
+    uint4* dst = dense + 2ull * seg_prefix[s];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
 }
 
 // ============================================================================ a6: adjacency clean-up
