@@ -44,6 +44,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 B_INST = 64                    # algorithmic bytes per k-mer instance in the count kernel
 
 
+def profiled_traffic(n_inst):
+    """HBM bytes per k_count launch from the committed rocprofv3 --pmc passes (profiles/rNN_traffic.json,
+    produced by tools/profile_gpu.sh + tools/summarize_prof.py on this same command).  Counters cannot be
+    read inside this process, so the figure is quoted only when the profiled run had the same instance count."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    t = json.load(open(files[-1]))
+    line = t.get("bench_line_under_profiler") or {}
+    if (line.get("counts") or {}).get("n_inst") != n_inst:
+        return None
+    return t["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(rs_np, K, sample_reads):
     """Reference components (or the port) on the first `sample_reads` reads, all host cores."""
     from superplus_amd import feudal
@@ -173,7 +188,7 @@ def main():
             "counts": {k: st[k] for k in ("n_reads", "n_inst", "n_records", "n_buckets", "n_items", "n_overflow_items",
                                           "n_distinct", "n_solid", "adj_probes", "hbm_bytes_peak")},
             "roofline": {"bound": "hbm", "kernel": "k_count", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(st["n_inst"]),
                          "algorithmic_bytes_per_launch": B_INST * st["n_inst"], "kernel_ms": k_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,14 @@
+#!/bin/bash
+# tools/profile_gpu.sh ROUND -- run on the GPU box (via gpurun) from the repo root.
+# Three separate rocprofv3 passes over the same bench command: kernel trace + stats, then the
+# two HBM traffic counters on their own (they do not fit one pass: MI355X_MICROARCH.md, PMC slots).
+set -e
+R=${1:-r01}
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$R
+rm -rf $OUT; mkdir -p $OUT
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/bench_write.log 2>&1
+find $OUT -name '*.csv' | head -50

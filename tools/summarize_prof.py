@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""tools/summarize_prof.py ROUND -- fold the rocprofv3 CSVs that tools/profile_gpu.sh left under
+gpurun_out/prof_ROUND/ into small committed files under profiles/:
+
+  profiles/ROUND_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (dfk kernels + totals)
+  profiles/ROUND_hbm_counters.csv   per-kernel mean FETCH_SIZE / WRITE_SIZE (separate --pmc passes)
+  profiles/ROUND_traffic.json       per-launch HBM bytes of the dominant kernel, corrected as
+                                    MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KiB and reads
+                                    exactly half of a 16 B/lane coalesced stream on gfx950; WRITE_SIZE
+                                    is exact for 16-B stores) -- bench.py quotes it as roofline.traffic
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+stats = list(csv.DictReader(open(glob.glob(src + "/trace/*/*_kernel_stats.csv")[0])))
+with open(os.path.join(dst, f"{R}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
+    for r in stats:
+        if "dfk::" in r["Name"]:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+for which in ("fetch", "write"):
+    for r in csv.DictReader(open(glob.glob(src + f"/{which}/*/*_counter_collection.csv")[0])):
+        if "dfk::" in r["Kernel_Name"]:
+            ctr[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(os.path.join(dst, f"{R}_hbm_counters.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "launches", "FETCH_SIZE_KiB_mean", "WRITE_SIZE_KiB_mean", "read_bytes_x2_corrected", "write_bytes"])
+    for k, v in ctr.items():
+        fs = sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"]))
+        ws = sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"]))
+        w.writerow([k, len(v["FETCH_SIZE"]), f"{fs:.1f}", f"{ws:.1f}", int(2 * fs * 1024), int(ws * 1024)])
+
+dom = [k for k in ctr if "k_count<" in k][0]
+fs = sum(ctr[dom]["FETCH_SIZE"]) / len(ctr[dom]["FETCH_SIZE"])
+ws = sum(ctr[dom]["WRITE_SIZE"]) / len(ctr[dom]["WRITE_SIZE"])
+avg_ns = [float(r["AverageNs"]) for r in stats if "k_count<" in r["Name"]][0]
+bench = [l for l in open(os.path.join(src, "bench_trace.log")) if l.startswith("{")]
+json.dump({"round": R, "kernel": dom, "avg_ns_rocprof": avg_ns,
+           "fetch_size_kib": fs, "write_size_kib": ws,
+           "hbm_bytes_per_launch": int(2 * fs * 1024 + ws * 1024),
+           "correction": "read bytes = 2 x FETCH_SIZE KiB (gfx950, 16 B/lane coalesced stream); write bytes = WRITE_SIZE KiB",
+           "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+           "bench_line_under_profiler": json.loads(bench[-1]) if bench else None},
+          open(os.path.join(dst, f"{R}_traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{R}_kernel_stats.csv")).read())
+print(open(os.path.join(dst, f"{R}_hbm_counters.csv")).read())
