@@ -125,14 +125,17 @@ int stage_trim(dfk_ctx* c, const Inputs& in, uint64_t* n_inst)
         unsigned grid = (unsigned)((in.n_reads + 255) / 256);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trim<K>), dim3(grid), dim3(256), 0, c->stream,
                            in.pq, in.pq_off, in.read_len, in.n_reads, c->cfg.min_qual, (uint32_t*)c->good_len.p,
-                           (unsigned long long*)ctr.p, (unsigned int*)((char*)ctr.p + 8));
+                           (unsigned long long*)ctr.p, (unsigned int*)((char*)ctr.p + 8),
+                           (unsigned long long*)((char*)ctr.p + 16));
         HIP_TRY(hipGetLastError());
     }
-    uint64_t h[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h, ctr.p, 16, hipMemcpyDeviceToHost, c->stream));
+    uint64_t h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h, ctr.p, 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->release(ctr);
     if ((uint32_t)h[1]) return fail(DFK_E_INPUT, "a PQVec stream is malformed or its length differs from read_len");
+    // createDict: nKmers = sum of goodLens == 0 -> "almost no good bases", Scram(1) (BuildReadQGraph48.cc:225-230)
+    if (h[2] == 0) return fail(DFK_E_NOGOOD, "Looks like your input data have almost no good bases.");
     *n_inst = h[0];
     return 0;
 }

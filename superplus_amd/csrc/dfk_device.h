@@ -90,6 +90,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
+// Lanes of one wave exchanging data through LDS.  The hardware runs a wave's LDS operations in
+// order, so no wait is needed, but the COMPILER must be told that other lanes may have written:
+// without the fences it forwards a lane's own earlier store to its later load (it did: the
+// popcount of a mask word was folded to 0 for lanes that had not set a bit themselves).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // record header (word 0): nk in bits 0-5, has_pred bit 6, has_succ bit 7, fine bucket id in bits 8-31
 __device__ __forceinline__ uint32_t rec_header(uint32_t nk, bool hp, bool hs, uint32_t bucket)
 { return nk | (hp ? 64u : 0u) | (hs ? 128u : 0u) | (bucket << 8); }

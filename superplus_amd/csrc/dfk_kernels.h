@@ -16,7 +16,8 @@ template <int K>
 __global__ void __launch_bounds__(256)
 k_trim(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, const uint32_t* __restrict__ read_len,
        uint64_t n_reads, uint32_t min_qual, uint32_t* __restrict__ good_len,
-       unsigned long long* __restrict__ n_inst, unsigned int* __restrict__ bad)
+       unsigned long long* __restrict__ n_inst, unsigned int* __restrict__ bad,
+       unsigned long long* __restrict__ sum_good)
 {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t gl = 0;
@@ -56,9 +57,11 @@ k_trim(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, cons
     }
     // instance total: wave reduce, one atomic per wave
     unsigned long long mine = gl >= (uint32_t)K + 1 ? (unsigned long long)(gl - K + 1) : 0ull;
+    unsigned long long good = gl;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    for (int d = 32; d > 0; d >>= 1) { mine += __shfl_down(mine, d, 64); good += __shfl_down(good, d, 64); }
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_inst, mine);
+    if ((threadIdx.x & 63) == 0 && good) atomicAdd(sum_good, good);
 }
 
 // ============================================================================ a2 (first half): super-k-mer partition
@@ -371,27 +374,27 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     if (hidx < 2 * re) v = records[hidx];
     reinterpret_cast<uint4*>(st->rec)[lane] = v;
     st->msk[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     const uint32_t nk = lane < COUNT_CHUNK ? (st->rec[8 * lane] & 63u) : 0u;
     const uint32_t incl = wave_incl_scan(nk, lane);
     const uint32_t start = incl - nk;
     const uint32_t total = __shfl(incl, 63, 64);
     if (lane < COUNT_CHUNK) st->starts[lane] = start;
     if (nk) atomicOr(&st->msk[start >> 5], 1u << (start & 31u));
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t c0 = __popc(st->msk[lane]);
+    wave_sync();
+    const uint32_t c0 = __popc(tld(&st->msk[lane]));
     st->pc[lane] = wave_incl_scan(c0, lane) - c0;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     bool ok = true;
     for (uint32_t t = lane; t < total; t += 64) {
         const uint32_t w = t >> 5;
-        const uint32_t bits = st->msk[w] & (0xFFFFFFFFu >> (31u - (t & 31u)));
+        const uint32_t bits = tld(&st->msk[w]) & (0xFFFFFFFFu >> (31u - (t & 31u)));
         const uint32_t r = st->pc[w] + __popc(bits) - 1u;
         const uint32_t q = t - st->starts[r];
         ok = insert_instance<K, USE_BC>(st->rec + 8 * r, q, keys, cnt, ctxs, bcw, S, n_fill) && ok;
     }
     if (!ok) atomicOr(overflow, 1u);
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
 }
 
 template <bool USE_BC>

@@ -15,3 +15,151 @@ def test_parity_synthetic(oracle, K, seed, G, pairs):
     st = util.check_parity(ref, d)
     assert st["n_solid"] > 0
     assert d.spectrum_json() == oracle.spectrum_json(ref["hist"])
+
+
+def test_golden_fixtures_through_abi(oracle, golden_dir):
+    """The committed golden vectors (reference classes, tests/golden/make_golden.py) through libdfk."""
+    import os
+    from superplus_amd.dfk import Dfk
+    from tests.test_oracle_golden import CASES, load_inputs
+    rs = load_inputs(golden_dir)
+    for tag, K, use_bc, min_bc in CASES:
+        exp = np.load(os.path.join(golden_dir, f"expect_{tag}.npz"))
+        d = Dfk(K=K, min_bc=min_bc, keep_pre_adjacency=True)
+        d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"] if use_bc else None)
+        assert np.array_equal(d.good_lens(), exp["good_len"]), tag
+        util.assert_same_solid(d.solid(pre_adjacency=True), exp["solid_pre"], tag + " kvec view")
+        util.assert_same_solid(d.solid(), exp["solid_post"], tag + " Dict view")
+        assert np.array_equal(d.spectrum(), exp["spectrum"]), tag
+        d.close()
+
+
+@pytest.mark.parametrize("min_freq,min_bc,use_bc,ign", [(1, 2, True, 0), (2, 0, True, 0), (3, 1, True, 0), (3, 2, False, 0),
+                                                       (3, 2, True, 2000), (5, 2, True, 10**9)])
+def test_filter_variants(oracle, min_freq, min_bc, use_bc, ign):
+    """MIN_FREQ / MIN_BC / no-barcode / ignBcBelow variants (areIgnoredBarcodes, areEnoughBarcodes;
+    min_freq == 1 skips recomputeAdjacencies, BuildReadQGraph48.cc:313)."""
+    rs = util.make_set(21, 50000, 5000)
+    ref, d = util.run_both(oracle, rs, K=48, min_freq=min_freq, min_bc=min_bc, use_bc=use_bc, ign_bc_below=ign)
+    util.check_parity(ref, d)
+
+
+def _custom(reads, quals, bc=None):
+    from superplus_amd import feudal
+    packed, boff, pq, poff = [], [0], [], [0]
+    for r, q in zip(reads, quals):
+        p = feudal.pack_bases(np.asarray(r, np.uint8)[None, :]).reshape(-1) if len(r) else np.zeros(0, np.uint8)
+        packed.append(p); boff.append(boff[-1] + len(p))
+        e = np.frombuffer(feudal.pq_encode(q), np.uint8)
+        pq.append(e); poff.append(poff[-1] + len(e))
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint8)
+    return dict(packed=cat(packed), base_off=np.array(boff, np.uint64), read_len=np.array([len(r) for r in reads], np.uint32),
+                pq_bytes=cat(pq), pq_off=np.array(poff, np.uint64),
+                bc=np.zeros(len(reads), np.int32) if bc is None else np.asarray(bc, np.int32), n_reads=len(reads))
+
+
+def test_ragged_and_degenerate_reads(oracle):
+    """Empty reads, reads shorter than K, exactly K (emit nothing, :153), K+1, long reads, low-quality islands."""
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 4, 3000, dtype=np.uint8)
+    reads, quals, bc = [], [], []
+    for i in range(1200):
+        L = int(rng.choice([0, 1, 20, 47, 48, 49, 50, 100, 150, 251, 400]))
+        pos = int(rng.integers(0, 3000 - 400))
+        r = g[pos:pos + L].copy()
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        q = rng.choice([40, 30, 20, 8, 7, 6, 2], L, p=[.3, .3, .2, .1, .04, .03, .03]).astype(np.uint8)
+        reads.append(r); quals.append(q); bc.append(int(rng.integers(0, 5)))
+    rs = _custom(reads, quals, bc)
+    for K in (40, 48, 60):
+        ref, d = util.run_both(oracle, rs, K=K)
+        util.check_parity(ref, d)
+
+
+def test_low_complexity_hot_buckets(oracle):
+    """Poly-A / dinucleotide repeats: one k-mer seen thousands of times, runs longer than NK_MAX in one bucket,
+    palindromes (not context-symmetrised)."""
+    rng = np.random.default_rng(4)
+    reads, quals, bc = [], [], []
+    pal = np.array([0, 1, 2, 3] * 12 + [0, 1, 2, 3][::-1] * 0, np.uint8)  # ACGT repeat: reverse-complement palindromic 48-mers
+    for i in range(3000):
+        kind = i % 4
+        if kind == 0:
+            r = np.zeros(100, np.uint8)
+        elif kind == 1:
+            r = np.tile(np.array([0, 3], np.uint8), 50)
+        elif kind == 2:
+            r = np.tile(np.array([0, 1, 2, 3], np.uint8), 25)
+        else:
+            r = rng.integers(0, 4, 100, dtype=np.uint8)
+        reads.append(r); quals.append(np.full(100, 35, np.uint8)); bc.append(1 + i % 7)
+    rs = _custom(reads, quals, bc)
+    ref, d = util.run_both(oracle, rs, K=48)
+    st = util.check_parity(ref, d)
+    assert ref["hist"].size > 1000        # a bin beyond the LDS spectrum range is exercised
+
+
+def test_lds_table_overflow_falls_back(oracle):
+    """Nearly every k-mer distinct and items far over the LDS table's capacity: the split/HBM-table
+    fallback must give the same answer."""
+    rs = util.make_set(31, 3000000, 20000, err=0.0)     # ~1.3x coverage: distinct ~= instances
+    ref, d = util.run_both(oracle, rs, K=48, min_freq=1, inst_per_item=60000)
+    st = util.check_parity(ref, d)
+    assert st["n_overflow_items"] > 0
+
+
+def test_no_good_bases_is_an_error(oracle):
+    from superplus_amd.dfk import Dfk, DfkError
+    rs = _custom([np.zeros(100, np.uint8)] * 10, [np.full(100, 2, np.uint8)] * 10)
+    d = Dfk(K=48)
+    with pytest.raises(DfkError) as e:
+        d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    assert e.value.code == -7
+    with pytest.raises(DfkError):                       # n_reads == 0 is the same condition (nKmers == 0)
+        d.count(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint8),
+                np.zeros(1, np.uint64), None)
+
+
+def test_malformed_pqvec_is_an_error():
+    from superplus_amd.dfk import Dfk, DfkError
+    rs = _custom([np.zeros(100, np.uint8)] * 4, [np.full(100, 30, np.uint8)] * 4)
+    rs["read_len"][2] = 99
+    with pytest.raises(DfkError) as e:
+        Dfk(K=48).count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    assert e.value.code == -5
+
+
+def test_result_independent_of_partition_geometry(oracle):
+    """Size-independent property at a size the oracle is not run on: the sorted solid set, spectrum and
+    counts cannot depend on minimizer length or item size (different bucketings of the same multiset)."""
+    import hashlib
+    from superplus_amd.dfk import Dfk
+    rs = util.make_set(41, 2000000, 300000)
+    sigs = []
+    for M, ipi in ((14, 0), (10, 3000), (16, 9000)):
+        d = Dfk(K=48, minimizer_len=M, inst_per_item=ipi)
+        d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+        s = d.solid(); h = d.spectrum(); st = d.stats()
+        assert h.sum() == len(s) == st["n_solid"] and (h * np.arange(len(h))).sum() <= st["n_inst"]
+        assert np.all(np.diff(s["w0"].astype(np.float64)) >= 0)
+        sigs.append((hashlib.sha256(s.tobytes()).hexdigest(), hashlib.sha256(h.tobytes()).hexdigest(), st["n_distinct"]))
+        d.close()
+    assert sigs[0] == sigs[1] == sigs[2]
+
+
+def test_single_bucket_overflow_uses_hbm_table(oracle):
+    """Tens of thousands of distinct k-mers that all contain one A14 (the smallest possible minimizer hash)
+    land in ONE fine bucket; it cannot be split, so it is counted in the HBM table (k_count_big)."""
+    rng = np.random.default_rng(9)
+    reads, quals, bc = [], [], []
+    for i in range(3000):
+        r = rng.integers(0, 4, 100, dtype=np.uint8)
+        r[43:57] = 0
+        if i % 3 == 0:                          # some exact duplicates so that solid k-mers exist
+            r = reads[-1].copy() if reads else r
+        reads.append(r); quals.append(np.full(100, 30, np.uint8)); bc.append(1 + i % 5)
+    rs = _custom(reads, quals, bc)
+    ref, d = util.run_both(oracle, rs, K=48, min_freq=2)
+    st = util.check_parity(ref, d)
+    assert st["n_overflow_items"] > 0 and st["n_solid"] > 0
