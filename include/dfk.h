@@ -142,21 +142,37 @@ int dfk_write_kvec(dfk_ctx* ctx, const char* path, int pre_adjacency);
 int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
 
 /* ---- multi-GPU pieces (one process per GPU; the caller owns the RCCL exchange) ----
- * The MapReduceEngine thread all-to-all ("swizzle", MapReduceEngine.h:345-388) becomes:
- *   dfk_shard_partition   kmerize this rank's reads into super-k-mer records grouped by
- *                         destination rank (owner = minimizer bucket % world)
- *   <caller: all_to_all of counts, then of the record bytes, over RCCL/xGMI>
- *   dfk_shard_count       count the records this rank owns
- *   dfk_shard_adj_*       second, small exchange for neighbours owned by other ranks
- * See INTEGRATION.md; superplus_amd/dist.py drives these with torch.distributed. */
-int dfk_shard_partition(dfk_ctx* ctx,
+ * The reference's only exchange is MapReduceEngine's thread all-to-all ("swizzle",
+ * MapReduceEngine.h:345-388): every key goes to the thread that owns hash % T.  Here every
+ * k-mer goes to the rank that owns its minimizer bucket (owner = bucket & (world-1); world is
+ * a power of two), travelling inside 32-byte super-k-mer records:
+ *
+ *   dfk_shard_begin       trim this rank's reads; returns its k-mer instance count
+ *   <caller: all-reduce the instance counts so that every rank derives the same bucket count>
+ *   dfk_shard_partition   kmerize into records grouped by destination rank
+ *   <caller: all-to-all of send_counts, then of the record bytes, over RCCL/xGMI>
+ *   dfk_shard_count       regroup the received records by fine bucket and count them: this
+ *                         rank now holds the solid k-mers it owns, pre-adjacency
+ *   dfk_shard_adj_queries neighbour keys of the local solid k-mers, grouped by owner rank
+ *   <caller: all-to-all of the 16-byte keys>
+ *   dfk_shard_adj_answer  presence of each received key in the local solid set
+ *   <caller: all-to-all of the answer bytes back>
+ *   dfk_shard_adj_apply   clear the context bits whose neighbour is not solid anywhere
+ *
+ * Afterwards dfk_solid_count/fetch, dfk_spectrum, dfk_good_lens return this rank's share
+ * (solid sets are disjoint; spectra add).  superplus_amd/dist.py drives these with
+ * torch.distributed; INTEGRATION.md shows the plain RCCL calls. */
+int dfk_shard_begin(dfk_ctx* ctx,
               const void* d_packed_bases, uint64_t packed_bytes, const void* d_base_off,
               const void* d_read_len, const void* d_pq_bytes, uint64_t pq_nbytes,
               const void* d_pq_off, const void* d_bc, uint64_t n_reads,
-              uint32_t world, const void** d_records, uint64_t* send_counts /* [world], in records */);
+              int64_t global_read_offset /* index of this shard's first read (ign_bc_below is global) */,
+              uint64_t* n_inst_local);
+int dfk_shard_partition(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global,
+              const void** d_records, uint64_t* send_counts /* [world], in 32-byte records */);
 int dfk_shard_count(dfk_ctx* ctx, const void* d_records, uint64_t n_records);
-int dfk_shard_adj_queries(dfk_ctx* ctx, uint32_t world, const void** d_keys,
-              uint64_t* send_counts /* [world], in 16-B keys */);
+int dfk_shard_adj_queries(dfk_ctx* ctx, const void** d_keys,
+              uint64_t* send_counts /* [world], in 16-byte keys */);
 int dfk_shard_adj_answer(dfk_ctx* ctx, const void* d_keys, uint64_t n_keys, void* d_present /* u8[n_keys] */);
 int dfk_shard_adj_apply(dfk_ctx* ctx, const void* d_present, uint64_t n_keys);
 

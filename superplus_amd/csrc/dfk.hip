@@ -65,7 +65,11 @@ struct dfk_ctx {
     bool sorted_ok = false, sorted_pre_ok = false;
     dfk_stats st{};
     // shard state (multi-GPU)
-    DevBuf shard_records; uint64_t shard_n_records = 0;
+    bool shard_open = false, shard_use_bc = false;
+    const void* sh_in[7] = {};                // caller's device arrays, valid until dfk_shard_partition returns
+    uint64_t sh_packed_bytes = 0, sh_pq_bytes = 0, sh_n_reads = 0, sh_n_inst_local = 0;
+    int64_t sh_read_id0 = 0;
+    DevBuf shard_records;
     DevBuf adj_keys, adj_src; uint64_t adj_n = 0;
     DevBuf set; uint64_t set_mask = 0;
     uint32_t shard_world = 1, shard_log2_nb = 0;
@@ -95,7 +99,7 @@ struct dfk_ctx {
         owned.clear(); held = 0;
         good_len = solid = solid_pre = shard_records = adj_keys = adj_src = set = DevBuf{};
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
-        n_solid = 0; shard_n_records = 0; adj_n = 0;
+        n_solid = 0; adj_n = 0; shard_open = false;
     }
 };
 
@@ -149,10 +153,10 @@ struct Partition {
 };
 
 template <int K>
-int stage_partition(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, Partition* P)
+int stage_partition(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, Partition* P)
 {
     const uint32_t M = c->cfg.minimizer_len;
-    PartParams pp{M, (uint32_t)K - M + 1, P->log2_nb, log2_world};
+    PartParams pp{M, (uint32_t)K - M + 1, P->log2_nb, log2_world, read_id0};
     const uint64_t nb = 1ull << P->log2_nb;
     DevBuf acc; int rc = c->alloc(acc, nb * 8, "bucket counters"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(acc.p, 0, nb * 8, c->stream));
@@ -219,6 +223,7 @@ void pack_items(const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t budge
 struct CountRun {                     // device state shared by the count launches of one run
     CountGlobals* g; uint4* seg; uint32_t* seg_count; unsigned long long* hist;
     CountParams cp; unsigned grid;
+    DevBuf big; uint64_t big_cap = 0;  // output of the HBM-table fallback (its own buffer)
 };
 
 template <int K> unsigned count_grid(const dfk_ctx* c)
@@ -268,26 +273,30 @@ int launch_count(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& r
 }
 
 template <int K, bool USE_BC>
-int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& singles, const CountRun& R)
+int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& singles, CountRun& R)
 {
     constexpr int KW = KTraits<K>::KW, NW = 8;
     // tables sized to >= 2x the item's instances (an upper bound on its distinct k-mers)
-    std::vector<BigItem> items; uint64_t words = 0;
+    std::vector<BigItem> items; uint64_t words = 0, tot_inst = 0;
     for (const ItemRange& r : singles) {
         uint64_t inst = 0; for (uint32_t b = r.b0; b < r.b1; ++b) inst += P.inst[b];
+        tot_inst += inst;
         uint32_t l2 = std::max<uint32_t>(13, ceil_log2(2 * inst + 64));
         items.push_back(BigItem{P.base[r.b0], P.base[r.b1], words, l2, 0});
         words += (uint64_t)(KW + 3) << l2;
     }
     DevBuf pool, d_items, d_fail;
-    int rc = c->alloc(pool, words * 4, "HBM fallback tables"); if (rc) return rc;
+    R.big_cap = tot_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;   // every solid k-mer has >= min_freq instances
+    int rc = c->alloc(R.big, R.big_cap * 32, "fallback solid entries"); if (rc) return rc;
+    rc = c->alloc(pool, words * 4, "HBM fallback tables"); if (rc) return rc;
     rc = c->alloc(d_items, items.size() * sizeof(BigItem), "fallback items"); if (rc) return rc;
     rc = c->alloc(d_fail, 16, "fallback flag"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(pool.p, 0, words * 4, c->stream));
     HIP_TRY(hipMemsetAsync(d_fail.p, 0, 16, c->stream));
     HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice, c->stream));
+    CountParams cpb = R.cp; cpb.seg_cap = R.big_cap; cpb.n_segments = 1;   // one segment: the fallback's own buffer
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_big<K, NW, USE_BC>), dim3((unsigned)items.size()), dim3(NW * 64), 0, c->stream,
-                       (const uint4*)P.records.p, (const BigItem*)d_items.p, R.cp, R.g, R.seg, R.hist,
+                       (const uint4*)P.records.p, (const BigItem*)d_items.p, cpb, R.g, (uint4*)R.big.p, R.hist,
                        (uint32_t*)pool.p, (uint32_t*)d_fail.p);
     HIP_TRY(hipGetLastError());
     uint32_t failed = 0;
@@ -299,7 +308,7 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
 }
 
 template <int K, bool USE_BC>
-int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t n_inst)
+int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t n_inst, unsigned attempt = 0)
 {
     constexpr int LOG2S = CountCfg<K>::LOG2S;
     const uint64_t budget = c->cfg.inst_per_item ? c->cfg.inst_per_item : (3ull << LOG2S) / 2;
@@ -310,13 +319,15 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     // LDS cursor.  Every solid k-mer has >= min_freq instances, which bounds the total.
     CountRun R{};
     R.grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ranges.size(), count_grid<K>(c)));
-    const uint32_t nseg = R.grid + 1;
+    const uint32_t nseg = R.grid;
     uint64_t cap = n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
     const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
     const uint64_t fixed = (uint64_t)HIST_GLOBAL_BINS * 8 + (64ull << 20);
     // the dense copy made afterwards needs room too: leave a third of what is left for it
     if (cap * 32 + fixed > room / 3 * 2) cap = room / 3 * 2 > fixed ? (room / 3 * 2 - fixed) / 32 : 0;
-    const uint64_t seg_cap = std::min<uint64_t>(cap / nseg + 1024, 0xFFFFFFF0ull);
+    // dynamic item scheduling balances the workgroups to within a few items (<= 3/4 S entries each);
+    // if a segment still fills up the whole stage is redone with twice the room
+    const uint64_t seg_cap = std::min<uint64_t>(((cap / nseg) * 5 / 4 + 8192) << attempt, 0xFFFFFFF0ull);
     DevBuf d_seg, d_segcnt, d_hist, d_g;
     int rc = c->alloc(d_seg, seg_cap * nseg * 32, "solid k-mer segments"); if (rc) return rc;
     rc = c->alloc(d_segcnt, 4ull * nseg, "segment counts"); if (rc) return rc;
@@ -362,13 +373,17 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     std::vector<uint32_t> segcnt(nseg);
     HIP_TRY(hipMemcpy(&hg, d_g.p, sizeof hg, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(segcnt.data(), d_segcnt.p, 4ull * nseg, hipMemcpyDeviceToHost));
-    segcnt[nseg - 1] = (uint32_t)std::min<uint64_t>(hg.big_cursor, seg_cap);
-    if (hg.solid_overflow || hg.big_cursor > seg_cap)
-        return fail(DFK_E_NOMEM, "a solid k-mer output segment (%llu entries) is full; raise hbm_budget_bytes",
-                    (unsigned long long)seg_cap);
+    if (hg.solid_overflow || hg.big_cursor > R.big_cap) {
+        c->release(d_seg); c->release(d_segcnt); c->release(d_hist); c->release(d_g); c->release(R.big);
+        if (attempt >= 4)
+            return fail(DFK_E_NOMEM, "a solid k-mer output segment (%llu entries) is full; raise hbm_budget_bytes",
+                        (unsigned long long)seg_cap);
+        TRACE("output segment full at %llu entries: redoing the count stage with more room", (unsigned long long)seg_cap);
+        return stage_count<K, USE_BC>(c, P, b_lo, b_hi, n_inst, attempt + 1);
+    }
     std::vector<uint64_t> prefix(nseg + 1, 0);
     for (uint32_t s = 0; s < nseg; ++s) prefix[s + 1] = prefix[s] + segcnt[s];
-    c->n_solid = prefix[nseg]; c->st.n_solid = c->n_solid; c->st.n_distinct = hg.n_distinct;
+    c->n_solid = prefix[nseg] + hg.big_cursor; c->st.n_solid = c->n_solid; c->st.n_distinct = hg.n_distinct;
 
     // dense solid array
     DevBuf d_prefix;
@@ -378,6 +393,8 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     hipLaunchKernelGGL(k_compact, dim3(8, nseg), dim3(256), 0, c->stream, (const uint4*)d_seg.p, seg_cap,
                        (const uint64_t*)d_prefix.p, (uint4*)c->solid.p);
     HIP_TRY(hipGetLastError());
+    if (hg.big_cursor)
+        HIP_TRY(hipMemcpyAsync((char*)c->solid.p + 32 * prefix[nseg], R.big.p, 32 * hg.big_cursor, hipMemcpyDeviceToDevice, c->stream));
 
     // spectrum (a5): bins 0..max count
     DevBuf d_max; rc = c->alloc(d_max, 16, "max bin"); if (rc) return rc;
@@ -391,6 +408,7 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     if (nb) HIP_TRY(hipMemcpy(c->hist.data(), d_hist.p, 8ull * nb, hipMemcpyDeviceToHost));
     TRACE("spectrum read back: %u bins, %llu solid", nb, (unsigned long long)c->n_solid);
     c->release(d_max); c->release(d_hist); c->release(d_g); c->release(d_seg); c->release(d_segcnt); c->release(d_prefix);
+    c->release(R.big);
     return 0;
 }
 
@@ -455,7 +473,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     c->st.ms_trim = t.stop();
     c->st.n_reads = in.n_reads; c->st.n_inst = n_inst; c->n_reads = in.n_reads;
     Partition P; P.log2_nb = pick_log2_nb(n_inst, 0);
-    rc = stage_partition<K>(c, in, n_inst, 0, &P); if (rc) return rc;
+    rc = stage_partition<K>(c, in, n_inst, 0, 0, &P); if (rc) return rc;
     const uint64_t nb = 1ull << P.log2_nb;
     rc = in.bc ? stage_count<K, true>(c, P, 0, nb, n_inst) : stage_count<K, false>(c, P, 0, nb, n_inst);
     if (rc) return rc;

@@ -83,6 +83,7 @@ struct PartParams {
     uint32_t W;            // K - M + 1
     uint32_t log2_nb;      // fine buckets = 1 << log2_nb
     uint32_t log2_world;   // fine buckets are laid out owner-major: owner rank = bucket & (world-1)
+    int64_t  read_id0;     // global index of this shard's first read (ignBcBelow compares global read ids)
 };
 
 constexpr int PART_THREADS = 256;
@@ -146,7 +147,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     const uint64_t n_words = (packed_bytes + 3) >> 2;
     const uint64_t bit0 = byte0 * 8;                             // bit offset of base 0 in the word stream
     int32_t tag = -1;                                            // :150-151
-    if (bc && (int64_t)r >= ign_bc_below) tag = bc[r];
+    if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
 
     const uint32_t mmask = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * M)) - 1u);
     const uint32_t rsh = 2 * (M - 1);
@@ -548,7 +549,7 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     __threadfence();
     __syncthreads();
     if (ctl[CTL_OVF]) { if (tid == 0) atomicOr(failed, 1u); return; }
-    uint4* seg_out = out + 2ull * cp.seg_cap * (cp.n_segments - 1);
+    uint4* seg_out = out;                                             // the fallback's own buffer, cp.seg_cap entries
     uint32_t occ = table_emit<K, USE_BC, false>(keys, cnt, ctxs, bcw, S, cp, seg_out, &g->big_cursor, nullptr,
                                                 &g->solid_overflow, nullptr, hist_global, tid, NT);
 #pragma unroll
@@ -660,6 +661,96 @@ k_adjacency(uint4* __restrict__ entries, uint64_t n, const SetSlot* __restrict__
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) probes += __shfl_down(probes, d, 64);
     if ((threadIdx.x & 63) == 0 && probes) atomicAdd(n_probes, probes);
+}
+
+
+// ============================================================================ multi-GPU adjacency exchange
+// Fine bucket of an arbitrary k-mer given as a 2K-bit big-endian value (same function of the
+// canonical m-mer set as k_partition computes while scanning a read).
+template <int K>
+__device__ __forceinline__ uint32_t kmer_bucket(u128 F, const PartParams& pp)
+{
+    const uint32_t M = pp.M;
+    const uint32_t mmask = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * M)) - 1u);
+    const uint32_t rsh = 2 * (M - 1);
+    uint32_t f = 0, rc = 0, mv = 0xFFFFFFFFu;
+    for (int i = 0; i < K; ++i) {
+        const int sh = 2 * (K - 1 - i);
+        const uint32_t b = (uint32_t)(sh >= 64 ? (F.hi >> (sh - 64)) : (F.lo >> sh)) & 3u;
+        f = ((f << 2) | b) & mmask;
+        rc = (rc >> 2) | ((3u - b) << rsh);
+        if (i + 1 >= (int)M) { uint32_t h = mix32(f < rc ? f : rc); mv = h < mv ? h : mv; }
+    }
+    uint32_t bucket = (mv * 0x9E3779B1u) >> (32 - pp.log2_nb);
+    return bucket;                       // owner rank = bucket & (world-1)
+}
+
+// Neighbour look-ups of the local solid k-mers, grouped by the rank that owns each neighbour.
+//   WRITE == false: per_owner[o] += number of queries for rank o
+//   WRITE == true : keys[base[o] + cursor[o]++] = canonical neighbour; src[...] = entry index << 3 | context bit
+template <int K, bool WRITE>
+__global__ void __launch_bounds__(256)
+k_adj_queries(const uint4* __restrict__ entries, uint64_t n, PartParams pp, unsigned long long* __restrict__ per_owner,
+              const uint64_t* __restrict__ base, SetSlot* __restrict__ keys, uint64_t* __restrict__ src)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t world = 1u << pp.log2_world;
+    uint32_t ctx = 0; u128 F{0, 0};
+    const u128 m = KTraits<K>::mask();
+    if (i < n) {
+        uint4 a = entries[2 * i], b = entries[2 * i + 1];
+        u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
+        F = shr128(kw, 128 - KTraits<K>::BITS);
+        ctx = b.y >> 24;
+    }
+    for (uint32_t bit = 0; bit < 8; ++bit) {
+        const bool has = (ctx >> bit) & 1u;
+        uint32_t owner = 0xFFFFFFFFu; uint64_t w0 = 0, w1 = 0;
+        if (has) {
+            u128 v;
+            if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }
+            else {
+                v = shr128(F, 2);
+                constexpr int TOP = KTraits<K>::BITS - 2;
+                if (TOP >= 64) v.hi |= (uint64_t)(bit - 4) << (TOP - 64); else v.lo |= (uint64_t)(bit - 4) << TOP;
+            }
+            owner = kmer_bucket<K>(v, pp) & (world - 1);
+            if (WRITE) canon_words<K>(v, &w0, &w1);
+        }
+        for (uint32_t o = 0; o < world; ++o) {
+            const unsigned long long mk = __ballot(owner == o);
+            if (!mk) continue;
+            unsigned long long wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&per_owner[o], (unsigned long long)__popcll(mk));
+            wbase = __shfl(wbase, 0, 64);
+            if (WRITE && owner == o) {
+                const uint64_t pos = base[o] + wbase + __popcll(mk & ((1ull << lane) - 1ull));
+                keys[pos] = SetSlot{w0, w1};
+                src[pos] = (i << 3) | bit;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_adj_answer(const SetSlot* __restrict__ keys, uint64_t n, const SetSlot* __restrict__ set, uint64_t mask,
+             uint8_t* __restrict__ present)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SetSlot k = keys[i];
+    present[i] = set_has(set, mask, k.w0, k.w1) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_adj_apply(uint4* __restrict__ entries, const uint64_t* __restrict__ src, const uint8_t* __restrict__ present, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || present[i]) return;
+    const uint64_t s = src[i];
+    uint32_t* word = reinterpret_cast<uint32_t*>(entries + 2 * (s >> 3) + 1) + 1;    // count_ctx
+    atomicAnd(word, ~(1u << (24 + (uint32_t)(s & 7))));
 }
 
 // ============================================================================ multi-GPU: regroup received records

@@ -1,0 +1,187 @@
+"""Multi-GPU driver: one process per GPU, the exchanges over torch.distributed (backend "nccl"
+is RCCL on ROCm, over xGMI inside a node).
+
+The reference's only exchange is MapReduceEngine's thread all-to-all (MapReduceEngine.h:345-388).
+Here: reads are sharded by contiguous pair ranges; every rank cuts its reads into super-k-mer
+records and sends each to the rank that owns its minimizer bucket (ONE all-to-all of 32-byte
+records); counting is then local; recomputeAdjacencies needs neighbours that live on other
+ranks, which costs one small all-to-all of 16-byte keys and one of 1-byte answers.
+
+`Comm` hides the transport so the same driver runs (a) under torch.distributed and (b) with all
+ranks inside one process, which is how the path is tested on a single GPU and how the
+exchange plumbing is tested on the CPU with gloo.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import dfk as _dfk
+from .dfk import Dfk, _check, lib
+
+
+def exchange(send: torch.Tensor, send_counts, unit: int, comm):
+    """All-to-all of variable-size slices.  `send` is a flat byte tensor holding, rank after rank,
+    send_counts[r] units of `unit` bytes for rank r.  Returns (recv bytes, recv_counts)."""
+    world = comm.world
+    sc = torch.tensor(list(send_counts), dtype=torch.int64, device=send.device)
+    rc = torch.empty_like(sc)
+    comm.all_to_all_single(rc, sc, None, None)
+    rcl = [int(x) for x in rc.tolist()]
+    recv = torch.empty(sum(rcl) * unit, dtype=torch.uint8, device=send.device)
+    comm.all_to_all_single(recv, send, [x * unit for x in rcl], [int(x) * unit for x in send_counts])
+    return recv, rcl
+
+
+class TorchComm:
+    """torch.distributed transport (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_to_all_single(self, out, inp, out_split, in_split):
+        try:
+            self.dist.all_to_all_single(out, inp, out_split, in_split, group=self.group)
+        except RuntimeError:
+            # a backend without all-to-all (some gloo builds): pairwise send/recv, same result
+            world, rank = self.world, self.rank
+            outs = list(out.split(out_split)) if out_split is not None else list(out.chunk(world))
+            ins = list(inp.split(in_split)) if in_split is not None else list(inp.chunk(world))
+            outs[rank].copy_(ins[rank])
+            reqs = []
+            for peer in range(world):
+                if peer == rank:
+                    continue
+                if ins[peer].numel():
+                    reqs.append(self.dist.isend(ins[peer].contiguous(), peer, group=self.group))
+                if outs[peer].numel():
+                    reqs.append(self.dist.irecv(outs[peer], peer, group=self.group))
+            for r in reqs:
+                r.wait()
+
+    def all_reduce_sum(self, value: int, device):
+        t = torch.tensor([value], dtype=torch.int64, device=device)
+        self.dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+
+def _view(ptr, nbytes, device):
+    """A uint8 torch view of library-owned device memory (no copy)."""
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    class _Holder:  # __cuda_array_interface__ carrier
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(h, device=device)
+
+
+class DistDfk(Dfk):
+    """Dfk whose count_device() runs the sharded pipeline.  After it returns, solid()/spectrum()/
+    good_lens() give THIS rank's share: solid sets of different ranks are disjoint, spectra add."""
+
+    def __init__(self, comm=None, **kw):
+        super().__init__(**kw)
+        self.comm = comm
+        self._n_inst_global = 0
+
+    # ---- phases (each is local; the driver below puts the collectives between them) ----
+    def begin(self, packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0=0):
+        n = C.c_uint64()
+        dp = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+        _check(lib().dfk_shard_begin(self._ctx, dp(packed), C.c_uint64(packed.numel()), dp(base_off), dp(read_len),
+                                     dp(pq_bytes), C.c_uint64(pq_bytes.numel()), dp(pq_off), dp(bc),
+                                     C.c_uint64(read_len.numel()), C.c_int64(read_id0), C.byref(n)))
+        self._device = packed.device
+        return n.value
+
+    def partition(self, world, n_inst_global):
+        ptr = C.c_void_p(); counts = (C.c_uint64 * world)()
+        _check(lib().dfk_shard_partition(self._ctx, C.c_uint32(world), C.c_uint64(n_inst_global), C.byref(ptr), counts))
+        counts = list(counts)
+        return _view(ptr.value, 32 * sum(counts), self._device), counts
+
+    def count_records(self, recv):
+        _check(lib().dfk_shard_count(self._ctx, C.c_void_p(recv.data_ptr() if recv.numel() else 0), C.c_uint64(recv.numel() // 32)))
+
+    def adj_queries(self, world):
+        ptr = C.c_void_p(); counts = (C.c_uint64 * world)()
+        _check(lib().dfk_shard_adj_queries(self._ctx, C.byref(ptr), counts))
+        counts = list(counts)
+        return _view(ptr.value, 16 * sum(counts), self._device), counts
+
+    def adj_answer(self, keys):
+        n = keys.numel() // 16
+        present = torch.empty(n, dtype=torch.uint8, device=self._device)
+        _check(lib().dfk_shard_adj_answer(self._ctx, C.c_void_p(keys.data_ptr() if n else 0), C.c_uint64(n),
+                                          C.c_void_p(present.data_ptr() if n else 0)))
+        return present
+
+    def adj_apply(self, present):
+        _check(lib().dfk_shard_adj_apply(self._ctx, C.c_void_p(present.data_ptr() if present.numel() else 0),
+                                         C.c_uint64(present.numel())))
+
+    # ---- the sharded createDict ----
+    def count_device(self, packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0=0):
+        comm = self.comm or TorchComm()
+        world = comm.world
+        n_local = self.begin(packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0)
+        n_global = comm.all_reduce_sum(n_local, packed.device)
+        if n_global == 0:
+            raise _dfk.DfkError(-7, "Looks like your input data have almost no good bases.")
+        self._n_inst_global = n_global
+        send, counts = self.partition(world, n_global)
+        recv, _ = exchange(send, counts, 32, comm)                        # the k-mer shuffle
+        self.count_records(recv)
+        del recv
+        keys, kcounts = self.adj_queries(world)
+        rkeys, rcounts = exchange(keys, kcounts, 16, comm)                 # neighbour queries
+        answers = self.adj_answer(rkeys)
+        back, _ = exchange(answers, rcounts, 1, comm)                      # answers return in query order
+        self.adj_apply(back)
+
+    def stats(self):
+        s = super().stats()
+        s["n_inst_global"] = self._n_inst_global
+        return s
+
+
+class _LocalComm:
+    """All ranks in one process: collectives are performed by run_inprocess() between phases."""
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+
+def _a2a(bufs, counts, unit):
+    """bufs[r] = flat bytes of rank r grouped by destination; counts[r][d] units.  -> per-destination concatenation."""
+    world = len(bufs)
+    offs = [np.concatenate([[0], np.cumsum(c)]) * unit for c in counts]
+    out, rcounts = [], []
+    for d in range(world):
+        parts = [bufs[r][int(offs[r][d]):int(offs[r][d + 1])] for r in range(world)]
+        out.append(torch.cat(parts) if parts else bufs[0][:0])
+        rcounts.append([counts[r][d] for r in range(world)])
+    return out, rcounts
+
+
+def run_inprocess(ranks, shards):
+    """Drive `ranks` (DistDfk objects, possibly all on one GPU) through the sharded pipeline with the
+    exchanges done by tensor slicing.  shards[r] = (packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0)."""
+    world = len(ranks)
+    n_local = [ranks[r].begin(*shards[r]) for r in range(world)]
+    n_global = sum(n_local)
+    sends = [ranks[r].partition(world, n_global) for r in range(world)]
+    recv, _ = _a2a([s[0] for s in sends], [s[1] for s in sends], 32)
+    recv = [x.clone() for x in recv]            # the send buffers are freed by count_records
+    for r in range(world):
+        ranks[r].count_records(recv[r])
+        ranks[r]._n_inst_global = n_global
+    q = [ranks[r].adj_queries(world) for r in range(world)]
+    rkeys, rcounts = _a2a([x[0] for x in q], [x[1] for x in q], 16)
+    answers = [ranks[r].adj_answer(rkeys[r].contiguous()) for r in range(world)]
+    back, _ = _a2a(answers, rcounts, 1)
+    for r in range(world):
+        ranks[r].adj_apply(back[r].contiguous())
+    return n_global

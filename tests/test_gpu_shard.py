@@ -1,0 +1,50 @@
+"""The multi-GPU (sharded) path on one GPU: every rank is a DistDfk context on cuda:0 and the
+all-to-all exchanges are done by tensor slicing (superplus_amd.dist.run_inprocess).  The union of
+the ranks' disjoint solid sets, the sum of their spectra and their goodLens must equal the oracle's
+single-process result bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _shards(rs, world, dev):
+    n = rs["n_reads"]
+    per = ((n // 2 + world - 1) // world) * 2                  # whole pairs
+    out = []
+    for r in range(world):
+        a, b = min(n, r * per), min(n, (r + 1) * per)
+        b0, b1 = int(rs["base_off"][a]), int(rs["base_off"][b])
+        q0, q1 = int(rs["pq_off"][a]), int(rs["pq_off"][b])
+        t = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x).astype(dt)).to(dev)
+        out.append((t(rs["packed"][b0:b1], np.uint8), t(rs["base_off"][a:b + 1] - rs["base_off"][a], np.int64),
+                    t(rs["read_len"][a:b], np.int32), t(rs["pq_bytes"][q0:q1], np.uint8),
+                    t(rs["pq_off"][a:b + 1] - rs["pq_off"][a], np.int64), t(rs["bc"][a:b], np.int32), a))
+    return out
+
+
+@pytest.mark.parametrize("world,K,ign", [(2, 48, 0), (4, 48, 3000), (8, 60, 0), (2, 40, 0)])
+def test_sharded_equals_single(oracle, world, K, ign):
+    from superplus_amd.dist import DistDfk, run_inprocess
+    rs = util.make_set(51 + world, 80000, 9000)
+    ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=K,
+                     ign_bc_below=ign)
+    dev = torch.device("cuda", 0)
+    ranks = [DistDfk(K=K, device=0, ign_bc_below=ign, keep_pre_adjacency=True) for _ in range(world)]
+    n_global = run_inprocess(ranks, _shards(rs, world, dev))
+    assert n_global == ref["n_inst"]
+    assert np.array_equal(np.concatenate([d.good_lens() for d in ranks]), ref["good_len"])
+    for pre in (True, False):
+        parts = [d.solid(pre_adjacency=pre) for d in ranks]
+        allk = np.concatenate(parts)
+        allk = allk[np.lexsort((allk["w1"], allk["w0"]))]
+        util.assert_same_solid(allk, ref["solid_pre" if pre else "solid"], f"world={world} pre={pre}")
+    assert min(len(d.solid()) for d in ranks) > 0               # every rank owns part of the set
+    hist = np.zeros(len(ref["hist"]), np.int64)
+    for d in ranks:
+        h = d.spectrum(); hist[: len(h)] += h
+    assert np.array_equal(hist, ref["hist"])
+    assert sum(d.stats()["n_distinct"] for d in ranks) == ref["n_distinct"]
