@@ -27,6 +27,7 @@
 //   mkreads  in.raw out_head             raw reads/quals -> out_head.{fastb,qualp} via
 //                                        the reference's BaseVec/PQVecEncoder/feudal writer
 //   rdreads  head out.raw                reference reader -> raw reads/quals
+//   side     head outdir                 .lens/.qhist/.dti/subsam.* as DF's ingest writes them (reference BinaryWriter)
 //   dict K head outdir minQual minFreq minBC useBC nThreads
 //                                        goodlens.u32, kmers.kvec (pre-adjacency, written by
 //                                        the reference's BinaryWriter), solid.bin (post
@@ -293,6 +294,36 @@ int rdreads( std::string const& head, char const* out )
     return 0;
 }
 
+// Side files DF's ingest writes next to the reads (10X/DF.cc:50-68,263-265; 10X/DfTools.cc:172-238), produced with the
+// reference's containers and BinaryWriter so that our front-end's serialisation can be compared byte for byte.
+struct SideDataSet { uint8_t dt; int64_t start; };                 // same layout as DataSet (10X/DfTools.h:30-45)
+TRIVIALLY_SERIALIZABLE(SideDataSet);
+
+int side( std::string const& head, std::string const& outdir )
+{
+    vecbvec reads; reads.ReadAll((head+".fastb").c_str());
+    VecPQVec quals; quals.ReadAll((head+".qualp").c_str());
+    vec<int64_t> bci; BinaryReader::readFile((head+".bci").c_str(),&bci);
+    vec<int16_t> lens(reads.size()); int maxLen = 0;
+    for ( size_t i = 0; i != reads.size(); ++i ) { lens[i] = reads[i].size(); if ( lens[i] > maxLen ) maxLen = lens[i]; }
+    vec<vec<vec<int64_t>>> hist( 2, vec<vec<int64_t>>( maxLen, vec<int64_t>(256,0) ) );
+    qvec q; int maxQ = -1;
+    for ( size_t id = 0; id != quals.size(); ++id )
+    { quals[id].unpack(&q);
+      for ( size_t pos = 0; pos != q.size(); ++pos ) { hist[id%2][pos][q[pos]]++; if ( q[pos] > maxQ ) maxQ = q[pos]; } }
+    for ( int pos = 0; pos != maxLen; ++pos ) { hist[0][pos].resize(maxQ+1); hist[1][pos].resize(maxQ+1); }
+    vec<SideDataSet> ds; SideDataSet a; memset(&a,0,sizeof a); a.dt = 2; a.start = 0; ds.push_back(a);
+    a.dt = 3; a.start = bci[1]; ds.push_back(a);
+    vec<String> names; names.push_back("C");
+    vec<int64_t> starts(1,0);
+    BinaryWriter::writeFile((outdir+"/frag_reads_orig.lens").c_str(),lens);
+    BinaryWriter::writeFile((outdir+"/frag_reads_orig.qhist").c_str(),hist);
+    BinaryWriter::writeFile((outdir+"/frag_reads_orig.dti").c_str(),ds);
+    BinaryWriter::writeFile((outdir+"/subsam.names").c_str(),names);
+    BinaryWriter::writeFile((outdir+"/subsam.starts").c_str(),starts);
+    return 0;
+}
+
 } // namespace
 
 int main( int argc, char** argv )
@@ -318,6 +349,7 @@ int main( int argc, char** argv )
     }
     if ( cmd == "mkreads" && argc == 4 ) return mkreads(argv[2],argv[3]);
     if ( cmd == "rdreads" && argc == 4 ) return rdreads(argv[2],argv[3]);
+    if ( cmd == "side" && argc == 4 ) return side(argv[2],argv[3]);
     if ( cmd == "dict" && argc == 10 )
     {
         unsigned K = atoi(argv[2]);

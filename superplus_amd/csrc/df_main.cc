@@ -1,0 +1,205 @@
+// superplus_amd/csrc/df_main.cc -- `DF` front-end for seam B2: keeps the reference's
+// command line (`DF ROOT=... LR=a.fastb[,b.fastb] [K=48 MIN_FREQ=3 MIN_BC=2 MIN_QUAL=7 OUT_DIR= ...]`,
+// 10X/DF.cc:79-195) and its on-disk inputs and outputs for the ingest + createDict part of the run:
+//
+//   reads  LR heads' .fastb/.qualp/.bci                                      (DF.cc:251-258)
+//   writes work_dir/data/frag_reads_orig.{fastb,qualp,bci}   LoadData        (10X/DfTools.cc:69-170)
+//          work_dir/data/frag_reads_orig.{lens,qhist,dti}    FirstLoadData   (DF.cc:50-68)
+//          work_dir/subsam.{names,starts}                                    (DF.cc:263-265,477-482)
+//          work_dir/stats/histogram_kmer_count.json          WriteKmerSpectrum (BuildReadQGraph48.cc:283-285)
+//          work_dir/kmers.kvec                               the dictionary  (BuildReadQGraph48.cc:287-288)
+//
+// The hot path itself runs in libdfk (HIP); this file is host plumbing only.  Not reproduced: the
+// 500-pair random sample frag_reads_orig.1000.* (write-only in the reference, needs its RNG) and
+// everything after createDict (graph build, pathing, the other seven stages), which are out of scope.
+#include "../../include/dfk.h"
+#include "feudal_io.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <ctime>
+#include <map>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+std::string date()
+{ time_t t = time(nullptr); char b[64]; strftime(b, sizeof b, "%a %b %d %H:%M:%S %Y", localtime(&t)); return b; }
+
+void mkpath(const std::string& p)
+{
+    for (size_t i = 1; i <= p.size(); ++i)
+        if (i == p.size() || p[i] == '/') mkdir(p.substr(0, i).c_str(), 0777);
+}
+
+bool is_file(const std::string& p) { struct stat s; return stat(p.c_str(), &s) == 0 && S_ISREG(s.st_mode); }
+
+[[noreturn]] void give_up(const std::string& msg) { printf("\n%s\nGiving up.\n", msg.c_str()); exit(1); }
+
+bool truthy(const std::string& v) { return v == "True" || v == "true" || v == "1" || v == "yes"; }
+
+// "{a,b}" or "a,b" -> list (ParseStringSet on "{" + LR + "}", DF.cc:247-248)
+std::vector<std::string> parse_set(std::string s)
+{
+    s.erase(std::remove(s.begin(), s.end(), '{'), s.end());
+    s.erase(std::remove(s.begin(), s.end(), '}'), s.end());
+    std::vector<std::string> out; std::stringstream ss(s); std::string tok;
+    while (std::getline(ss, tok, ',')) if (!tok.empty()) out.push_back(tok);
+    return out;
+}
+
+struct DataSet { uint8_t dt; uint8_t pad[7]; int64_t start; };   // 10X/DfTools.h:23-45; dt 2 = UNBAR_10X, 3 = BAR_10X
+static_assert(sizeof(DataSet) == 16, "DataSet is 16 bytes");
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    std::map<std::string, std::string> a = {
+        {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
+        {"OUT_DIR", ""}, {"LR", ""}, {"LR_SELECT_FRAC", "1.0"}, {"EXIT_LOAD", "False"}, {"DEVICE", "0"}, {"MAX_MEM_GB", "0"},
+        {"MINIMIZER", "0"}, {"KVEC", "True"}};
+    std::string command = "DF";
+    for (int i = 1; i < argc; ++i) {
+        std::string s = argv[i]; command += " " + s;
+        size_t eq = s.find('=');
+        if (eq == std::string::npos) give_up("DF: arguments are KEY=VALUE; got '" + s + "'");
+        a[s.substr(0, eq)] = s.substr(eq + 1);        // other reference arguments (PIPELINE, ALIGN, NUM_THREADS ...) are accepted and unused
+    }
+    const unsigned K = (unsigned)atoi(a["K"].c_str());
+    if (K != 40 && K != 48 && K != 60) give_up("K must be 40, 48 or 60");                        // DF.cc:209
+    if (a["LR"].empty()) give_up("I'm not sure you really want to do this, since it may\ndelete your starting files.  So I'm going to quit.");
+    for (const std::string& f : parse_set(a["LR_SELECT_FRAC"]))
+        if (atof(f.c_str()) != 1.0) give_up("LR_SELECT_FRAC != 1.0 needs the reference's random number stream; not supported");
+
+    std::string work_dir = a["ROOT"] + "/GapToy/" + a["INSTANCE"];                                  // DF.cc:221-222
+    if (!a["OUT_DIR"].empty()) work_dir = a["OUT_DIR"];
+    mkpath(work_dir); mkpath(work_dir + "/data"); mkpath(work_dir + "/stats"); mkpath(work_dir + "/logs");
+    { FILE* f = fopen((work_dir + "/the_command").c_str(), "a"); if (f) { char h[256] = "host"; gethostname(h, sizeof h); fprintf(f, "\n%s: %s\n", h, command.c_str()); fclose(f); } }
+
+    std::vector<std::string> heads;
+    for (std::string lr : parse_set(a["LR"])) {
+        size_t p = lr.find(".fastb");
+        std::string head = p == std::string::npos ? lr : lr.substr(0, p);
+        if (!is_file(head + ".fastb") || !is_file(head + ".qualp") || !is_file(head + ".bci"))
+            give_up("Can't file your LR input files " + head + ".*.");                             // DF.cc:251-258
+        heads.push_back(head);
+    }
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        // ---- LoadData (10X/DfTools.cc:69-170): unbarcoded pairs of every input first, then barcoded pairs
+        //      barcode by barcode; bci rebuilt; pairs stay together (even = R1, odd = R2).
+        printf("%s: reading in linked read data\n", date().c_str());
+        struct In { std::vector<uint8_t> packed, pq; std::vector<uint64_t> boff, qoff; std::vector<uint32_t> len; std::vector<int64_t> bci; };
+        std::vector<In> ins(heads.size());
+        for (size_t i = 0; i < heads.size(); ++i) {
+            feudal::read_fastb(heads[i] + ".fastb", &ins[i].packed, &ins[i].boff, &ins[i].len);
+            feudal::read_qualp(heads[i] + ".qualp", &ins[i].pq, &ins[i].qoff);
+            ins[i].bci = feudal::read_bci(heads[i] + ".bci");
+            const In& x = ins[i];
+            if (x.qoff.size() != x.boff.size()) throw std::runtime_error(heads[i] + ": .fastb and .qualp disagree on the number of reads");
+            if (x.bci.size() < 2 || x.bci[0] != 0) throw std::runtime_error("barcode 0 is unbarcoded data and must start at 0");
+            if (x.bci[1] % 2 || (uint64_t)x.bci[1] > x.len.size() || (uint64_t)x.bci.back() > x.len.size())
+                throw std::runtime_error(heads[i] + ": .bci does not describe these reads");
+        }
+        feudal::Reads R;
+        std::vector<int64_t> bci{0};
+        std::vector<DataSet> datasets;
+        R.base_off.push_back(0); R.pq_off.push_back(0);
+        auto append = [&](const In& x, int64_t lo, int64_t hi) {
+            if (hi <= lo) return;
+            R.packed.insert(R.packed.end(), x.packed.begin() + x.boff[lo], x.packed.begin() + x.boff[hi]);
+            R.pq.insert(R.pq.end(), x.pq.begin() + x.qoff[lo], x.pq.begin() + x.qoff[hi]);
+            for (int64_t r = lo; r < hi; ++r) {
+                R.base_off.push_back(R.base_off.back() + (x.boff[r + 1] - x.boff[r]));
+                R.pq_off.push_back(R.pq_off.back() + (x.qoff[r + 1] - x.qoff[r]));
+                R.read_len.push_back(x.len[r]);
+            }
+        };
+        for (const In& x : ins) {                                                                   // PASS_UNBARCODED
+            DataSet d{}; d.dt = 2; d.start = (int64_t)R.size(); datasets.push_back(d);
+            append(x, 0, x.bci[1]);
+        }
+        for (const In& x : ins) {                                                                   // PASS_BARCODED
+            DataSet d{}; d.dt = 3; d.start = (int64_t)R.size(); datasets.push_back(d);
+            for (size_t b = 1; b + 1 < x.bci.size(); ++b) { bci.push_back((int64_t)R.size()); append(x, x.bci[b], x.bci[b + 1]); }
+        }
+        bci.push_back((int64_t)R.size());
+        ins.clear();
+        const std::string rh = work_dir + "/data/frag_reads_orig";
+        feudal::write_fastb(rh + ".fastb", R.packed.data(), R.base_off, R.read_len);
+        feudal::write_qualp(rh + ".qualp", R.pq.data(), R.pq_off);
+        { feudal::BinWriter w(rh + ".bci"); w.vec(bci); }
+        printf("%s: loaded %zu reads\n", date().c_str(), R.size());
+        for (const DataSet& d : datasets) printf("\t%s starts at %ld\n", d.dt == 2 ? "UNBAR_10X" : "BAR_10X", (long)d.start);
+
+        // ---- lens, quality histogram, datasets (DF.cc:50-68, DfTools.cc:172-238)
+        std::vector<int16_t> lens(R.size()); int max_len = 0;
+        for (size_t i = 0; i < R.size(); ++i) { lens[i] = (int16_t)R.read_len[i]; max_len = std::max<int>(max_len, lens[i]); }
+        printf("%s: computing quality histogram\n", date().c_str());
+        std::vector<int64_t> qh((size_t)2 * max_len * 256, 0);                  // [parity][pos][q]
+        int max_q = -1;
+        for (size_t r = 0; r < R.size(); ++r) {
+            const uint8_t* p = R.pq.data() + R.pq_off[r]; const uint8_t* end = R.pq.data() + R.pq_off[r + 1];
+            int pos = 0;
+            while (p < end && *p) {                                            // PQVec blocks (feudal/PQVec.cc:87-127)
+                unsigned nQs = p[0], hdr = p[1] | (p[2] << 8), nBits = hdr & 7, minQ = (hdr >> 3) & 63;
+                uint64_t bit = 17;
+                for (unsigned i = 0; i < nQs; ++i, bit += nBits) {
+                    unsigned v = 0;
+                    for (unsigned b = 0; b < nBits; ++b) v |= ((p[(bit + b) >> 3] >> ((bit + b) & 7)) & 1u) << b;
+                    int q = (int)(minQ + v);
+                    if (pos < max_len) { qh[((r & 1) * max_len + pos) * 256 + q]++; max_q = std::max(max_q, q); }
+                    ++pos;
+                }
+                p += ((uint64_t)nQs * nBits + 24) >> 3;
+            }
+        }
+        { feudal::BinWriter w(rh + ".lens"); w.vec(lens); }
+        { feudal::BinWriter w(rh + ".qhist");                                   // vec<vec<vec<int64_t>>> [2][max_len][max_q+1]
+          w.pod<uint64_t>(2);
+          for (int par = 0; par < 2; ++par) {
+              w.pod<uint64_t>((uint64_t)max_len);
+              for (int pos = 0; pos < max_len; ++pos) { w.pod<uint64_t>((uint64_t)(max_q + 1)); w.raw(&qh[((size_t)par * max_len + pos) * 256], 8 * (size_t)(max_q + 1)); }
+          } }
+        { feudal::BinWriter w(rh + ".dti"); w.vec(datasets); }
+        { feudal::BinWriter w(work_dir + "/subsam.names"); w.pod<uint64_t>(1); w.str("C"); }
+        { feudal::BinWriter w(work_dir + "/subsam.starts"); w.vec(std::vector<int64_t>{0}); }
+        if (truthy(a["EXIT_LOAD"])) return 0;                                   // DF.cc:483
+
+        // ---- barcode expansion (DF.cc:447-452) and createDict on the GPU
+        std::vector<int32_t> bc(R.size(), 0);
+        for (size_t b = 0; b + 1 < bci.size(); ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
+        dfk_config cfg{};
+        cfg.abi_version = DFK_ABI_VERSION; cfg.K = K; cfg.min_qual = (uint32_t)atoi(a["MIN_QUAL"].c_str());
+        cfg.min_freq = (uint32_t)atoi(a["MIN_FREQ"].c_str()); cfg.min_bc = (uint32_t)atoi(a["MIN_BC"].c_str());
+        cfg.device = atoi(a["DEVICE"].c_str()); cfg.ign_bc_below = 0;           // bc_start = 0 for LR-only input (DF.cc:344-349)
+        cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
+        cfg.hbm_budget_bytes = (uint64_t)atoll(a["MAX_MEM_GB"].c_str()) << 30;  // 0 = 90 % of free HBM
+        dfk_ctx* ctx = nullptr;
+        if (dfk_create(&cfg, &ctx)) { fprintf(stderr, "DF: %s\n", dfk_last_error()); return 1; }
+        printf("%s: building dictionary on the GPU\n", date().c_str());
+        int rc = dfk_count(ctx, R.packed.data(), R.base_off.data(), R.read_len.data(), R.pq.data(), R.pq_off.data(), bc.data(), R.size());
+        if (rc == DFK_E_NOGOOD) { printf("\nLooks like your input data have almost no good bases.\nGiving up.\n\n"); return 1; }   // :227-230
+        if (rc) { fprintf(stderr, "DF: %s\n", dfk_last_error()); return rc == DFK_E_NOMEM ? 185 : 1; }                       // Martian::exit code
+        uint64_t need = 0; dfk_spectrum_json(ctx, nullptr, 0, &need);
+        std::string js(need, '\0'); dfk_spectrum_json(ctx, &js[0], need, &need);
+        { FILE* f = fopen((work_dir + "/stats/histogram_kmer_count.json").c_str(), "wb"); if (!f) throw std::runtime_error("cannot write spectrum"); fwrite(js.data(), 1, js.size(), f); fclose(f); }
+        uint64_t nk = 0; dfk_solid_count(ctx, &nk);
+        if (truthy(a["KVEC"])) { printf("%s: writing kmers.kvec\n", date().c_str()); if (dfk_write_kvec(ctx, (work_dir + "/kmers.kvec").c_str(), 0)) throw std::runtime_error(dfk_last_error()); }
+        dfk_stats st{}; dfk_get_stats(ctx, &st);
+        dfk_destroy(ctx);
+        double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("%s: dictionary covers %llu kmers\n", date().c_str(), (unsigned long long)nk);
+        printf("%s: %llu k-mer instances, GPU %.1f ms (count kernel %.1f ms), ingest+count stage %.2f s wall\n", date().c_str(),
+               (unsigned long long)st.n_inst, st.ms_total, st.ms_count, secs);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "DF: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -75,6 +75,9 @@ def main():
     head = os.path.join(HERE, "reads")
     subprocess.check_call([REFDRV, "mkreads", raw, head], stdout=subprocess.DEVNULL)
     feudal.write_bci(head + ".bci", bci)
+    side = os.path.join(HERE, "side")
+    os.makedirs(side, exist_ok=True)
+    subprocess.check_call([REFDRV, "side", head, side])      # .lens/.qhist/.dti/subsam.* via the reference's BinaryWriter
     for K, use_bc, min_bc, tag in ((48, 1, 2, "k48"), (48, 1, 1, "k48_minbc1"), (40, 0, 0, "k40_nobc"), (60, 0, 0, "k60_nobc")):
         out = os.path.join(HERE, "tmp_" + tag)
         os.makedirs(out, exist_ok=True)

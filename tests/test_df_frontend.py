@@ -1,0 +1,84 @@
+"""The `DF` front-end (seam B2).  Ingest is host-only, so these run on the CPU: DF ... EXIT_LOAD=True
+must reproduce the files the reference's LoadData/FirstLoadData write (tests/golden/side/* were written
+by the reference's own BinaryWriter and containers through oracle/_ref/refdrv)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from superplus_amd import feudal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DF = os.path.join(ROOT, "superplus_amd", "DF")
+
+
+def run_df(*args):
+    return subprocess.run([DF, *args], capture_output=True, text=True)
+
+
+def test_ingest_matches_reference_side_files(tmp_path, golden_dir):
+    r = run_df(f"LR={golden_dir}/reads.fastb", f"OUT_DIR={tmp_path}/w", "EXIT_LOAD=True", "PIPELINE=cs", "NUM_THREADS=4")
+    assert r.returncode == 0, r.stdout + r.stderr
+    rd = lambda p: open(p, "rb").read()
+    for ext in ("fastb", "qualp", "bci"):          # one LR input already in LoadData order: copied verbatim
+        assert rd(f"{tmp_path}/w/data/frag_reads_orig.{ext}") == rd(f"{golden_dir}/reads.{ext}"), ext
+    for name in ("frag_reads_orig.lens", "frag_reads_orig.qhist"):
+        assert rd(f"{tmp_path}/w/data/{name}") == rd(f"{golden_dir}/side/{name}"), name
+    # .dti: 16-byte records {u8 dt, 7 pad bytes (undefined in the reference), i64 start} -- compare fields
+    dt = np.dtype([("dt", "u1"), ("pad", "V7"), ("start", "<i8")])
+    a = np.frombuffer(rd(f"{tmp_path}/w/data/frag_reads_orig.dti")[16:], dt)
+    b = np.frombuffer(rd(f"{golden_dir}/side/frag_reads_orig.dti")[16:], dt)
+    assert list(a["dt"]) == list(b["dt"]) == [2, 3] and list(a["start"]) == list(b["start"])
+    assert rd(f"{tmp_path}/w/subsam.starts") == rd(f"{golden_dir}/side/subsam.starts")
+    # FeudalString writes size+1 bytes; the byte after the text is whatever follows it in the reference
+    assert rd(f"{tmp_path}/w/subsam.names")[:-1] == rd(f"{golden_dir}/side/subsam.names")[:-1]
+    assert "the_command" in os.listdir(f"{tmp_path}/w")
+
+
+def test_two_inputs_reordered_like_loaddata(tmp_path, golden_dir):
+    """LoadData (10X/DfTools.cc:99-160): all inputs' unbarcoded pairs first, then barcoded pairs input by input,
+    barcode by barcode, with the barcode index rebuilt."""
+    packed, boff, rlen = feudal.read_fastb(f"{golden_dir}/reads.fastb")
+    pq, qoff = feudal.read_qualp(f"{golden_dir}/reads.qualp")
+    bci = feudal.read_bci(f"{golden_dir}/reads.bci")
+    # second input = a slice of the first: unbarcoded [0,100) + barcodes 1..3
+    cut = int(bci[4])
+    def sub(lo, hi):
+        return (packed[int(boff[lo]):int(boff[hi])], boff[lo:hi + 1] - boff[lo], rlen[lo:hi],
+                pq[int(qoff[lo]):int(qoff[hi])], qoff[lo:hi + 1] - qoff[lo])
+    u = sub(0, 100); b = sub(int(bci[1]), cut)
+    p2 = np.concatenate([u[0], b[0]]); bo2 = np.concatenate([u[1], b[1][1:] + u[1][-1]]); l2 = np.concatenate([u[2], b[2]])
+    q2 = np.concatenate([u[3], b[3]]); qo2 = np.concatenate([u[4], b[4][1:] + u[4][-1]])
+    bci2 = np.concatenate([[0], bci[1:5] - bci[1] + 100]).astype(np.int64)
+    feudal.write_fastb(f"{tmp_path}/b.fastb", p2, bo2, l2); feudal.write_qualp(f"{tmp_path}/b.qualp", q2, qo2)
+    feudal.write_bci(f"{tmp_path}/b.bci", bci2)
+    r = run_df("LR={" + f"{golden_dir}/reads.fastb,{tmp_path}/b.fastb" + "}", f"ROOT={tmp_path}", "EXIT_LOAD=True")
+    assert r.returncode == 0, r.stdout + r.stderr
+    w = f"{tmp_path}/GapToy/1/data/frag_reads_orig"
+    _, obo, ol = feudal.read_fastb(w + ".fastb")
+    obci = feudal.read_bci(w + ".bci")
+    n1, nu1 = len(rlen), int(bci[1])
+    exp_len = np.concatenate([rlen[:nu1], l2[:100], rlen[nu1:], l2[100:]])
+    assert np.array_equal(ol, exp_len)
+    exp_bci = np.concatenate([[0], bci[1:-1] + 100, (bci2[1:-1] - 100) + n1 + 100, [n1 + len(l2)]])
+    assert np.array_equal(obci, exp_bci)
+    assert "UNBAR_10X starts at 0" in r.stdout and f"BAR_10X starts at {nu1 + 100}" in r.stdout
+
+
+def test_missing_input_gives_up_like_the_reference(tmp_path):
+    r = run_df(f"LR={tmp_path}/nope.fastb", f"OUT_DIR={tmp_path}/w")
+    assert r.returncode == 1 and "Can't file your LR input files" in r.stdout
+    assert run_df("K=47", "LR=x").returncode == 1
+
+
+@pytest.mark.gpu
+def test_df_end_to_end_on_gpu(tmp_path, golden_dir, oracle):
+    r = run_df(f"LR={golden_dir}/reads.fastb", f"OUT_DIR={tmp_path}/w", "K=48")
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = np.load(f"{golden_dir}/expect_k48.npz")
+    assert open(f"{tmp_path}/w/stats/histogram_kmer_count.json").read() == oracle.spectrum_json(exp["spectrum"])
+    kv = open(f"{tmp_path}/w/kmers.kvec", "rb").read()
+    assert kv[:8] == b"BINWRITE" and int.from_bytes(kv[8:16], "little") == len(exp["solid_post"])
+    assert kv[16:] == exp["solid_post"].tobytes()
+    assert f"dictionary covers {len(exp['solid_post']):,}".replace(",", "") in r.stdout.replace(",", "")
