@@ -59,7 +59,7 @@ struct dfk_ctx {
     uint64_t n_reads = 0;
     DevBuf good_len;                          // u32[n_reads]
     DevBuf solid, solid_pre;                  // dfk_entry32[n_solid]
-    uint64_t n_solid = 0;
+    uint64_t n_solid = 0, n_boundary = 0;
     std::vector<int64_t> hist;
     std::vector<dfk_entry32> sorted, sorted_pre;
     bool sorted_ok = false, sorted_pre_ok = false;
@@ -74,15 +74,39 @@ struct dfk_ctx {
     DevBuf set; uint64_t set_mask = 0;
     uint32_t shard_world = 1, shard_log2_nb = 0;
 
+    // Freed blocks are kept and reused (hipMalloc/hipFree of multi-GB blocks cost milliseconds each and
+    // hipFree synchronises the device); the pool counts against the same budget.
+    struct Block { void* p; size_t bytes; };
+    std::vector<Block> pool;
+    uint64_t pooled = 0;
+
+    void trim_pool(uint64_t need)
+    {
+        while (!pool.empty() && held + pooled + need > budget) {
+            (void)hipFree(pool.back().p); pooled -= pool.back().bytes; pool.pop_back();
+        }
+    }
     int alloc(DevBuf& b, size_t bytes, const char* what)
     {
-        bytes = bytes ? bytes : 16;
-        if (held + bytes > budget)
-            return fail(DFK_E_NOMEM, "HBM budget exceeded allocating %zu bytes for %s (held %llu, budget %llu)",
-                        bytes, what, (unsigned long long)held, (unsigned long long)budget);
-        hipError_t e = hipMalloc(&b.p, bytes);
-        if (e != hipSuccess) return fail(DFK_E_NOMEM, "hipMalloc(%zu) for %s: %s", bytes, what, hipGetErrorString(e));
-        b.bytes = bytes; held += bytes; peak = std::max(peak, held);
+        bytes = bytes ? (bytes + 255) & ~(size_t)255 : 256;
+        size_t best = pool.size();
+        for (size_t i = 0; i < pool.size(); ++i)
+            if (pool[i].bytes >= bytes && pool[i].bytes <= bytes + bytes / 2 + (1u << 20) &&
+                (best == pool.size() || pool[i].bytes < pool[best].bytes)) best = i;
+        if (best != pool.size()) {
+            b.p = pool[best].p; b.bytes = pool[best].bytes; pooled -= b.bytes;
+            pool.erase(pool.begin() + best);
+        } else {
+            if (held + bytes > budget)
+                return fail(DFK_E_NOMEM, "HBM budget exceeded allocating %zu bytes for %s (held %llu, budget %llu)",
+                            bytes, what, (unsigned long long)held, (unsigned long long)budget);
+            trim_pool(bytes);
+            hipError_t e = hipMalloc(&b.p, bytes);
+            if (e != hipSuccess && !pool.empty()) { trim_pool(budget); e = hipMalloc(&b.p, bytes); }
+            if (e != hipSuccess) return fail(DFK_E_NOMEM, "hipMalloc(%zu) for %s: %s", bytes, what, hipGetErrorString(e));
+            b.bytes = bytes;
+        }
+        held += b.bytes; peak = std::max(peak, held);
         owned.push_back(b.p);
         return 0;
     }
@@ -91,11 +115,16 @@ struct dfk_ctx {
         if (!b.p) return;
         auto it = std::find(owned.begin(), owned.end(), b.p);
         if (it != owned.end()) owned.erase(it);
-        (void)hipFree(b.p); held -= b.bytes; b.p = nullptr; b.bytes = 0;
+        pool.push_back(Block{b.p, b.bytes}); pooled += b.bytes;
+        held -= b.bytes; b.p = nullptr; b.bytes = 0;
     }
+    void drop_pool() { for (Block& k : pool) (void)hipFree(k.p); pool.clear(); pooled = 0; }
     void release_all()
     {
-        for (void* p : owned) (void)hipFree(p);
+        // results of the previous run go back to the pool (sizes come from the DevBufs that own them)
+        DevBuf* live[] = {&good_len, &solid, &solid_pre, &shard_records, &adj_keys, &adj_src, &set};
+        for (DevBuf* d : live) release(*d);
+        for (void* p : owned) (void)hipFree(p);                        // anything an aborted run left behind
         owned.clear(); held = 0;
         good_len = solid = solid_pre = shard_records = adj_keys = adj_src = set = DevBuf{};
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
@@ -126,7 +155,7 @@ int stage_trim(dfk_ctx* c, const Inputs& in, uint64_t* n_inst)
     HIP_TRY(hipMemsetAsync(ctr.p, 0, 32, c->stream));
     rc = c->alloc(c->good_len, sizeof(uint32_t) * in.n_reads, "goodLens"); if (rc) return rc;
     if (in.n_reads) {
-        unsigned grid = (unsigned)((in.n_reads + 255) / 256);
+        unsigned grid = (unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trim<K>), dim3(grid), dim3(256), 0, c->stream,
                            in.pq, in.pq_off, in.read_len, in.n_reads, c->cfg.min_qual, (uint32_t*)c->good_len.p,
                            (unsigned long long*)ctr.p, (unsigned int*)((char*)ctr.p + 8),
@@ -336,7 +365,8 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     HIP_TRY(hipMemsetAsync(d_segcnt.p, 0, 4ull * nseg, c->stream));
     HIP_TRY(hipMemsetAsync(d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
     HIP_TRY(hipMemsetAsync(d_g.p, 0, sizeof(CountGlobals), c->stream));
-    R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, nseg, seg_cap};
+    R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, nseg, seg_cap, c->cfg.min_freq > 1 ? 1u : 0u,
+                       (c->cfg.flags & DFK_F_KEEP_PRE_ADJ) ? 1u : 0u};
     R.g = (CountGlobals*)d_g.p; R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p;
     R.hist = (unsigned long long*)d_hist.p;
 
@@ -384,6 +414,7 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     std::vector<uint64_t> prefix(nseg + 1, 0);
     for (uint32_t s = 0; s < nseg; ++s) prefix[s + 1] = prefix[s] + segcnt[s];
     c->n_solid = prefix[nseg] + hg.big_cursor; c->st.n_solid = c->n_solid; c->st.n_distinct = hg.n_distinct;
+    c->n_boundary = hg.n_boundary;
 
     // dense solid array
     DevBuf d_prefix;
@@ -413,10 +444,12 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
 }
 
 // ------------------------------------------------------------------ stage: adjacency (a6)
+// k_count has already settled every context bit whose neighbour was counted in the same table.  What is
+// left (pad byte 0 of an entry) concerns neighbours in other items: those k-mers go into an HBM set.
 int build_set(dfk_ctx* c)
 {
-    uint64_t slots = 1ull << std::max<uint32_t>(10, ceil_log2(2 * c->n_solid + 2));
-    int rc = c->alloc(c->set, slots * sizeof(SetSlot), "solid k-mer set"); if (rc) return rc;
+    uint64_t slots = 1ull << std::max<uint32_t>(10, ceil_log2(2 * c->n_boundary + 2));
+    int rc = c->alloc(c->set, slots * sizeof(SetSlot), "boundary k-mer set"); if (rc) return rc;
     c->set_mask = slots - 1;
     hipLaunchKernelGGL(k_fill_u64, dim3(2048), dim3(256), 0, c->stream, (uint64_t*)c->set.p, slots * 2, ~0ull);
     if (c->n_solid)
@@ -426,20 +459,32 @@ int build_set(dfk_ctx* c)
     return 0;
 }
 
+// DFK_F_KEEP_PRE_ADJ: the kmers.kvec view (contexts before any clean-up)
+int make_pre_view(dfk_ctx* c)
+{
+    if (!(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return 0;
+    int rc = c->alloc(c->solid_pre, c->n_solid * 32, "pre-adjacency copy"); if (rc) return rc;
+    if (!c->n_solid) return 0;
+    if (c->cfg.min_freq > 1)
+        hipLaunchKernelGGL(k_make_pre, dim3((unsigned)((c->n_solid + 255) / 256)), dim3(256), 0, c->stream,
+                           (uint4*)c->solid.p, (uint4*)c->solid_pre.p, c->n_solid);
+    else
+        HIP_TRY(hipMemcpyAsync(c->solid_pre.p, c->solid.p, c->n_solid * 32, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int K>
 int stage_adjacency(dfk_ctx* c)
 {
     Timer t(c->stream);
     t.start();
-    if (c->cfg.flags & DFK_F_KEEP_PRE_ADJ) {
-        int rc = c->alloc(c->solid_pre, c->n_solid * 32, "pre-adjacency copy"); if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(c->solid_pre.p, c->solid.p, c->n_solid * 32, hipMemcpyDeviceToDevice, c->stream));
-    }
-    if (c->cfg.min_freq > 1 && c->n_solid) {                       // BuildReadQGraph48.cc:313
-        int rc = build_set(c); if (rc) return rc;
+    int rc = make_pre_view(c); if (rc) return rc;
+    if (c->cfg.min_freq > 1 && c->n_solid && c->n_boundary) {          // BuildReadQGraph48.cc:313
+        rc = build_set(c); if (rc) return rc;
         DevBuf d_n; rc = c->alloc(d_n, 16, "probe counter"); if (rc) return rc;
         HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adjacency<K>), dim3((unsigned)((c->n_solid + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adjacency<K>), dim3((unsigned)std::min<uint64_t>((c->n_solid + 255) / 256, 8192)), dim3(256), 0, c->stream,
                            (uint4*)c->solid.p, c->n_solid, (const SetSlot*)c->set.p, c->set_mask, (unsigned long long*)d_n.p);
         HIP_TRY(hipGetLastError());
         uint64_t np = 0;
@@ -555,6 +600,7 @@ void dfk_destroy(dfk_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->release_all();
+    c->drop_pool();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

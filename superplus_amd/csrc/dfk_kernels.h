@@ -19,9 +19,12 @@ k_trim(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, cons
        unsigned long long* __restrict__ n_inst, unsigned int* __restrict__ bad,
        unsigned long long* __restrict__ sum_good)
 {
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t gl = 0;
-    if (r < n_reads) {
+    // grid-stride: the totals are reduced per block, so the three global atomics are issued once per
+    // block (same-address atomics run at ~88 per microsecond on this chip; one per wave of reads cost 10 ms)
+    unsigned long long mine = 0, good = 0;
+    bool any_bad = false;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t gl = 0;
         uint64_t p = pq_off[r], end = pq_off[r + 1];
         uint32_t idx = 0, run = 0;
         bool ok = true;
@@ -51,17 +54,27 @@ k_trim(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, cons
             p += blk;
         }
         uint32_t rl = read_len[r];
-        if (!ok || idx != rl) { atomicOr(bad, 1u); gl = 0; }
+        if (!ok || idx != rl) { any_bad = true; gl = 0; }
         if (gl > rl) gl = rl;
         good_len[r] = gl;
+        good += gl;
+        if (gl >= (uint32_t)K + 1) mine += gl - K + 1;
     }
-    // instance total: wave reduce, one atomic per wave
-    unsigned long long mine = gl >= (uint32_t)K + 1 ? (unsigned long long)(gl - K + 1) : 0ull;
-    unsigned long long good = gl;
+    __shared__ unsigned long long sh[2][4];
+    __shared__ unsigned int sh_bad;
+    if (threadIdx.x == 0) sh_bad = 0;
+    __syncthreads();
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { mine += __shfl_down(mine, d, 64); good += __shfl_down(good, d, 64); }
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_inst, mine);
-    if ((threadIdx.x & 63) == 0 && good) atomicAdd(sum_good, good);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = mine; sh[1][threadIdx.x >> 6] = good; }
+    if (any_bad) atomicOr(&sh_bad, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a0 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], a1 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        if (a0) atomicAdd(n_inst, a0);
+        if (a1) atomicAdd(sum_good, a1);
+        if (sh_bad) atomicOr(bad, 1u);
+    }
 }
 
 // ============================================================================ a2 (first half): super-k-mer partition
@@ -237,8 +250,10 @@ struct CountItem { uint64_t rec_begin; uint64_t rec_end; };
 struct CountParams {
     uint32_t min_freq, min_bc;
     uint32_t n_items;
-    uint32_t n_segments;             // output segments (one per persistent workgroup) + 1 for the HBM fallback
+    uint32_t n_segments;             // output segments (one per persistent workgroup)
     uint64_t seg_cap;                // entries per segment
+    uint32_t do_adj;                 // resolve adjacencies inside the table where possible (min_freq > 1)
+    uint32_t keep_pre;               // keep the pre-adjacency context byte in the entry's pad field (tests)
 };
 
 struct CountGlobals {                // device-resident counters
@@ -248,12 +263,15 @@ struct CountGlobals {                // device-resident counters
     unsigned int n_overflow;         // items that overflowed their table
     unsigned int solid_overflow;     // an output segment ran out of room
     unsigned int pad;
+    unsigned long long n_boundary;   // solid entries left with unresolved (cross-item) context bits
 };
 
 constexpr int COUNT_HIST_BINS = 1024;
 constexpr uint32_t COUNT_MAX_PROBE = 96;
 constexpr uint32_t HIST_GLOBAL_BINS = 1u << 24;   // KDef count saturates at 2^24-1 (ReadPather.h:128-129)
 constexpr int COUNT_CHUNK = 32;                   // records a wave stages at a time
+constexpr uint32_t ADJ_TASKS = 4096;              // neighbour look-ups queued per table in LDS
+constexpr uint32_t FLAG_SOLID = 0x80000000u;      // barcode word reused after counting: solid flag | unresolved context bits
 
 template <int K> struct WaveStage {               // per-wave private LDS
     uint32_t rec[COUNT_CHUNK * 8 + 8];            // staged records (+ pad for the 5-word window read)
@@ -406,49 +424,159 @@ __device__ __forceinline__ bool bc_pass(uint32_t v, uint32_t min_bc)
     return (v & BCW_MULTI) != 0;                                     // >= 2 distinct barcodes > 0, or an ignored (-1) one
 }
 
-// Emit the solid slots of a finished table into this workgroup's output segment and the
-// spectrum.  `cursor` is the segment's fill count: an LDS word for k_count (no global atomics,
-// no barriers), a global word for the HBM fallback.
-template <int K, bool USE_BC, bool LDS_HIST>
-__device__ __forceinline__ uint32_t table_emit(const uint32_t* keys, const uint32_t* cnt, const uint32_t* ctxs, const uint32_t* bcw,
-                                               uint32_t S, const CountParams& cp, uint4* __restrict__ seg_out,
-                                               unsigned long long* cursor64, uint32_t* cursor32, unsigned int* seg_overflow,
-                                               uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
-                                               int tid, int nthreads)
+// Look a canonical k-mer up in a finished table (no concurrent inserts).  Returns its slot or ~0.
+template <int KW>
+__device__ __forceinline__ uint32_t table_find(const uint32_t* keys, const uint32_t* cnt, uint32_t S, u128 c)
 {
+    const uint32_t k0 = (uint32_t)c.lo, k1 = (uint32_t)(c.lo >> 32), k2 = (uint32_t)c.hi, k3 = (uint32_t)(c.hi >> 32);
+    uint32_t slot = key_hash(c) & (S - 1);
+    for (uint32_t p = 0; p <= COUNT_MAX_PROBE + 1; ++p) {
+        if (tld(&cnt[slot]) == 0) return ~0u;
+        bool same = tld(&keys[slot]) == k0 && tld(&keys[S + slot]) == k1 && tld(&keys[2 * S + slot]) == k2;
+        if (KW == 4) same = same && tld(&keys[3 * S + slot]) == k3;
+        if (same) return slot;
+        slot = (slot + 1) & (S - 1);
+    }
+    return ~0u;
+}
+
+// canonical 2K-bit value of a k-mer given as a 2K-bit big-endian value
+template <int K>
+__device__ __forceinline__ u128 canon_value(u128 F)
+{
+    const u128 m = KTraits<K>::mask();
+    u128 nf{~F.lo & m.lo, ~F.hi & m.hi};
+    u128 top = shl128(nf, 128 - KTraits<K>::BITS);
+    u128 R{rev2_64(top.hi), rev2_64(top.lo)};
+    return lt128(R, F) ? R : F;
+}
+
+// Finish a counted table: decide solidity, clean up adjacencies, emit.
+//
+// recomputeAdjacencies (ReadPather.h:329-364) keeps a context bit only if the neighbouring k-mer is
+// solid.  A neighbour observed next to this k-mer in a read almost always shares its minimizer bucket
+// and therefore THIS table, which holds every instance of every k-mer it contains.  So:
+//   pass 1  every slot: solid?  the barcode word becomes {FLAG_SOLID | unresolved bits}; each set context
+//           bit of a solid slot becomes a task (slot, bit) in an LDS queue
+//   pass 2  tasks, densely over the threads: neighbour found in this table -> keep the bit iff that slot
+//           is solid (final answer); not found -> the neighbour lives in another item: bit stays, marked
+//           unresolved for the small HBM pass afterwards (k_adjacency) -- about one bit in ten
+//   pass 3  emit solid slots into the workgroup's output segment (LDS cursor) and the spectrum
+// `sync` is __syncthreads for the whole workgroup.
+template <int K, bool USE_BC, bool LDS_HIST>
+__device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
+                                                 uint32_t S, const CountParams& cp, uint4* __restrict__ seg_out,
+                                                 unsigned long long* cursor64, uint32_t* cursor32, unsigned int* seg_overflow,
+                                                 uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
+                                                 uint32_t* tasks, uint32_t* n_tasks, uint32_t* n_boundary,
+                                                 int tid, int nthreads)
+{
+    constexpr int KW = KTraits<K>::KW;
     const int lane = tid & 63;
     uint32_t n_occ = 0;
+    const u128 m = KTraits<K>::mask();
+    // one queued look-up: is the neighbour of `slot` across context bit `bit` in this table, and solid?
+    auto resolve = [&](uint32_t task) {
+        const uint32_t slot = task & 0x0FFFFFFFu, bit = task >> 28;
+        u128 F{(uint64_t)tld(&keys[slot]) | ((uint64_t)tld(&keys[S + slot]) << 32),
+               (uint64_t)tld(&keys[2 * S + slot]) | (KW == 4 ? ((uint64_t)tld(&keys[3 * S + slot]) << 32) : 0ull)};
+        u128 v;
+        if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }         // kmer[1:] + base
+        else {                                                                                 // base + kmer[:-1]
+            v = shr128(F, 2);
+            constexpr int TOP = KTraits<K>::BITS - 2;
+            if (TOP >= 64) v.hi |= (uint64_t)(bit - 4) << (TOP - 64); else v.lo |= (uint64_t)(bit - 4) << TOP;
+        }
+        const uint32_t f = table_find<KW>(keys, cnt, S, canon_value<K>(v));
+        if (f == ~0u) atomicOr(&bcw[slot], 1u << bit);                                         // lives in another item
+        else if (!(tld(&bcw[f]) & FLAG_SOLID)) atomicAnd(&ctxs[slot], ~(1u << bit));           // here, and not solid
+    };
+    auto sync = [&]() { if (!LDS_HIST) __threadfence(); __syncthreads(); };                   // HBM table: publish first
+    // ---- pass 1
     for (uint32_t base = 0; base < S; base += nthreads) {
         const uint32_t slot = base + tid;
-        uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
-        uint32_t count = c > 0xFFFFFFu ? 0xFFFFFFu : c;               // KDef::setCount saturation (ReadPather.h:128-129)
-        bool solid = c != 0 && count >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&bcw[slot]) : 0u, cp.min_bc);
-        n_occ += c != 0;
+        if (slot >= S) continue;
+        const uint32_t c = tld(&cnt[slot]);
+        if (!c) continue;
+        ++n_occ;
+        const uint32_t count = c > 0xFFFFFFu ? 0xFFFFFFu : c;
+        const bool solid = count >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&bcw[slot]) : 0u, cp.min_bc);
+        if (solid && cp.do_adj) {
+            const uint32_t ctx = tld(&ctxs[slot]) & 0xFFu;
+            if (cp.keep_pre) tst(&ctxs[slot], ctx | (ctx << 8));
+            const uint32_t nb = __popc(ctx);
+            uint32_t pos = nb ? atomicAdd(n_tasks, nb) : 0u;
+            if (pos + nb <= ADJ_TASKS)
+                for (uint32_t bit = 0; bit < 8; ++bit) if (ctx & (1u << bit)) tasks[pos++] = slot | (bit << 28);
+        }
+        tst(&bcw[slot], solid ? FLAG_SOLID : 0u);
+    }
+    sync();
+    // ---- pass 2
+    if (cp.do_adj) {
+        const uint32_t total = __builtin_amdgcn_readfirstlane(tld(n_tasks));
+        if (total <= ADJ_TASKS) {
+            for (uint32_t t = tid; t < total; t += nthreads) resolve(tasks[t]);
+            sync();
+        } else {
+            // more look-ups than the queue holds (a table full of solid k-mers): redo the queueing in slot
+            // ranges that cannot overflow it (<= 8 look-ups per slot)
+            for (uint32_t lo = 0; lo < S; lo += ADJ_TASKS / 8) {
+                __syncthreads();
+                if (tid == 0) tst(n_tasks, 0u);
+                __syncthreads();
+                for (uint32_t slot = lo + tid; slot < min(S, lo + ADJ_TASKS / 8); slot += nthreads) {
+                    if (!(tld(&cnt[slot]) && (tld(&bcw[slot]) & FLAG_SOLID))) continue;
+                    const uint32_t ctx = tld(&ctxs[slot]) & 0xFFu;
+                    uint32_t pos = atomicAdd(n_tasks, __popc(ctx));
+                    for (uint32_t bit = 0; bit < 8; ++bit) if (ctx & (1u << bit)) tasks[pos++] = slot | (bit << 28);
+                }
+                __syncthreads();
+                const uint32_t n = __builtin_amdgcn_readfirstlane(tld(n_tasks));
+                for (uint32_t t = tid; t < n; t += nthreads) resolve(tasks[t]);
+            }
+            sync();
+        }
+    }
+    // ---- pass 3
+    uint32_t boundary = 0;
+    for (uint32_t base = 0; base < S; base += nthreads) {
+        const uint32_t slot = base + tid;
+        const uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
+        const uint32_t flags = c ? tld(&bcw[slot]) : 0u;
+        const bool solid = (flags & FLAG_SOLID) != 0;
         unsigned long long m = __ballot(solid);
         if (!m) continue;
         uint32_t n = __popcll(m);
         unsigned long long wbase = 0;
         if (lane == 0) wbase = cursor32 ? (unsigned long long)atomicAdd(cursor32, n) : atomicAdd(cursor64, (unsigned long long)n);
-        wbase = __shfl(wbase, 0, 64);
+        wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
         if (solid) {
+            const uint32_t count = c > 0xFFFFFFu ? 0xFFFFFFu : c;      // KDef::setCount saturation (ReadPather.h:128-129)
+            const uint32_t cw = tld(&ctxs[slot]);
+            const uint32_t pending = flags & 0xFFu & cw;                // a bit cleared locally needs no further look-up
+            boundary += pending != 0;
             unsigned long long idx = wbase + __popcll(m & ((1ull << lane) - 1ull));
             if (idx < cp.seg_cap) {
                 u128 v{(uint64_t)tld(&keys[slot]) | ((uint64_t)tld(&keys[S + slot]) << 32),
-                       (uint64_t)tld(&keys[2 * S + slot]) | (KTraits<K>::KW == 4 ? ((uint64_t)tld(&keys[3 * S + slot]) << 32) : 0ull)};
+                       (uint64_t)tld(&keys[2 * S + slot]) | (KW == 4 ? ((uint64_t)tld(&keys[3 * S + slot]) << 32) : 0ull)};
                 u128 kw = shl128(v, 128 - KTraits<K>::BITS);           // left-align: KMer<K> storage
-                uint32_t cc = count | (tld(&ctxs[slot]) << 24);
                 seg_out[2 * idx] = uint4{(uint32_t)kw.hi, (uint32_t)(kw.hi >> 32), (uint32_t)kw.lo, (uint32_t)(kw.lo >> 32)};
-                seg_out[2 * idx + 1] = uint4{0xFFFFFFFFu, cc, 0xFFFFFFFFu, 0u};
+                // pad (word 3) carries the unresolved bits (and the original context for tests) until k_adjacency
+                seg_out[2 * idx + 1] = uint4{0xFFFFFFFFu, count | ((cw & 0xFFu) << 24), 0xFFFFFFFFu, pending | (cw & 0xFF00u)};
             } else atomicOr(seg_overflow, 1u);
             if (LDS_HIST && count < (uint32_t)COUNT_HIST_BINS) atomicAdd(&hist_lds[count], 1u);
             else atomicAdd(&hist_global[count], 1ull);
         }
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) boundary += __shfl_down(boundary, d, 64);
+    if (lane == 0 && boundary) atomicAdd(n_boundary, boundary);
     return n_occ;
 }
 
 // ctl words (LDS)
-enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_CURSOR = 4, CTL_DISTINCT = 5, CTL_N = 8 };
+enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_CURSOR = 4, CTL_DISTINCT = 5, CTL_NTASK = 6, CTL_BOUNDARY = 7, CTL_N = 8 };
 
 template <int K, int LOG2S, int NWAVES, bool USE_BC>
 __global__ void __launch_bounds__(NWAVES * 64)
@@ -466,16 +594,17 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
     uint32_t* bcw = ctxs + S;                       // [S]
     uint32_t* hist = bcw + S;                       // [COUNT_HIST_BINS]
     uint32_t* ctl = hist + COUNT_HIST_BINS;         // [CTL_N]
-    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(ctl + CTL_N);
+    uint32_t* tasks = ctl + CTL_N;                  // [ADJ_TASKS]
+    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(tasks + ADJ_TASKS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WaveStage<K>* st = stages + wave;
     uint4* seg_out = out + 2ull * cp.seg_cap * blockIdx.x;
 
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) hist[i] = 0;
-    if (tid == 0) { ctl[CTL_CURSOR] = seg_count[blockIdx.x]; ctl[CTL_DISTINCT] = 0; }
+    if (tid == 0) { ctl[CTL_CURSOR] = seg_count[blockIdx.x]; ctl[CTL_DISTINCT] = 0; ctl[CTL_BOUNDARY] = 0; }
     for (;;) {
         __syncthreads();
-        if (tid == 0) { ctl[CTL_ITEM] = atomicAdd(&g->next_item, 1u); ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; }
+        if (tid == 0) { ctl[CTL_ITEM] = atomicAdd(&g->next_item, 1u); ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0; }
         for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;             // slot state; the other words are written on claim
         __syncthreads();
         const uint32_t item = __builtin_amdgcn_readfirstlane(ctl[CTL_ITEM]);
@@ -498,8 +627,9 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
         if (__builtin_amdgcn_readfirstlane(ctl[CTL_OVF])) {
             if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = item;
         } else {
-            uint32_t occ = table_emit<K, USE_BC, true>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
-                                                       &g->solid_overflow, hist, hist_global, tid, NT);
+            uint32_t occ = table_finish<K, USE_BC, true>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
+                                                         &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
+                                                         &ctl[CTL_BOUNDARY], tid, NT);
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
             if (lane == 0 && occ) atomicAdd(&ctl[CTL_DISTINCT], occ);
@@ -511,13 +641,14 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
         uint32_t cur = ctl[CTL_CURSOR];
         seg_count[blockIdx.x] = cur > cp.seg_cap ? (uint32_t)cp.seg_cap : cur;
         if (ctl[CTL_DISTINCT]) atomicAdd(&g->n_distinct, (unsigned long long)ctl[CTL_DISTINCT]);
+        if (ctl[CTL_BOUNDARY]) atomicAdd(&g->n_boundary, (unsigned long long)ctl[CTL_BOUNDARY]);
     }
 }
 
 template <int K, int LOG2S, int NWAVES>
 constexpr size_t count_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N) + sizeof(WaveStage<K>) * NWAVES;
+    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + ADJ_TASKS) + sizeof(WaveStage<K>) * NWAVES;
 }
 
 // Fallback: one workgroup per overflowed item, table in HBM (tab = [KW+3][S] words, zeroed by
@@ -535,6 +666,7 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     constexpr int NT = NWAVES * 64;
     __shared__ WaveStage<K> stages[NWAVES];
     __shared__ uint32_t ctl[CTL_N];
+    __shared__ uint32_t tasks[ADJ_TASKS];
     const BigItem it = items[blockIdx.x];
     const uint32_t S = 1u << it.log2s;
     uint32_t* keys = tab_pool + it.tab_off;
@@ -542,7 +674,7 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     uint32_t* ctxs = cnt + S;
     uint32_t* bcw = ctxs + S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; }
+    if (tid == 0) { ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_NTASK] = 0; ctl[CTL_BOUNDARY] = 0; }
     __syncthreads();
     for (uint64_t c = it.rec_begin + (uint64_t)COUNT_CHUNK * wave; c < it.rec_end; c += (uint64_t)COUNT_CHUNK * NWAVES)
         wave_count_chunk<K, USE_BC>(records, c, it.rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[CTL_FILL], &ctl[CTL_OVF]);
@@ -550,11 +682,14 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     __syncthreads();
     if (ctl[CTL_OVF]) { if (tid == 0) atomicOr(failed, 1u); return; }
     uint4* seg_out = out;                                             // the fallback's own buffer, cp.seg_cap entries
-    uint32_t occ = table_emit<K, USE_BC, false>(keys, cnt, ctxs, bcw, S, cp, seg_out, &g->big_cursor, nullptr,
-                                                &g->solid_overflow, nullptr, hist_global, tid, NT);
+    uint32_t occ = table_finish<K, USE_BC, false>(keys, cnt, ctxs, bcw, S, cp, seg_out, &g->big_cursor, nullptr,
+                                                  &g->solid_overflow, nullptr, hist_global, tasks, &ctl[CTL_NTASK],
+                                                  &ctl[CTL_BOUNDARY], tid, NT);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
     if (lane == 0 && occ) atomicAdd(&g->n_distinct, (unsigned long long)occ);
+    __syncthreads();
+    if (tid == 0 && ctl[CTL_BOUNDARY]) atomicAdd(&g->n_boundary, (unsigned long long)ctl[CTL_BOUNDARY]);
 }
 
 // Gather the output segments into one dense array: block b copies a slice of segment blockIdx.y.
@@ -588,6 +723,7 @@ k_set_insert(const uint4* __restrict__ entries, uint64_t n, SetSlot* __restrict_
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (!(entries[2 * i + 1].w & 0xFFu)) return;                     // only k-mers with unresolved context bits can be asked for
     uint4 a = entries[2 * i];
     uint64_t w0 = (uint64_t)a.x | ((uint64_t)a.y << 32), w1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
     uint64_t s = set_hash(w0, w1) & mask;
@@ -628,41 +764,65 @@ __global__ void __launch_bounds__(256)
 k_adjacency(uint4* __restrict__ entries, uint64_t n, const SetSlot* __restrict__ set, uint64_t mask,
             unsigned long long* __restrict__ n_probes)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Only the context bits k_count could not settle inside its table (pad byte 0 of the entry) are
+    // looked up; the set holds exactly the solid k-mers that have such bits (adjacency is mutual: if
+    // X's neighbour Y was counted in another item, then Y's neighbour X was too).
     unsigned long long probes = 0;
-    if (i < n) {
-        uint4 a = entries[2 * i], b = entries[2 * i + 1];
+    const u128 m = KTraits<K>::mask();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 b = entries[2 * i + 1];
+        const uint32_t pending = b.w & 0xFFu;
+        if (!pending) continue;
+        uint4 a = entries[2 * i];
         u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
         u128 F = shr128(kw, 128 - KTraits<K>::BITS);                  // 2K-bit big-endian value
-        const u128 m = KTraits<K>::mask();
         uint32_t ctx = b.y >> 24;
-        if (ctx & 0x0Fu) {
-            u128 sx = shl128(F, 2); sx.lo &= m.lo; sx.hi &= m.hi;     // kmer.toSuccessor(0)
-            for (uint32_t c = 0; c < 4; ++c) if (ctx & (1u << c)) {
-                uint64_t w0, w1; canon_words<K>(u128{sx.lo | c, sx.hi}, &w0, &w1);
-                ++probes;
-                if (!set_has(set, mask, w0, w1)) ctx &= ~(1u << c);
+        for (uint32_t bit = 0; bit < 8; ++bit) if (pending & (1u << bit)) {
+            u128 v;
+            if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }            // kmer.toSuccessor
+            else {
+                v = shr128(F, 2);                                                                     // kmer.toPredecessor
+                constexpr int TOP = KTraits<K>::BITS - 2;
+                if (TOP >= 64) v.hi |= (uint64_t)(bit - 4) << (TOP - 64); else v.lo |= (uint64_t)(bit - 4) << TOP;
             }
-        }
-        if (ctx & 0xF0u) {
-            u128 px = shr128(F, 2);                                   // kmer.toPredecessor(0)
-            constexpr int TOP = KTraits<K>::BITS - 2;
-            for (uint32_t c = 0; c < 4; ++c) if (ctx & (0x10u << c)) {
-                u128 v = px;
-                if (TOP >= 64) v.hi |= (uint64_t)c << (TOP - 64); else v.lo |= (uint64_t)c << TOP;
-                uint64_t w0, w1; canon_words<K>(v, &w0, &w1);
-                ++probes;
-                if (!set_has(set, mask, w0, w1)) ctx &= ~(0x10u << c);
-            }
+            uint64_t w0, w1; canon_words<K>(v, &w0, &w1);
+            ++probes;
+            if (!set_has(set, mask, w0, w1)) ctx &= ~(1u << bit);
         }
         b.y = (b.y & 0xFFFFFFu) | (ctx << 24);
+        b.w = 0;
         entries[2 * i + 1] = b;
     }
+    __shared__ unsigned long long sh[4];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) probes += __shfl_down(probes, d, 64);
-    if ((threadIdx.x & 63) == 0 && probes) atomicAdd(n_probes, probes);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = probes;
+    __syncthreads();
+    if (threadIdx.x == 0 && (sh[0] + sh[1] + sh[2] + sh[3])) atomicAdd(n_probes, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// Test support (DFK_F_KEEP_PRE_ADJ): the kmers.kvec view = entries with their original context byte
+// (kept in pad byte 1 by k_count); clears the pad of both copies' source bits it consumed.
+__global__ void __launch_bounds__(256)
+k_make_pre(uint4* __restrict__ entries, uint4* __restrict__ pre, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 a = entries[2 * i], b = entries[2 * i + 1];
+    pre[2 * i] = a;
+    pre[2 * i + 1] = uint4{b.x, (b.y & 0xFFFFFFu) | (((b.w >> 8) & 0xFFu) << 24), b.z, 0u};
+    b.w &= 0xFFu;
+    entries[2 * i + 1] = b;
+}
+
+__global__ void __launch_bounds__(256)
+k_clear_pad(uint4* __restrict__ entries, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* w = reinterpret_cast<uint32_t*>(entries + 2 * i + 1) + 3;
+    if (*w) *w = 0;
+}
 
 // ============================================================================ multi-GPU adjacency exchange
 // Fine bucket of an arbitrary k-mer given as a 2K-bit big-endian value (same function of the
@@ -685,51 +845,68 @@ __device__ __forceinline__ uint32_t kmer_bucket(u128 F, const PartParams& pp)
     return bucket;                       // owner rank = bucket & (world-1)
 }
 
-// Neighbour look-ups of the local solid k-mers, grouped by the rank that owns each neighbour.
+// Neighbour look-ups the local tables could not settle, grouped by the rank that owns each neighbour.
 //   WRITE == false: per_owner[o] += number of queries for rank o
 //   WRITE == true : keys[base[o] + cursor[o]++] = canonical neighbour; src[...] = entry index << 3 | context bit
+// Each block handles slices of 256 entries: it counts per owner in LDS, reserves its ranges with one global
+// atomic per owner, then writes (same-address global atomics are far too slow to issue per wave).
 template <int K, bool WRITE>
 __global__ void __launch_bounds__(256)
 k_adj_queries(const uint4* __restrict__ entries, uint64_t n, PartParams pp, unsigned long long* __restrict__ per_owner,
               const uint64_t* __restrict__ base, SetSlot* __restrict__ keys, uint64_t* __restrict__ src)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    __shared__ unsigned int cnt[64];
+    __shared__ unsigned long long start[64];
     const uint32_t world = 1u << pp.log2_world;
-    uint32_t ctx = 0; u128 F{0, 0};
     const u128 m = KTraits<K>::mask();
-    if (i < n) {
-        uint4 a = entries[2 * i], b = entries[2 * i + 1];
-        u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
-        F = shr128(kw, 128 - KTraits<K>::BITS);
-        ctx = b.y >> 24;
-    }
-    for (uint32_t bit = 0; bit < 8; ++bit) {
-        const bool has = (ctx >> bit) & 1u;
-        uint32_t owner = 0xFFFFFFFFu; uint64_t w0 = 0, w1 = 0;
-        if (has) {
-            u128 v;
-            if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }
-            else {
-                v = shr128(F, 2);
-                constexpr int TOP = KTraits<K>::BITS - 2;
-                if (TOP >= 64) v.hi |= (uint64_t)(bit - 4) << (TOP - 64); else v.lo |= (uint64_t)(bit - 4) << TOP;
-            }
-            owner = kmer_bucket<K>(v, pp) & (world - 1);
-            if (WRITE) canon_words<K>(v, &w0, &w1);
+    auto neighbour = [&](u128 F, uint32_t bit) {
+        u128 v;
+        if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }
+        else {
+            v = shr128(F, 2);
+            constexpr int TOP = KTraits<K>::BITS - 2;
+            if (TOP >= 64) v.hi |= (uint64_t)(bit - 4) << (TOP - 64); else v.lo |= (uint64_t)(bit - 4) << TOP;
         }
-        for (uint32_t o = 0; o < world; ++o) {
-            const unsigned long long mk = __ballot(owner == o);
-            if (!mk) continue;
-            unsigned long long wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&per_owner[o], (unsigned long long)__popcll(mk));
-            wbase = __shfl(wbase, 0, 64);
-            if (WRITE && owner == o) {
-                const uint64_t pos = base[o] + wbase + __popcll(mk & ((1ull << lane) - 1ull));
+        return v;
+    };
+    const uint64_t n_round = (n + 255) / 256 * 256;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n_round; i0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t i = i0 + threadIdx.x;
+        if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t pending = 0; u128 F{0, 0};
+        if (i < n) {
+            pending = entries[2 * i + 1].w & 0xFFu;
+            if (pending) {
+                uint4 a = entries[2 * i];
+                u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
+                F = shr128(kw, 128 - KTraits<K>::BITS);
+            }
+        }
+        uint32_t owners = 0;                                          // 8 x 4-bit... owner ids can need 6 bits: keep per bit in a loop
+        for (uint32_t bit = 0; bit < 8; ++bit) if (pending & (1u << bit)) {
+            const uint32_t o = kmer_bucket<K>(neighbour(F, bit), pp) & (world - 1);
+            atomicAdd(&cnt[o], 1u);
+        }
+        (void)owners;
+        __syncthreads();
+        if (threadIdx.x < world) {
+            const unsigned int c = cnt[threadIdx.x];
+            start[threadIdx.x] = c ? atomicAdd(&per_owner[threadIdx.x], (unsigned long long)c) : 0ull;
+            cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        if (WRITE) {
+            for (uint32_t bit = 0; bit < 8; ++bit) if (pending & (1u << bit)) {
+                u128 v = neighbour(F, bit);
+                const uint32_t o = kmer_bucket<K>(v, pp) & (world - 1);
+                const uint64_t pos = base[o] + start[o] + atomicAdd(&cnt[o], 1u);
+                uint64_t w0, w1; canon_words<K>(v, &w0, &w1);
                 keys[pos] = SetSlot{w0, w1};
                 src[pos] = (i << 3) | bit;
             }
         }
+        __syncthreads();
     }
 }
 
