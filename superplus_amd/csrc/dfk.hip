@@ -34,9 +34,13 @@ struct DevBuf {
 
 // LDS table geometry per K (DESIGN.md "count kernel"): slots and waves per workgroup
 template <int K> struct CountCfg;
-template <> struct CountCfg<40> { static constexpr int LOG2S = 12, NWAVES = 16; };
-template <> struct CountCfg<48> { static constexpr int LOG2S = 12, NWAVES = 16; };
-template <> struct CountCfg<60> { static constexpr int LOG2S = 12, NWAVES = 12; };
+#ifndef DFK_LOG2S
+#define DFK_LOG2S 11
+#define DFK_NWAVES 8
+#endif
+template <> struct CountCfg<40> { static constexpr int LOG2S = DFK_LOG2S, NWAVES = DFK_NWAVES; };
+template <> struct CountCfg<48> { static constexpr int LOG2S = DFK_LOG2S, NWAVES = DFK_NWAVES; };
+template <> struct CountCfg<60> { static constexpr int LOG2S = DFK_LOG2S, NWAVES = DFK_NWAVES; };
 
 struct Inputs {           // device pointers
     const uint8_t* packed; uint64_t packed_bytes;

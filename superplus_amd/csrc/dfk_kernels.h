@@ -270,7 +270,7 @@ constexpr int COUNT_HIST_BINS = 1024;
 constexpr uint32_t COUNT_MAX_PROBE = 96;
 constexpr uint32_t HIST_GLOBAL_BINS = 1u << 24;   // KDef count saturates at 2^24-1 (ReadPather.h:128-129)
 constexpr int COUNT_CHUNK = 32;                   // records a wave stages at a time
-constexpr uint32_t ADJ_TASKS = 4096;              // neighbour look-ups queued per table in LDS
+constexpr uint32_t ADJ_TASKS_BIG = 4096;          // neighbour look-up queue of the HBM-table fallback
 constexpr uint32_t FLAG_SOLID = 0x80000000u;      // barcode word reused after counting: solid flag | unresolved context bits
 
 template <int K> struct WaveStage {               // per-wave private LDS
@@ -463,7 +463,7 @@ __device__ __forceinline__ u128 canon_value(u128 F)
 //           unresolved for the small HBM pass afterwards (k_adjacency) -- about one bit in ten
 //   pass 3  emit solid slots into the workgroup's output segment (LDS cursor) and the spectrum
 // `sync` is __syncthreads for the whole workgroup.
-template <int K, bool USE_BC, bool LDS_HIST>
+template <int K, bool USE_BC, bool LDS_HIST, uint32_t ADJ_TASKS>
 __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
                                                  uint32_t S, const CountParams& cp, uint4* __restrict__ seg_out,
                                                  unsigned long long* cursor64, uint32_t* cursor32, unsigned int* seg_overflow,
@@ -545,6 +545,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         const uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
         const uint32_t flags = c ? tld(&bcw[slot]) : 0u;
         const bool solid = (flags & FLAG_SOLID) != 0;
+        if (LDS_HIST && c) tst(&cnt[slot], 0u);                       // the LDS table is left empty for the next item
         unsigned long long m = __ballot(solid);
         if (!m) continue;
         uint32_t n = __popcll(m);
@@ -576,7 +577,8 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
 }
 
 // ctl words (LDS)
-enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_CURSOR = 4, CTL_DISTINCT = 5, CTL_NTASK = 6, CTL_BOUNDARY = 7, CTL_N = 8 };
+enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_CURSOR = 4, CTL_DISTINCT = 5, CTL_NTASK = 6, CTL_BOUNDARY = 7,
+       CTL_RB_LO = 8, CTL_RB_HI = 9, CTL_RE_LO = 10, CTL_RE_HI = 11, CTL_N = 16 };
 
 template <int K, int LOG2S, int NWAVES, bool USE_BC>
 __global__ void __launch_bounds__(NWAVES * 64)
@@ -594,22 +596,37 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
     uint32_t* bcw = ctxs + S;                       // [S]
     uint32_t* hist = bcw + S;                       // [COUNT_HIST_BINS]
     uint32_t* ctl = hist + COUNT_HIST_BINS;         // [CTL_N]
-    uint32_t* tasks = ctl + CTL_N;                  // [ADJ_TASKS]
-    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(tasks + ADJ_TASKS);
+    uint32_t* tasks = ctl + CTL_N;                  // [S] neighbour look-up queue
+    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(tasks + S);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WaveStage<K>* st = stages + wave;
     uint4* seg_out = out + 2ull * cp.seg_cap * blockIdx.x;
 
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) hist[i] = 0;
-    if (tid == 0) { ctl[CTL_CURSOR] = seg_count[blockIdx.x]; ctl[CTL_DISTINCT] = 0; ctl[CTL_BOUNDARY] = 0; }
+    for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;                 // slot state; the other words are written on claim
+    // The item loop is software-pipelined: while the workgroup counts item i, thread 0 already holds the
+    // ticket and the record range of item i+1 in registers (a returning global atomic plus a dependent
+    // load are ~4 us of latency that every wave would otherwise wait for behind a barrier).
+    if (tid == 0) {
+        ctl[CTL_CURSOR] = seg_count[blockIdx.x]; ctl[CTL_DISTINCT] = 0; ctl[CTL_BOUNDARY] = 0;
+        ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0;
+        const uint32_t it0 = atomicAdd(&g->next_item, 1u);
+        uint64_t b0 = 0, e0 = 0;
+        if (it0 < cp.n_items) { b0 = items[it0].rec_begin; e0 = items[it0].rec_end; }
+        ctl[CTL_ITEM] = it0; ctl[CTL_RB_LO] = (uint32_t)b0; ctl[CTL_RB_HI] = (uint32_t)(b0 >> 32);
+        ctl[CTL_RE_LO] = (uint32_t)e0; ctl[CTL_RE_HI] = (uint32_t)(e0 >> 32);
+    }
     for (;;) {
-        __syncthreads();
-        if (tid == 0) { ctl[CTL_ITEM] = atomicAdd(&g->next_item, 1u); ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0; }
-        for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;             // slot state; the other words are written on claim
-        __syncthreads();
+        __syncthreads();                                               // table empty, counters reset, item published
         const uint32_t item = __builtin_amdgcn_readfirstlane(ctl[CTL_ITEM]);
         if (item >= cp.n_items) break;
-        const uint64_t rb = items[item].rec_begin, re = items[item].rec_end;
+        const uint64_t rb = (uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RB_LO]) | ((uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RB_HI]) << 32);
+        const uint64_t re = (uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RE_LO]) | ((uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RE_HI]) << 32);
+        uint32_t nx = 0xFFFFFFFFu; uint64_t nb = 0, ne = 0;
+        if (tid == 0) {
+            nx = atomicAdd(&g->next_item, 1u);
+            if (nx < cp.n_items) { nb = items[nx].rec_begin; ne = items[nx].rec_end; }
+        }
         // Waves pull chunks of the item from an LDS ticket.  All loop control is made scalar
         // (readfirstlane) so the compiler emits uniform branches, and the trip count is bounded.
         const uint32_t n_chunks = (uint32_t)((re - rb + COUNT_CHUNK - 1) / COUNT_CHUNK);
@@ -626,13 +643,20 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(ctl[CTL_OVF])) {
             if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = item;
+            for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;         // abandon the table
+            __syncthreads();                                           // everyone has read CTL_OVF before it is reset
         } else {
-            uint32_t occ = table_finish<K, USE_BC, true>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
+            uint32_t occ = table_finish<K, USE_BC, true, S>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
                                                          &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
                                                          &ctl[CTL_BOUNDARY], tid, NT);
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
             if (lane == 0 && occ) atomicAdd(&ctl[CTL_DISTINCT], occ);
+        }
+        if (tid == 0) {                                                // publish the prefetched item, reset the per-item words
+            ctl[CTL_ITEM] = nx; ctl[CTL_RB_LO] = (uint32_t)nb; ctl[CTL_RB_HI] = (uint32_t)(nb >> 32);
+            ctl[CTL_RE_LO] = (uint32_t)ne; ctl[CTL_RE_HI] = (uint32_t)(ne >> 32);
+            ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0;
         }
     }
     __syncthreads();
@@ -648,7 +672,7 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
 template <int K, int LOG2S, int NWAVES>
 constexpr size_t count_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + ADJ_TASKS) + sizeof(WaveStage<K>) * NWAVES;
+    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + (1u << LOG2S)) + sizeof(WaveStage<K>) * NWAVES;
 }
 
 // Fallback: one workgroup per overflowed item, table in HBM (tab = [KW+3][S] words, zeroed by
@@ -666,7 +690,7 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     constexpr int NT = NWAVES * 64;
     __shared__ WaveStage<K> stages[NWAVES];
     __shared__ uint32_t ctl[CTL_N];
-    __shared__ uint32_t tasks[ADJ_TASKS];
+    __shared__ uint32_t tasks[ADJ_TASKS_BIG];
     const BigItem it = items[blockIdx.x];
     const uint32_t S = 1u << it.log2s;
     uint32_t* keys = tab_pool + it.tab_off;
@@ -682,7 +706,7 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     __syncthreads();
     if (ctl[CTL_OVF]) { if (tid == 0) atomicOr(failed, 1u); return; }
     uint4* seg_out = out;                                             // the fallback's own buffer, cp.seg_cap entries
-    uint32_t occ = table_finish<K, USE_BC, false>(keys, cnt, ctxs, bcw, S, cp, seg_out, &g->big_cursor, nullptr,
+    uint32_t occ = table_finish<K, USE_BC, false, ADJ_TASKS_BIG>(keys, cnt, ctxs, bcw, S, cp, seg_out, &g->big_cursor, nullptr,
                                                   &g->solid_overflow, nullptr, hist_global, tasks, &ctl[CTL_NTASK],
                                                   &ctl[CTL_BOUNDARY], tid, NT);
 #pragma unroll
