@@ -54,7 +54,7 @@ typedef struct dfk_config {
     uint32_t minimizer_len;     /* 0 = default; 8..16 */
     uint32_t flags;             /* DFK_F_* */
     uint64_t inst_per_item;     /* 0 = default; k-mer instances packed into one LDS table pass */
-    uint64_t reserved[4];
+    uint64_t reserved[4];       /* [0] = hash-slice passes (power of two), 0 = sized from the HBM budget */
 } dfk_config;
 
 #define DFK_F_KEEP_PRE_ADJ   1u   /* also keep contexts before recomputeAdjacencies (kmers.kvec view) */
@@ -85,7 +85,7 @@ typedef struct dfk_stats {
      * context's stream */
     float ms_upload, ms_trim, ms_part_count, ms_part_scatter, ms_count, ms_fallback, ms_adjacency, ms_total;
     uint64_t hbm_bytes_peak;    /* peak device bytes held by the context */
-    uint64_t reserved[8];
+    uint64_t reserved[8];       /* [0] = hash-slice passes used */
 } dfk_stats;
 
 typedef struct dfk_ctx dfk_ctx;

@@ -62,8 +62,10 @@ struct dfk_ctx {
     bool have = false;
     uint64_t n_reads = 0;
     DevBuf good_len;                          // u32[n_reads]
-    DevBuf solid, solid_pre;                  // dfk_entry32[n_solid]
+    struct Part { DevBuf buf, pre; uint64_t n = 0; };   // dfk_entry32[n]: one per hash-slice pass
+    std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
+    unsigned seg_attempt = 0;                 // output segments are sized (estimate << seg_attempt)
     std::vector<int64_t> hist;
     std::vector<dfk_entry32> sorted, sorted_pre;
     bool sorted_ok = false, sorted_pre_ok = false;
@@ -126,11 +128,13 @@ struct dfk_ctx {
     void release_all()
     {
         // results of the previous run go back to the pool (sizes come from the DevBufs that own them)
-        DevBuf* live[] = {&good_len, &solid, &solid_pre, &shard_records, &adj_keys, &adj_src, &set};
+        DevBuf* live[] = {&good_len, &shard_records, &adj_keys, &adj_src, &set};
         for (DevBuf* d : live) release(*d);
+        for (Part& pt : parts) { release(pt.buf); release(pt.pre); }
+        parts.clear();
         for (void* p : owned) (void)hipFree(p);                        // anything an aborted run left behind
         owned.clear(); held = 0;
-        good_len = solid = solid_pre = shard_records = adj_keys = adj_src = set = DevBuf{};
+        good_len = shard_records = adj_keys = adj_src = set = DevBuf{};
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
         n_solid = 0; adj_n = 0; shard_open = false;
     }
@@ -178,24 +182,39 @@ int stage_trim(dfk_ctx* c, const Inputs& in, uint64_t* n_inst)
 }
 
 // ------------------------------------------------------------------ stage: partition (a2, first half)
-struct Partition {
+// Fine buckets are numbered in one global space of 2^log2_nb (owner-rank-major when sharded).  The count
+// launch sees all of them once; a scatter launch materialises the records of one hash slice ("pass"):
+// buckets with (id & (P-1)) == pass, renumbered id >> log2(P).  This is the reference's nPasses idea
+// (MapReduceEngine.h:454) applied to HBM capacity.
+struct BucketTable {
+    uint32_t log2_nb = 0;                 // global
+    std::vector<uint64_t> acc;            // [nb] records<<32 | instances, global numbering
+    uint64_t n_records = 0;
+};
+struct Partition {                        // one pass
     DevBuf records; uint64_t n_records = 0;
-    uint32_t log2_nb = 0;
-    std::vector<uint64_t> base;       // [nb+1] first record of each fine bucket (owner-major order)
-    std::vector<uint32_t> inst;       // [nb]   instances per fine bucket
+    uint32_t log2_nb = 0;                 // local (this pass)
+    std::vector<uint64_t> base;           // [nb+1] first record of each local fine bucket
+    std::vector<uint32_t> inst;           // [nb]   instances per local fine bucket
+    uint64_t n_inst = 0;
 };
 
 template <int K>
-int stage_partition(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, Partition* P)
+PartParams part_params(const dfk_ctx* c, uint32_t log2_nb, uint32_t log2_world, int64_t read_id0, uint32_t log2_pass, uint32_t pass)
 {
     const uint32_t M = c->cfg.minimizer_len;
-    PartParams pp{M, (uint32_t)K - M + 1, P->log2_nb, log2_world, read_id0};
-    const uint64_t nb = 1ull << P->log2_nb;
+    return PartParams{M, (uint32_t)K - M + 1, log2_nb, log2_world, read_id0, log2_pass, pass};
+}
+
+template <int K>
+int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, BucketTable* T)
+{
+    const PartParams pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 0);
+    const uint64_t nb = 1ull << T->log2_nb;
     DevBuf acc; int rc = c->alloc(acc, nb * 8, "bucket counters"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(acc.p, 0, nb * 8, c->stream));
     const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
     const size_t lds_a = sizeof(uint32_t) * pp.W * PART_THREADS;
-    const size_t lds_b = lds_a + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
     Timer t(c->stream);
     t.start();
     if (grid)
@@ -206,25 +225,41 @@ int stage_partition(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     HIP_TRY(hipGetLastError());
     c->st.ms_part_count = t.stop();
     TRACE("partition count pass done (%llu buckets)", (unsigned long long)nb);
-    std::vector<uint64_t> h(nb);
-    HIP_TRY(hipMemcpy(h.data(), acc.p, nb * 8, hipMemcpyDeviceToHost));
+    T->acc.resize(nb);
+    HIP_TRY(hipMemcpy(T->acc.data(), acc.p, nb * 8, hipMemcpyDeviceToHost));
     c->release(acc);
-    P->base.assign(nb + 1, 0); P->inst.assign(nb, 0);
-    uint64_t tot_inst = 0;
-    for (uint64_t b = 0; b < nb; ++b) {
-        P->base[b + 1] = P->base[b] + (h[b] >> 32);
-        P->inst[b] = (uint32_t)h[b]; tot_inst += (uint32_t)h[b];
-    }
-    P->n_records = P->base[nb];
+    uint64_t tot_inst = 0; T->n_records = 0;
+    for (uint64_t b = 0; b < nb; ++b) { T->n_records += T->acc[b] >> 32; tot_inst += (uint32_t)T->acc[b]; }
     if (tot_inst != n_inst)
         return fail(DFK_E_HIP, "partition count pass saw %llu instances, trim saw %llu",
                     (unsigned long long)tot_inst, (unsigned long long)n_inst);
+    c->st.n_records = T->n_records; c->st.n_buckets = nb;
+    return 0;
+}
+
+template <int K>
+int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0,
+                      uint32_t log2_pass, uint32_t pass, Partition* P)
+{
+    const PartParams pp = part_params<K>(c, T.log2_nb, log2_world, read_id0, log2_pass, pass);
+    P->log2_nb = T.log2_nb - log2_pass;
+    const uint64_t nb = 1ull << P->log2_nb;
+    P->base.assign(nb + 1, 0); P->inst.assign(nb, 0); P->n_inst = 0;
+    for (uint64_t j = 0; j < nb; ++j) {
+        const uint64_t h = T.acc[(j << log2_pass) | pass];
+        P->base[j + 1] = P->base[j] + (h >> 32);
+        P->inst[j] = (uint32_t)h; P->n_inst += (uint32_t)h;
+    }
+    P->n_records = P->base[nb];
     DevBuf dbase, cur;
-    rc = c->alloc(dbase, (nb + 1) * 8, "bucket bases"); if (rc) return rc;
+    int rc = c->alloc(dbase, (nb + 1) * 8, "bucket bases"); if (rc) return rc;
     rc = c->alloc(cur, nb * 4, "bucket cursors"); if (rc) return rc;
     rc = c->alloc(P->records, P->n_records * 32, "super-k-mer records"); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(dbase.p, P->base.data(), (nb + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(cur.p, 0, nb * 4, c->stream));
+    const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
+    const size_t lds_b = sizeof(uint32_t) * pp.W * PART_THREADS + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
+    Timer t(c->stream);
     t.start();
     if (grid)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3(grid), dim3(PART_THREADS), lds_b, c->stream,
@@ -232,10 +267,9 @@ int stage_partition(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr,
                            (const uint64_t*)dbase.p, (uint32_t*)cur.p, (uint4*)P->records.p);
     HIP_TRY(hipGetLastError());
-    c->st.ms_part_scatter = t.stop();
-    TRACE("partition scatter done (%llu records)", (unsigned long long)P->n_records);
+    c->st.ms_part_scatter += t.stop();
+    TRACE("partition scatter pass %u/%u done (%llu records)", pass + 1, 1u << log2_pass, (unsigned long long)P->n_records);
     c->release(dbase); c->release(cur);
-    c->st.n_records = P->n_records; c->st.n_buckets = nb;
     return 0;
 }
 
@@ -253,11 +287,45 @@ void pack_items(const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t budge
     if (acc) out->push_back({start, (uint32_t)b_hi});
 }
 
+constexpr int E_SEGMENT_FULL = -100;   // internal: redo the run with larger output segments
+
 struct CountRun {                     // device state shared by the count launches of one run
-    CountGlobals* g; uint4* seg; uint32_t* seg_count; unsigned long long* hist;
-    CountParams cp; unsigned grid;
+    CountGlobals* g = nullptr; uint4* seg = nullptr; uint32_t* seg_count = nullptr; unsigned long long* hist = nullptr;
+    CountParams cp{}; unsigned grid = 0;
     DevBuf big; uint64_t big_cap = 0;  // output of the HBM-table fallback (its own buffer)
+    DevBuf d_hist, d_g;                // spectrum bins and counters: live across the passes of one run
+    uint64_t solid_seen = 0, inst_seen = 0;   // totals of the passes done so far (sizes the next pass's output)
 };
+
+int count_run_begin(dfk_ctx* c, CountRun* R)
+{
+    int rc = c->alloc(R->d_hist, (uint64_t)HIST_GLOBAL_BINS * 8, "spectrum bins"); if (rc) return rc;
+    rc = c->alloc(R->d_g, sizeof(CountGlobals), "count globals"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(R->d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(R->d_g.p, 0, sizeof(CountGlobals), c->stream));
+    R->g = (CountGlobals*)R->d_g.p; R->hist = (unsigned long long*)R->d_hist.p;
+    return 0;
+}
+
+// spectrum (a5): bins 0..max count, after the last pass
+int count_run_end(dfk_ctx* c, CountRun* R)
+{
+    CountGlobals hg{};
+    HIP_TRY(hipMemcpy(&hg, R->d_g.p, sizeof hg, hipMemcpyDeviceToHost));
+    c->st.n_distinct = hg.n_distinct; c->n_boundary = hg.n_boundary;
+    DevBuf d_max; int rc = c->alloc(d_max, 16, "max bin"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_max.p, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_hist_max, dim3(1024), dim3(256), 0, c->stream, (const unsigned long long*)R->d_hist.p, HIST_GLOBAL_BINS,
+                       (unsigned int*)d_max.p);
+    uint32_t nb = 0;
+    HIP_TRY(hipMemcpyAsync(&nb, d_max.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->hist.assign(nb, 0);
+    if (nb) HIP_TRY(hipMemcpy(c->hist.data(), R->d_hist.p, 8ull * nb, hipMemcpyDeviceToHost));
+    TRACE("spectrum read back: %u bins, %llu solid", nb, (unsigned long long)c->n_solid);
+    c->release(d_max); c->release(R->d_hist); c->release(R->d_g);
+    return 0;
+}
 
 template <int K> unsigned count_grid(const dfk_ctx* c)
 {
@@ -340,49 +408,50 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     return 0;
 }
 
+// Count one pass: pack items, run k_count (+ split / HBM-table fallbacks), gather the pass's solid k-mers
+// into a dense part.
 template <int K, bool USE_BC>
-int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t n_inst, unsigned attempt = 0)
+int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
 {
+    const unsigned attempt = c->seg_attempt;
     constexpr int LOG2S = CountCfg<K>::LOG2S;
+    const uint64_t nb = 1ull << P.log2_nb;
     const uint64_t budget = c->cfg.inst_per_item ? c->cfg.inst_per_item : (3ull << LOG2S) / 2;
     std::vector<ItemRange> ranges;
-    pack_items(P, b_lo, b_hi, budget, &ranges);
+    pack_items(P, 0, nb, budget, &ranges);
 
-    // Output: one segment per persistent workgroup (+1 for the HBM fallback), filled through an
-    // LDS cursor.  Every solid k-mer has >= min_freq instances, which bounds the total.
-    CountRun R{};
+    // Output: one segment per persistent workgroup, filled through an LDS cursor.  Every solid k-mer has
+    // >= min_freq instances, which bounds the total; after the first pass the observed solid/instance
+    // ratio gives a much tighter estimate.
     R.grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ranges.size(), count_grid<K>(c)));
     const uint32_t nseg = R.grid;
-    uint64_t cap = n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
+    uint64_t cap = P.n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
+    if (R.inst_seen) cap = std::min<uint64_t>(cap, (uint64_t)(1.3 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
     const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
-    const uint64_t fixed = (uint64_t)HIST_GLOBAL_BINS * 8 + (64ull << 20);
-    // the dense copy made afterwards needs room too: leave a third of what is left for it
-    if (cap * 32 + fixed > room / 3 * 2) cap = room / 3 * 2 > fixed ? (room / 3 * 2 - fixed) / 32 : 0;
+    // the dense part made afterwards needs room too: leave a third of what is left for it
+    if (cap * 32 > room / 3 * 2) cap = room / 3 * 2 / 32;
     // dynamic item scheduling balances the workgroups to within a few items (<= 3/4 S entries each);
-    // if a segment still fills up the whole stage is redone with twice the room
+    // if a segment still fills up the whole pass is redone with twice the room
     const uint64_t seg_cap = std::min<uint64_t>(((cap / nseg) * 5 / 4 + 8192) << attempt, 0xFFFFFFF0ull);
-    DevBuf d_seg, d_segcnt, d_hist, d_g;
+    DevBuf d_seg, d_segcnt;
     int rc = c->alloc(d_seg, seg_cap * nseg * 32, "solid k-mer segments"); if (rc) return rc;
     rc = c->alloc(d_segcnt, 4ull * nseg, "segment counts"); if (rc) return rc;
-    rc = c->alloc(d_hist, (uint64_t)HIST_GLOBAL_BINS * 8, "spectrum bins"); if (rc) return rc;
-    rc = c->alloc(d_g, sizeof(CountGlobals), "count globals"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_segcnt.p, 0, 4ull * nseg, c->stream));
-    HIP_TRY(hipMemsetAsync(d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
-    HIP_TRY(hipMemsetAsync(d_g.p, 0, sizeof(CountGlobals), c->stream));
+    CountGlobals before{};
+    HIP_TRY(hipMemcpy(&before, R.d_g.p, sizeof before, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemsetAsync(&R.g->big_cursor, 0, 8, c->stream));
     R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, nseg, seg_cap, c->cfg.min_freq > 1 ? 1u : 0u,
                        (c->cfg.flags & DFK_F_KEEP_PRE_ADJ) ? 1u : 0u};
-    R.g = (CountGlobals*)d_g.p; R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p;
-    R.hist = (unsigned long long*)d_hist.p;
+    R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p;
 
     Timer t(c->stream);
     std::vector<ItemRange> overflowed;
-    c->st.n_items = ranges.size();
-    c->st.ms_count = 0;
+    c->st.n_items += ranges.size();
     rc = launch_count<K, USE_BC>(c, P, ranges, R, &overflowed, &c->st.ms_count); if (rc) return rc;
     t.start();
     // items that overflowed their LDS table: split at fine-bucket boundaries and retry; a single
     // fine bucket that still overflows is counted in an HBM table
-    c->st.n_overflow_items = overflowed.size();
+    c->st.n_overflow_items += overflowed.size();
     std::vector<ItemRange> singles;
     while (!overflowed.empty()) {
         std::vector<ItemRange> next;
@@ -400,50 +469,39 @@ int stage_count(dfk_ctx* c, const Partition& P, uint64_t b_lo, uint64_t b_hi, ui
     }
     TRACE("fallback: %zu single-bucket items", singles.size());
     if (!singles.empty()) { rc = launch_count_big<K, USE_BC>(c, P, singles, R); if (rc) return rc; }
-    c->st.ms_fallback = t.stop();
+    c->st.ms_fallback += t.stop();
     TRACE("count stage kernels done");
 
     CountGlobals hg{};
     std::vector<uint32_t> segcnt(nseg);
-    HIP_TRY(hipMemcpy(&hg, d_g.p, sizeof hg, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&hg, R.d_g.p, sizeof hg, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(segcnt.data(), d_segcnt.p, 4ull * nseg, hipMemcpyDeviceToHost));
     if (hg.solid_overflow || hg.big_cursor > R.big_cap) {
-        c->release(d_seg); c->release(d_segcnt); c->release(d_hist); c->release(d_g); c->release(R.big);
-        if (attempt >= 4)
-            return fail(DFK_E_NOMEM, "a solid k-mer output segment (%llu entries) is full; raise hbm_budget_bytes",
-                        (unsigned long long)seg_cap);
-        TRACE("output segment full at %llu entries: redoing the count stage with more room", (unsigned long long)seg_cap);
-        return stage_count<K, USE_BC>(c, P, b_lo, b_hi, n_inst, attempt + 1);
+        // undo this pass's contribution to the running counters and the spectrum is not possible for the
+        // histogram, so a pass that overflowed its output restarts the whole run with more room
+        c->release(d_seg); c->release(d_segcnt); c->release(R.big);
+        fail(DFK_E_NOMEM, "a solid k-mer output segment (%llu entries) is full", (unsigned long long)seg_cap);
+        return E_SEGMENT_FULL;
     }
     std::vector<uint64_t> prefix(nseg + 1, 0);
-    for (uint32_t s = 0; s < nseg; ++s) prefix[s + 1] = prefix[s] + segcnt[s];
-    c->n_solid = prefix[nseg] + hg.big_cursor; c->st.n_solid = c->n_solid; c->st.n_distinct = hg.n_distinct;
-    c->n_boundary = hg.n_boundary;
-
-    // dense solid array
+    for (uint32_t sg = 0; sg < nseg; ++sg) prefix[sg + 1] = prefix[sg] + segcnt[sg];
+    dfk_ctx::Part part;
+    part.n = prefix[nseg] + hg.big_cursor;
     DevBuf d_prefix;
-    rc = c->alloc(c->solid, c->n_solid * 32, "solid k-mer entries"); if (rc) return rc;
+    rc = c->alloc(part.buf, part.n * 32, "solid k-mer entries"); if (rc) return rc;
     rc = c->alloc(d_prefix, 8ull * (nseg + 1), "segment prefix"); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_prefix.p, prefix.data(), 8ull * (nseg + 1), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_compact, dim3(8, nseg), dim3(256), 0, c->stream, (const uint4*)d_seg.p, seg_cap,
-                       (const uint64_t*)d_prefix.p, (uint4*)c->solid.p);
+                       (const uint64_t*)d_prefix.p, (uint4*)part.buf.p);
     HIP_TRY(hipGetLastError());
     if (hg.big_cursor)
-        HIP_TRY(hipMemcpyAsync((char*)c->solid.p + 32 * prefix[nseg], R.big.p, 32 * hg.big_cursor, hipMemcpyDeviceToDevice, c->stream));
-
-    // spectrum (a5): bins 0..max count
-    DevBuf d_max; rc = c->alloc(d_max, 16, "max bin"); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(d_max.p, 0, 16, c->stream));
-    hipLaunchKernelGGL(k_hist_max, dim3(1024), dim3(256), 0, c->stream, (const unsigned long long*)d_hist.p, HIST_GLOBAL_BINS,
-                       (unsigned int*)d_max.p);
-    uint32_t nb = 0;
-    HIP_TRY(hipMemcpyAsync(&nb, d_max.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync((char*)part.buf.p + 32 * prefix[nseg], R.big.p, 32 * hg.big_cursor, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->hist.assign(nb, 0);
-    if (nb) HIP_TRY(hipMemcpy(c->hist.data(), d_hist.p, 8ull * nb, hipMemcpyDeviceToHost));
-    TRACE("spectrum read back: %u bins, %llu solid", nb, (unsigned long long)c->n_solid);
-    c->release(d_max); c->release(d_hist); c->release(d_g); c->release(d_seg); c->release(d_segcnt); c->release(d_prefix);
-    c->release(R.big);
+    c->release(d_seg); c->release(d_segcnt); c->release(d_prefix); c->release(R.big);
+    c->parts.push_back(part);
+    c->n_solid += part.n; c->st.n_solid = c->n_solid;
+    R.solid_seen += part.n; R.inst_seen += P.n_inst;
+    (void)before;
     return 0;
 }
 
@@ -456,9 +514,10 @@ int build_set(dfk_ctx* c)
     int rc = c->alloc(c->set, slots * sizeof(SetSlot), "boundary k-mer set"); if (rc) return rc;
     c->set_mask = slots - 1;
     hipLaunchKernelGGL(k_fill_u64, dim3(2048), dim3(256), 0, c->stream, (uint64_t*)c->set.p, slots * 2, ~0ull);
-    if (c->n_solid)
-        hipLaunchKernelGGL(k_set_insert, dim3((unsigned)((c->n_solid + 255) / 256)), dim3(256), 0, c->stream,
-                           (const uint4*)c->solid.p, c->n_solid, (SetSlot*)c->set.p, c->set_mask);
+    for (const dfk_ctx::Part& pt : c->parts)
+        if (pt.n)
+            hipLaunchKernelGGL(k_set_insert, dim3((unsigned)((pt.n + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint4*)pt.buf.p, pt.n, (SetSlot*)c->set.p, c->set_mask);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -467,13 +526,15 @@ int build_set(dfk_ctx* c)
 int make_pre_view(dfk_ctx* c)
 {
     if (!(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return 0;
-    int rc = c->alloc(c->solid_pre, c->n_solid * 32, "pre-adjacency copy"); if (rc) return rc;
-    if (!c->n_solid) return 0;
-    if (c->cfg.min_freq > 1)
-        hipLaunchKernelGGL(k_make_pre, dim3((unsigned)((c->n_solid + 255) / 256)), dim3(256), 0, c->stream,
-                           (uint4*)c->solid.p, (uint4*)c->solid_pre.p, c->n_solid);
-    else
-        HIP_TRY(hipMemcpyAsync(c->solid_pre.p, c->solid.p, c->n_solid * 32, hipMemcpyDeviceToDevice, c->stream));
+    for (dfk_ctx::Part& pt : c->parts) {
+        int rc = c->alloc(pt.pre, pt.n * 32, "pre-adjacency copy"); if (rc) return rc;
+        if (!pt.n) continue;
+        if (c->cfg.min_freq > 1)
+            hipLaunchKernelGGL(k_make_pre, dim3((unsigned)((pt.n + 255) / 256)), dim3(256), 0, c->stream,
+                               (uint4*)pt.buf.p, (uint4*)pt.pre.p, pt.n);
+        else
+            HIP_TRY(hipMemcpyAsync(pt.pre.p, pt.buf.p, pt.n * 32, hipMemcpyDeviceToDevice, c->stream));
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -488,8 +549,10 @@ int stage_adjacency(dfk_ctx* c)
         rc = build_set(c); if (rc) return rc;
         DevBuf d_n; rc = c->alloc(d_n, 16, "probe counter"); if (rc) return rc;
         HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adjacency<K>), dim3((unsigned)std::min<uint64_t>((c->n_solid + 255) / 256, 8192)), dim3(256), 0, c->stream,
-                           (uint4*)c->solid.p, c->n_solid, (const SetSlot*)c->set.p, c->set_mask, (unsigned long long*)d_n.p);
+        for (const dfk_ctx::Part& pt : c->parts)
+            if (pt.n)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adjacency<K>), dim3((unsigned)std::min<uint64_t>((pt.n + 255) / 256, 8192)), dim3(256), 0,
+                                   c->stream, (uint4*)pt.buf.p, pt.n, (const SetSlot*)c->set.p, c->set_mask, (unsigned long long*)d_n.p);
         HIP_TRY(hipGetLastError());
         uint64_t np = 0;
         HIP_TRY(hipMemcpyAsync(&np, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -510,6 +573,24 @@ uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
     return std::min<uint32_t>(l, 23);
 }
 
+uint32_t pick_passes(const dfk_ctx* c, uint64_t n_records, uint64_t n_inst)
+{
+    if (c->cfg.reserved[0]) {                                        // dfk_config.reserved[0] = forced number of passes (tests)
+        uint32_t l = 0; while ((1ull << l) < c->cfg.reserved[0]) ++l;
+        return l;
+    }
+    // one pass holds its records (32 B each) plus its output segments and dense part (~ n_inst/8 x 32 B x 2.3);
+    // finished parts of earlier passes stay resident.  Keep a pass's working set under ~40 % of what is free.
+    const uint64_t room = c->budget > c->held ? c->budget - c->held : 0;
+    const double solid_all = (double)n_inst / 8.0 * 32.0;            // generous estimate of the final dictionary
+    uint32_t l = 0;
+    for (; l < 8; ++l) {
+        const double pass_ws = ((double)n_records * 32.0 + solid_all * 1.3) / (double)(1u << l);
+        if (pass_ws + solid_all < 0.9 * (double)room && pass_ws < 0.45 * (double)room) break;
+    }
+    return l;
+}
+
 template <int K>
 int run_typed(dfk_ctx* c, const Inputs& in)
 {
@@ -521,12 +602,21 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     int rc = stage_trim<K>(c, in, &n_inst); if (rc) return rc;
     c->st.ms_trim = t.stop();
     c->st.n_reads = in.n_reads; c->st.n_inst = n_inst; c->n_reads = in.n_reads;
-    Partition P; P.log2_nb = pick_log2_nb(n_inst, 0);
-    rc = stage_partition<K>(c, in, n_inst, 0, 0, &P); if (rc) return rc;
-    const uint64_t nb = 1ull << P.log2_nb;
-    rc = in.bc ? stage_count<K, true>(c, P, 0, nb, n_inst) : stage_count<K, false>(c, P, 0, nb, n_inst);
-    if (rc) return rc;
-    c->release(P.records);
+    BucketTable T; T.log2_nb = pick_log2_nb(n_inst, 0);
+    rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
+    const uint32_t log2_pass = std::min<uint32_t>(pick_passes(c, T.n_records, n_inst), T.log2_nb > 4 ? T.log2_nb - 4 : 0);
+    TRACE("%llu instances, %llu records, %u pass(es)", (unsigned long long)n_inst, (unsigned long long)T.n_records, 1u << log2_pass);
+    CountRun R;
+    rc = count_run_begin(c, &R); if (rc) return rc;
+    for (uint32_t pass = 0; pass < (1u << log2_pass); ++pass) {
+        Partition P;
+        rc = partition_scatter<K>(c, in, T, 0, 0, log2_pass, pass, &P); if (rc) return rc;
+        rc = in.bc ? stage_count<K, true>(c, P, R) : stage_count<K, false>(c, P, R);
+        if (rc) return rc;
+        c->release(P.records);
+    }
+    c->st.reserved[0] = 1u << log2_pass;
+    rc = count_run_end(c, &R); if (rc) return rc;
     rc = stage_adjacency<K>(c); if (rc) return rc;
     c->st.ms_total = total.stop();
     c->st.hbm_bytes_peak = c->peak;
@@ -536,12 +626,20 @@ int run_typed(dfk_ctx* c, const Inputs& in)
 
 int run(dfk_ctx* c, const Inputs& in)
 {
-    switch (c->cfg.K) {
-    case 40: return run_typed<40>(c, in);
-    case 48: return run_typed<48>(c, in);
-    case 60: return run_typed<60>(c, in);
+    for (c->seg_attempt = 0;; ++c->seg_attempt) {
+        int rc;
+        switch (c->cfg.K) {
+        case 40: rc = run_typed<40>(c, in); break;
+        case 48: rc = run_typed<48>(c, in); break;
+        case 60: rc = run_typed<60>(c, in); break;
+        default: return fail(DFK_E_ARG, "K must be 40, 48 or 60");
+        }
+        if (rc != E_SEGMENT_FULL) return rc;
+        // the spectrum and counters of the failed attempt cannot be unwound: start over with twice the room
+        if (c->seg_attempt >= 4) return DFK_E_NOMEM;
+        TRACE("output segment full: redoing the run with larger segments");
+        c->release_all(); c->st = dfk_stats{};
     }
-    return fail(DFK_E_ARG, "K must be 40, 48 or 60");
 }
 
 int fetch_sorted(dfk_ctx* c, bool pre, std::vector<dfk_entry32>** out)
@@ -549,10 +647,14 @@ int fetch_sorted(dfk_ctx* c, bool pre, std::vector<dfk_entry32>** out)
     std::vector<dfk_entry32>& v = pre ? c->sorted_pre : c->sorted;
     bool& ok = pre ? c->sorted_pre_ok : c->sorted_ok;
     if (!ok) {
-        const DevBuf& src = pre ? c->solid_pre : c->solid;
-        if (pre && !src.p) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
+        if (pre && !(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
         v.resize(c->n_solid);
-        if (c->n_solid) HIP_TRY(hipMemcpy(v.data(), src.p, c->n_solid * 32, hipMemcpyDeviceToHost));
+        uint64_t at = 0;
+        for (const dfk_ctx::Part& pt : c->parts) {
+            const DevBuf& src = pre ? pt.pre : pt.buf;
+            if (pt.n) HIP_TRY(hipMemcpy(v.data() + at, src.p, pt.n * 32, hipMemcpyDeviceToHost));
+            at += pt.n;
+        }
         std::sort(v.begin(), v.end(), [](const dfk_entry32& a, const dfk_entry32& b) {
             return a.w0 != b.w0 ? a.w0 < b.w0 : a.w1 < b.w1; });
         ok = true;

@@ -97,6 +97,8 @@ struct PartParams {
     uint32_t log2_nb;      // fine buckets = 1 << log2_nb
     uint32_t log2_world;   // fine buckets are laid out owner-major: owner rank = bucket & (world-1)
     int64_t  read_id0;     // global index of this shard's first read (ignBcBelow compares global read ids)
+    uint32_t log2_pass;    // hash-slice passes: this launch keeps fine buckets with (id & (P-1)) == pass ...
+    uint32_t pass;         // ... and numbers them id >> log2_pass (WRITE launches only; the count launch sees all)
 };
 
 constexpr int PART_THREADS = 256;
@@ -176,6 +178,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     uint32_t wpos = (uint32_t)bit0 & 31u;
 
     auto close_run = [&]() {
+        if (WRITE && cur_b == 0xFFFFFFFFu) return;                  // run belongs to another pass
         if (!WRITE) {
             atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
         } else {
@@ -210,6 +213,10 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
             uint32_t bucket = (mv * 0x9E3779B1u) >> bshift;
             // owner-major position: all fine buckets of one owner rank are contiguous
             bucket = ((bucket & ((1u << pp.log2_world) - 1u)) << (pp.log2_nb - pp.log2_world)) | (bucket >> pp.log2_world);
+            if (WRITE) {                                          // hash-slice pass: foreign buckets become "no bucket"
+                const bool mine = (bucket & ((1u << pp.log2_pass) - 1u)) == pp.pass;
+                bucket = mine ? (bucket >> pp.log2_pass) : 0xFFFFFFFFu;
+            }
             if (s == 0) { cur_b = bucket; cur_s0 = 0; cur_nk = 1; }
             else if (bucket != cur_b || cur_nk == (uint32_t)KTraits<K>::NK_MAX) {
                 close_run();

@@ -50,7 +50,9 @@ class Stats(C.Structure):
                 ("hbm_bytes_peak", C.c_uint64), ("reserved", C.c_uint64 * 8)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["n_passes"] = int(self.reserved[0])
+        return d
 
 
 _lib = None
@@ -87,10 +89,11 @@ class Dfk:
     torch tensors already on this context's device."""
 
     def __init__(self, K=48, min_qual=7, min_freq=3, min_bc=2, ign_bc_below=0, device=0, hbm_budget_bytes=0,
-                 minimizer_len=0, keep_pre_adjacency=False, inst_per_item=0):
+                 minimizer_len=0, keep_pre_adjacency=False, inst_per_item=0, passes=0):
         cfg = Config(abi_version=ABI_VERSION, K=K, min_qual=min_qual, min_freq=min_freq, min_bc=min_bc, device=device,
                      ign_bc_below=ign_bc_below, hbm_budget_bytes=hbm_budget_bytes, minimizer_len=minimizer_len,
                      flags=F_KEEP_PRE_ADJ if keep_pre_adjacency else 0, inst_per_item=inst_per_item)
+        cfg.reserved[0] = passes          # hash-slice passes (power of two); 0 = sized from the HBM budget
         self._ctx = C.c_void_p()
         _check(lib().dfk_create(C.byref(cfg), C.byref(self._ctx)))
         self.K = K

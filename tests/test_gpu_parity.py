@@ -163,3 +163,13 @@ def test_single_bucket_overflow_uses_hbm_table(oracle):
     ref, d = util.run_both(oracle, rs, K=48, min_freq=2)
     st = util.check_parity(ref, d)
     assert st["n_overflow_items"] > 0 and st["n_solid"] > 0
+
+
+@pytest.mark.parametrize("passes", [2, 8])
+def test_hash_slice_passes(oracle, passes):
+    """Capacity passes (MapReduceEngine's nPasses idea): fine buckets are counted in slices; the union must
+    equal the single-pass result and the oracle."""
+    rs = util.make_set(61, 150000, 20000)
+    ref, d = util.run_both(oracle, rs, K=48, passes=passes)
+    st = util.check_parity(ref, d)
+    assert st["n_passes"] == passes
