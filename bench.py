@@ -59,13 +59,14 @@ def profiled_traffic(n_inst):
     return t["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(rs_np, K, sample_reads):
+def cpu_baseline(rs, K, sample_reads):
     """Reference components (or the port) on the first `sample_reads` reads, all host cores."""
     from superplus_amd import feudal
-    n = min(sample_reads, rs_np["n_reads"]) & ~1
-    sub = dict(packed=rs_np["packed"][: int(rs_np["base_off"][n])], base_off=rs_np["base_off"][: n + 1],
-               read_len=rs_np["read_len"][:n], pq_bytes=rs_np["pq_bytes"][: int(rs_np["pq_off"][n])],
-               pq_off=rs_np["pq_off"][: n + 1], bc=rs_np["bc"][:n])
+    n = min(sample_reads, rs.n_reads) & ~1
+    nb, nq = int(rs.base_off[n]), int(rs.pq_off[n])
+    sub = dict(packed=rs.packed[:nb].cpu().numpy(), base_off=rs.base_off[: n + 1].cpu().numpy().astype(np.uint64),
+               read_len=rs.read_len[:n].cpu().numpy().astype(np.uint32), pq_bytes=rs.pq_bytes[:nq].cpu().numpy(),
+               pq_off=rs.pq_off[: n + 1].cpu().numpy().astype(np.uint64), bc=rs.bc[:n].cpu().numpy().astype(np.int32))
     cores = os.cpu_count() or 1
     refdrv = os.path.join(ROOT, "oracle", "_ref", "refdrv")
     if os.path.exists(refdrv):
@@ -105,6 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mb", type=float, default=100.0, help="genome size per GPU, Mb")
     ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--passes", type=int, default=0, help="hash-slice passes (0 = sized from free HBM)")
     ap.add_argument("--K", type=int, default=48)
     ap.add_argument("--minimizer", type=int, default=0)
     ap.add_argument("--inst-per-item", type=int, default=0)
@@ -131,9 +133,10 @@ def main():
     rs = synth.make_reads(genome, pairs, 20261004 + 17 * (rank + 1))
     del genome
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()          # the library sizes its HBM budget from what is free when the context is created
 
     if world == 1:
-        d = Dfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item)
+        d = Dfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes)
         def step():
             d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc)
             return d.stats()
@@ -186,13 +189,13 @@ def main():
             "stage_ms": {k: round(st[k], 3) for k in ("ms_trim", "ms_part_count", "ms_part_scatter", "ms_count",
                                                      "ms_fallback", "ms_adjacency", "ms_total")},
             "counts": {k: st[k] for k in ("n_reads", "n_inst", "n_records", "n_buckets", "n_items", "n_overflow_items",
-                                          "n_distinct", "n_solid", "adj_probes", "hbm_bytes_peak")},
+                                          "n_distinct", "n_solid", "adj_probes", "hbm_bytes_peak", "n_passes")},
             "roofline": {"bound": "hbm", "kernel": "k_count", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(st["n_inst"]),
                          "algorithmic_bytes_per_launch": B_INST * st["n_inst"], "kernel_ms": k_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rs.numpy(), args.K, args.cpu_sample_reads)
+            out["cpu_baseline"] = cpu_baseline(rs, args.K, args.cpu_sample_reads)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

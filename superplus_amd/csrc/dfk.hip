@@ -181,22 +181,43 @@ int stage_trim(dfk_ctx* c, const Inputs& in, uint64_t* n_inst)
     return 0;
 }
 
+// ------------------------------------------------------------------ device-side scans
+// exclusive scan of n u64 on the stream (three levels cover 2^33 elements)
+int device_scan(dfk_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n)
+{
+    constexpr uint64_t PER = (uint64_t)SCAN_THREADS * SCAN_ITEMS;
+    if (n == 0) return 0;
+    const uint64_t nblk = (n + PER - 1) / PER;
+    if (nblk == 1) {
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_THREADS), 0, c->stream, in, out, n, (uint64_t*)nullptr);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    DevBuf sums; int rc = c->alloc(sums, nblk * 8, "scan block sums"); if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, c->stream, in, out, n, (uint64_t*)sums.p);
+    HIP_TRY(hipGetLastError());
+    rc = device_scan(c, (const uint64_t*)sums.p, (uint64_t*)sums.p, nblk); if (rc) return rc;
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_THREADS), 0, c->stream, out, n, (const uint64_t*)sums.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));          // sums is about to return to the pool
+    c->release(sums);
+    return 0;
+}
+
 // ------------------------------------------------------------------ stage: partition (a2, first half)
 // Fine buckets are numbered in one global space of 2^log2_nb (owner-rank-major when sharded).  The count
 // launch sees all of them once; a scatter launch materialises the records of one hash slice ("pass"):
 // buckets with (id & (P-1)) == pass, renumbered id >> log2(P).  This is the reference's nPasses idea
-// (MapReduceEngine.h:454) applied to HBM capacity.
+// (MapReduceEngine.h:454) applied to HBM capacity.  Bucket tables never leave the GPU.
 struct BucketTable {
     uint32_t log2_nb = 0;                 // global
-    std::vector<uint64_t> acc;            // [nb] records<<32 | instances, global numbering
-    uint64_t n_records = 0;
+    DevBuf acc;                           // u64[nb] records<<32 | instances, global numbering
+    uint64_t n_records = 0, n_inst = 0;
 };
 struct Partition {                        // one pass
-    DevBuf records; uint64_t n_records = 0;
+    DevBuf records, base, ipre, items;    // records; u64 base[nb+1] (first record of each bucket); u64 ipre[nb+1]
+    uint64_t n_records = 0, n_inst = 0, n_items = 0;   //   (instance prefix); ItemRange items[n_items]
     uint32_t log2_nb = 0;                 // local (this pass)
-    std::vector<uint64_t> base;           // [nb+1] first record of each local fine bucket
-    std::vector<uint32_t> inst;           // [nb]   instances per local fine bucket
-    uint64_t n_inst = 0;
 };
 
 template <int K>
@@ -206,13 +227,28 @@ PartParams part_params(const dfk_ctx* c, uint32_t log2_nb, uint32_t log2_world, 
     return PartParams{M, (uint32_t)K - M + 1, log2_nb, log2_world, read_id0, log2_pass, pass};
 }
 
+// totals of a counter table (records, instances)
+int table_totals(dfk_ctx* c, const DevBuf& acc, uint64_t nb, uint64_t* n_records, uint64_t* n_inst)
+{
+    DevBuf tot; int rc = c->alloc(tot, 16, "bucket totals"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(tot.p, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_sum_acc, dim3(1024), dim3(256), 0, c->stream, (const unsigned long long*)acc.p, nb, (unsigned long long*)tot.p);
+    HIP_TRY(hipGetLastError());
+    uint64_t h[2];
+    HIP_TRY(hipMemcpyAsync(h, tot.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->release(tot);
+    *n_records = h[0]; *n_inst = h[1];
+    return 0;
+}
+
 template <int K>
 int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, BucketTable* T)
 {
     const PartParams pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 0);
     const uint64_t nb = 1ull << T->log2_nb;
-    DevBuf acc; int rc = c->alloc(acc, nb * 8, "bucket counters"); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(acc.p, 0, nb * 8, c->stream));
+    int rc = c->alloc(T->acc, nb * 8, "bucket counters"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
     const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
     const size_t lds_a = sizeof(uint32_t) * pp.W * PART_THREADS;
     Timer t(c->stream);
@@ -220,42 +256,72 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     if (grid)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
-                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)acc.p,
+                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p,
                            (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint4*)nullptr);
     HIP_TRY(hipGetLastError());
     c->st.ms_part_count = t.stop();
-    TRACE("partition count pass done (%llu buckets)", (unsigned long long)nb);
-    T->acc.resize(nb);
-    HIP_TRY(hipMemcpy(T->acc.data(), acc.p, nb * 8, hipMemcpyDeviceToHost));
-    c->release(acc);
-    uint64_t tot_inst = 0; T->n_records = 0;
-    for (uint64_t b = 0; b < nb; ++b) { T->n_records += T->acc[b] >> 32; tot_inst += (uint32_t)T->acc[b]; }
-    if (tot_inst != n_inst)
+    rc = table_totals(c, T->acc, nb, &T->n_records, &T->n_inst); if (rc) return rc;
+    TRACE("partition count pass done (%llu buckets, %llu records)", (unsigned long long)nb, (unsigned long long)T->n_records);
+    if (T->n_inst != n_inst)
         return fail(DFK_E_HIP, "partition count pass saw %llu instances, trim saw %llu",
-                    (unsigned long long)tot_inst, (unsigned long long)n_inst);
+                    (unsigned long long)T->n_inst, (unsigned long long)n_inst);
     c->st.n_records = T->n_records; c->st.n_buckets = nb;
     return 0;
 }
+
+// base[], ipre[] and the work items of one pass, all on the device
+int pass_tables(dfk_ctx* c, const DevBuf& acc, uint32_t log2_nb_global, uint32_t log2_pass, uint32_t pass, uint64_t budget, Partition* P)
+{
+    P->log2_nb = log2_nb_global - log2_pass;
+    const uint64_t nb = 1ull << P->log2_nb;
+    DevBuf rec, inst, flags, idx;
+    int rc = c->alloc(rec, (nb + 1) * 8, "bucket record counts"); if (rc) return rc;
+    rc = c->alloc(inst, (nb + 1) * 8, "bucket instance counts"); if (rc) return rc;
+    rc = c->alloc(P->base, (nb + 1) * 8, "bucket bases"); if (rc) return rc;
+    rc = c->alloc(P->ipre, (nb + 1) * 8, "bucket instance prefix"); if (rc) return rc;
+    const unsigned g1 = (unsigned)((nb + 1 + 255) / 256);
+    hipLaunchKernelGGL(k_slice, dim3(g1), dim3(256), 0, c->stream, (const unsigned long long*)acc.p, log2_pass, pass, nb,
+                       (uint64_t*)rec.p, (uint64_t*)inst.p);
+    HIP_TRY(hipGetLastError());
+    rc = device_scan(c, (const uint64_t*)rec.p, (uint64_t*)P->base.p, nb + 1); if (rc) return rc;
+    rc = device_scan(c, (const uint64_t*)inst.p, (uint64_t*)P->ipre.p, nb + 1); if (rc) return rc;
+    // items
+    rc = c->alloc(flags, (nb + 1) * 8, "item flags"); if (rc) return rc;
+    rc = c->alloc(idx, (nb + 1) * 8, "item index"); if (rc) return rc;
+    hipLaunchKernelGGL(k_item_flags, dim3(g1), dim3(256), 0, c->stream, (const uint64_t*)P->ipre.p, nb, budget, (uint64_t*)flags.p);
+    HIP_TRY(hipGetLastError());
+    rc = device_scan(c, (const uint64_t*)flags.p, (uint64_t*)idx.p, nb + 1); if (rc) return rc;
+    uint64_t tot[3];
+    HIP_TRY(hipMemcpyAsync(&tot[0], (const uint64_t*)P->base.p + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&tot[1], (const uint64_t*)P->ipre.p + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&tot[2], (const uint64_t*)idx.p + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    P->n_records = tot[0]; P->n_inst = tot[1]; P->n_items = tot[2];
+    rc = c->alloc(P->items, std::max<uint64_t>(1, P->n_items) * sizeof(ItemRange), "work items"); if (rc) return rc;
+    hipLaunchKernelGGL(k_item_pairs, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, (const uint64_t*)flags.p,
+                       (const uint64_t*)idx.p, nb, (ItemRange*)P->items.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->release(rec); c->release(inst); c->release(flags); c->release(idx);
+    return 0;
+}
+
+void release_pass(dfk_ctx* c, Partition* P)
+{ c->release(P->records); c->release(P->base); c->release(P->ipre); c->release(P->items); }
+
+template <int K> constexpr uint64_t default_item_budget() { return (3ull << CountCfg<K>::LOG2S) / 2; }
 
 template <int K>
 int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0,
                       uint32_t log2_pass, uint32_t pass, Partition* P)
 {
     const PartParams pp = part_params<K>(c, T.log2_nb, log2_world, read_id0, log2_pass, pass);
-    P->log2_nb = T.log2_nb - log2_pass;
+    const uint64_t budget = c->cfg.inst_per_item ? c->cfg.inst_per_item : default_item_budget<K>();
+    int rc = pass_tables(c, T.acc, T.log2_nb, log2_pass, pass, budget, P); if (rc) return rc;
     const uint64_t nb = 1ull << P->log2_nb;
-    P->base.assign(nb + 1, 0); P->inst.assign(nb, 0); P->n_inst = 0;
-    for (uint64_t j = 0; j < nb; ++j) {
-        const uint64_t h = T.acc[(j << log2_pass) | pass];
-        P->base[j + 1] = P->base[j] + (h >> 32);
-        P->inst[j] = (uint32_t)h; P->n_inst += (uint32_t)h;
-    }
-    P->n_records = P->base[nb];
-    DevBuf dbase, cur;
-    int rc = c->alloc(dbase, (nb + 1) * 8, "bucket bases"); if (rc) return rc;
+    DevBuf cur;
     rc = c->alloc(cur, nb * 4, "bucket cursors"); if (rc) return rc;
     rc = c->alloc(P->records, P->n_records * 32, "super-k-mer records"); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(dbase.p, P->base.data(), (nb + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(cur.p, 0, nb * 4, c->stream));
     const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
     const size_t lds_b = sizeof(uint32_t) * pp.W * PART_THREADS + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
@@ -265,28 +331,16 @@ int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3(grid), dim3(PART_THREADS), lds_b, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr,
-                           (const uint64_t*)dbase.p, (uint32_t*)cur.p, (uint4*)P->records.p);
+                           (const uint64_t*)P->base.p, (uint32_t*)cur.p, (uint4*)P->records.p);
     HIP_TRY(hipGetLastError());
     c->st.ms_part_scatter += t.stop();
-    TRACE("partition scatter pass %u/%u done (%llu records)", pass + 1, 1u << log2_pass, (unsigned long long)P->n_records);
-    c->release(dbase); c->release(cur);
+    TRACE("partition scatter pass %u/%u done (%llu records, %llu items)", pass + 1, 1u << log2_pass,
+          (unsigned long long)P->n_records, (unsigned long long)P->n_items);
+    c->release(cur);
     return 0;
 }
 
 // ------------------------------------------------------------------ stage: count (a2 second half, a3, a4, a5)
-struct ItemRange { uint32_t b0, b1; };     // fine buckets [b0,b1)
-
-void pack_items(const Partition& P, uint64_t b_lo, uint64_t b_hi, uint64_t budget, std::vector<ItemRange>* out)
-{
-    uint64_t acc = 0; uint32_t start = (uint32_t)b_lo;
-    for (uint64_t b = b_lo; b < b_hi; ++b) {
-        if (P.base[b + 1] == P.base[b]) { if (b == start) start = (uint32_t)b + 1; continue; }
-        if (acc && acc + P.inst[b] > budget) { out->push_back({start, (uint32_t)b}); start = (uint32_t)b; acc = 0; }
-        acc += P.inst[b];
-    }
-    if (acc) out->push_back({start, (uint32_t)b_hi});
-}
-
 constexpr int E_SEGMENT_FULL = -100;   // internal: redo the run with larger output segments
 
 struct CountRun {                     // device state shared by the count launches of one run
@@ -335,41 +389,38 @@ template <int K> unsigned count_grid(const dfk_ctx* c)
     return (unsigned)c->prop.multiProcessorCount * per_cu;
 }
 
+// one k_count launch over `n_items` device-resident items; overflowed items come back as bucket ranges
 template <int K, bool USE_BC>
-int launch_count(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& ranges, const CountRun& R,
+int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint64_t n_items, const CountRun& R,
                  std::vector<ItemRange>* overflowed, float* kernel_ms)
 {
     constexpr int LOG2S = CountCfg<K>::LOG2S, NW = CountCfg<K>::NWAVES;
-    if (ranges.empty()) return 0;
-    std::vector<CountItem> items(ranges.size());
-    for (size_t i = 0; i < ranges.size(); ++i) items[i] = CountItem{P.base[ranges[i].b0], P.base[ranges[i].b1]};
-    DevBuf d_items, d_ovf;
-    int rc = c->alloc(d_items, items.size() * sizeof(CountItem), "count items"); if (rc) return rc;
-    rc = c->alloc(d_ovf, items.size() * 4, "overflow list"); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(CountItem), hipMemcpyHostToDevice, c->stream));
+    if (n_items == 0) return 0;
+    if (n_items >= (1ull << 32)) return fail(DFK_E_ARG, "too many work items in one pass");
+    DevBuf d_ovf;
+    int rc = c->alloc(d_ovf, n_items * sizeof(ItemRange), "overflow list"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(&R.g->next_item, 0, 8, c->stream));      // next_item, n_overflow
-    CountParams cp = R.cp; cp.n_items = (uint32_t)items.size();
+    CountParams cp = R.cp; cp.n_items = (uint32_t)n_items;
     const size_t lds = count_lds_bytes<K, LOG2S, NW>();
     auto kern = k_count<K, LOG2S, NW, USE_BC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    TRACE("k_count: %zu items, grid %u, lds %zu, seg_cap %llu", items.size(), R.grid, lds, (unsigned long long)R.cp.seg_cap);
+    TRACE("k_count: %llu items, grid %u, lds %zu, seg_cap %llu", (unsigned long long)n_items, R.grid, lds, (unsigned long long)R.cp.seg_cap);
     Timer tk(c->stream);
     tk.start();
     hipLaunchKernelGGL(kern, dim3(R.grid), dim3(NW * 64), lds, c->stream,
-                       (const uint4*)P.records.p, (const CountItem*)d_items.p, cp, R.g, R.seg, R.seg_count, R.hist,
-                       (uint32_t*)d_ovf.p);
+                       (const uint4*)P.records.p, d_items, (const uint64_t*)P.base.p, cp, R.g, R.seg, R.seg_count, R.hist,
+                       (ItemRange*)d_ovf.p);
     HIP_TRY(hipGetLastError());
     *kernel_ms += tk.stop();
-    TRACE("k_count done");
     CountGlobals g{};
     HIP_TRY(hipMemcpyAsync(&g, R.g, sizeof g, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (g.n_overflow) {
-        std::vector<uint32_t> ov(g.n_overflow);
-        HIP_TRY(hipMemcpy(ov.data(), d_ovf.p, 4ull * g.n_overflow, hipMemcpyDeviceToHost));
-        for (uint32_t i : ov) overflowed->push_back(ranges[i]);
+        const size_t at = overflowed->size();
+        overflowed->resize(at + g.n_overflow);
+        HIP_TRY(hipMemcpy(overflowed->data() + at, d_ovf.p, sizeof(ItemRange) * g.n_overflow, hipMemcpyDeviceToHost));
     }
-    c->release(d_items); c->release(d_ovf);
+    c->release(d_ovf);
     return 0;
 }
 
@@ -377,18 +428,33 @@ template <int K, bool USE_BC>
 int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& singles, CountRun& R)
 {
     constexpr int KW = KTraits<K>::KW, NW = 8;
-    // tables sized to >= 2x the item's instances (an upper bound on its distinct k-mers)
+    // instance counts of the single buckets (ipre[b1] - ipre[b0]) size their tables: >= 2x the instances,
+    // an upper bound on the distinct k-mers
+    const uint32_t n = (uint32_t)singles.size();
+    std::vector<uint32_t> idx(2 * n);
+    for (uint32_t i = 0; i < n; ++i) { idx[2 * i] = singles[i].b0; idx[2 * i + 1] = singles[i].b1; }
+    DevBuf d_idx, d_val;
+    int rc = c->alloc(d_idx, 8ull * n, "gather index"); if (rc) return rc;
+    rc = c->alloc(d_val, 16ull * n, "gather values"); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_idx.p, idx.data(), 8ull * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather_u64, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, (const uint64_t*)P.ipre.p,
+                       (const uint32_t*)d_idx.p, 2 * n, (uint64_t*)d_val.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint64_t> val(2 * n);
+    HIP_TRY(hipMemcpyAsync(val.data(), d_val.p, 16ull * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->release(d_idx); c->release(d_val);
     std::vector<BigItem> items; uint64_t words = 0, tot_inst = 0;
-    for (const ItemRange& r : singles) {
-        uint64_t inst = 0; for (uint32_t b = r.b0; b < r.b1; ++b) inst += P.inst[b];
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t inst = val[2 * i + 1] - val[2 * i];
         tot_inst += inst;
         uint32_t l2 = std::max<uint32_t>(13, ceil_log2(2 * inst + 64));
-        items.push_back(BigItem{P.base[r.b0], P.base[r.b1], words, l2, 0});
+        items.push_back(BigItem{singles[i].b0, singles[i].b1, words, l2, 0});
         words += (uint64_t)(KW + 3) << l2;
     }
     DevBuf pool, d_items, d_fail;
     R.big_cap = tot_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;   // every solid k-mer has >= min_freq instances
-    int rc = c->alloc(R.big, R.big_cap * 32, "fallback solid entries"); if (rc) return rc;
+    rc = c->alloc(R.big, R.big_cap * 32, "fallback solid entries"); if (rc) return rc;
     rc = c->alloc(pool, words * 4, "HBM fallback tables"); if (rc) return rc;
     rc = c->alloc(d_items, items.size() * sizeof(BigItem), "fallback items"); if (rc) return rc;
     rc = c->alloc(d_fail, 16, "fallback flag"); if (rc) return rc;
@@ -397,7 +463,7 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice, c->stream));
     CountParams cpb = R.cp; cpb.seg_cap = R.big_cap; cpb.n_segments = 1;   // one segment: the fallback's own buffer
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_big<K, NW, USE_BC>), dim3((unsigned)items.size()), dim3(NW * 64), 0, c->stream,
-                       (const uint4*)P.records.p, (const BigItem*)d_items.p, cpb, R.g, (uint4*)R.big.p, R.hist,
+                       (const uint4*)P.records.p, (const BigItem*)d_items.p, (const uint64_t*)P.base.p, cpb, R.g, (uint4*)R.big.p, R.hist,
                        (uint32_t*)pool.p, (uint32_t*)d_fail.p);
     HIP_TRY(hipGetLastError());
     uint32_t failed = 0;
@@ -408,22 +474,16 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     return 0;
 }
 
-// Count one pass: pack items, run k_count (+ split / HBM-table fallbacks), gather the pass's solid k-mers
-// into a dense part.
+// Count one pass: run k_count over its items (+ split / HBM-table fallbacks), gather the pass's solid
+// k-mers into a dense part.
 template <int K, bool USE_BC>
 int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
 {
     const unsigned attempt = c->seg_attempt;
-    constexpr int LOG2S = CountCfg<K>::LOG2S;
-    const uint64_t nb = 1ull << P.log2_nb;
-    const uint64_t budget = c->cfg.inst_per_item ? c->cfg.inst_per_item : (3ull << LOG2S) / 2;
-    std::vector<ItemRange> ranges;
-    pack_items(P, 0, nb, budget, &ranges);
-
     // Output: one segment per persistent workgroup, filled through an LDS cursor.  Every solid k-mer has
     // >= min_freq instances, which bounds the total; after the first pass the observed solid/instance
     // ratio gives a much tighter estimate.
-    R.grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ranges.size(), count_grid<K>(c)));
+    R.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(P.n_items, count_grid<K>(c)));
     const uint32_t nseg = R.grid;
     uint64_t cap = P.n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
     if (R.inst_seen) cap = std::min<uint64_t>(cap, (uint64_t)(1.3 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
@@ -431,54 +491,53 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
     // the dense part made afterwards needs room too: leave a third of what is left for it
     if (cap * 32 > room / 3 * 2) cap = room / 3 * 2 / 32;
     // dynamic item scheduling balances the workgroups to within a few items (<= 3/4 S entries each);
-    // if a segment still fills up the whole pass is redone with twice the room
+    // if a segment still fills up the whole run is redone with twice the room
     const uint64_t seg_cap = std::min<uint64_t>(((cap / nseg) * 5 / 4 + 8192) << attempt, 0xFFFFFFF0ull);
     DevBuf d_seg, d_segcnt;
     int rc = c->alloc(d_seg, seg_cap * nseg * 32, "solid k-mer segments"); if (rc) return rc;
     rc = c->alloc(d_segcnt, 4ull * nseg, "segment counts"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_segcnt.p, 0, 4ull * nseg, c->stream));
-    CountGlobals before{};
-    HIP_TRY(hipMemcpy(&before, R.d_g.p, sizeof before, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemsetAsync(&R.g->big_cursor, 0, 8, c->stream));
     R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, nseg, seg_cap, c->cfg.min_freq > 1 ? 1u : 0u,
                        (c->cfg.flags & DFK_F_KEEP_PRE_ADJ) ? 1u : 0u};
-    R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p;
+    R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p; R.big_cap = 0;
 
     Timer t(c->stream);
     std::vector<ItemRange> overflowed;
-    c->st.n_items += ranges.size();
-    rc = launch_count<K, USE_BC>(c, P, ranges, R, &overflowed, &c->st.ms_count); if (rc) return rc;
+    c->st.n_items += P.n_items;
+    rc = launch_count<K, USE_BC>(c, P, (const ItemRange*)P.items.p, P.n_items, R, &overflowed, &c->st.ms_count); if (rc) return rc;
     t.start();
-    // items that overflowed their LDS table: split at fine-bucket boundaries and retry; a single
-    // fine bucket that still overflows is counted in an HBM table
+    // items that overflowed their LDS table are halved by bucket index and retried; a single fine bucket
+    // that still overflows is counted in an HBM table
     c->st.n_overflow_items += overflowed.size();
     std::vector<ItemRange> singles;
     while (!overflowed.empty()) {
         std::vector<ItemRange> next;
         for (const ItemRange& r : overflowed) {
-            std::vector<uint32_t> nz;
-            for (uint32_t b = r.b0; b < r.b1; ++b) if (P.base[b + 1] != P.base[b]) nz.push_back(b);
-            if (nz.size() <= 1) { singles.push_back(r); continue; }
-            uint32_t mid = nz[nz.size() / 2];
+            if (r.b1 - r.b0 <= 1) { singles.push_back(r); continue; }
+            const uint32_t mid = r.b0 + (r.b1 - r.b0) / 2;
             next.push_back({r.b0, mid}); next.push_back({mid, r.b1});
         }
         overflowed.clear();
+        if (next.empty()) break;
         TRACE("retrying %zu split items", next.size());
+        DevBuf d_next; rc = c->alloc(d_next, next.size() * sizeof(ItemRange), "split items"); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(d_next.p, next.data(), next.size() * sizeof(ItemRange), hipMemcpyHostToDevice, c->stream));
         float ignored = 0;
-        rc = launch_count<K, USE_BC>(c, P, next, R, &overflowed, &ignored); if (rc) return rc;
+        rc = launch_count<K, USE_BC>(c, P, (const ItemRange*)d_next.p, next.size(), R, &overflowed, &ignored);
+        c->release(d_next);
+        if (rc) return rc;
     }
     TRACE("fallback: %zu single-bucket items", singles.size());
     if (!singles.empty()) { rc = launch_count_big<K, USE_BC>(c, P, singles, R); if (rc) return rc; }
     c->st.ms_fallback += t.stop();
-    TRACE("count stage kernels done");
 
     CountGlobals hg{};
     std::vector<uint32_t> segcnt(nseg);
     HIP_TRY(hipMemcpy(&hg, R.d_g.p, sizeof hg, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(segcnt.data(), d_segcnt.p, 4ull * nseg, hipMemcpyDeviceToHost));
     if (hg.solid_overflow || hg.big_cursor > R.big_cap) {
-        // undo this pass's contribution to the running counters and the spectrum is not possible for the
-        // histogram, so a pass that overflowed its output restarts the whole run with more room
+        // the spectrum and counters cannot be unwound: the caller restarts the run with more room
         c->release(d_seg); c->release(d_segcnt); c->release(R.big);
         fail(DFK_E_NOMEM, "a solid k-mer output segment (%llu entries) is full", (unsigned long long)seg_cap);
         return E_SEGMENT_FULL;
@@ -501,7 +560,6 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
     c->parts.push_back(part);
     c->n_solid += part.n; c->st.n_solid = c->n_solid;
     R.solid_seen += part.n; R.inst_seen += P.n_inst;
-    (void)before;
     return 0;
 }
 
@@ -567,10 +625,11 @@ int stage_adjacency(dfk_ctx* c)
 
 uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
 {
-    // fine buckets of ~512-1024 instances; items pack several of them
-    uint32_t l = ceil_log2(n_inst / 1024 + 1);
+    // fine buckets of ~256-512 instances; an item packs several of them up to its instance budget.
+    // The record header keeps 24 bits of the (rank-local) bucket id for the multi-GPU regroup.
+    uint32_t l = ceil_log2(n_inst / 512 + 1);
     l = std::max<uint32_t>(l, 4 + log2_world);
-    return std::min<uint32_t>(l, 23);
+    return std::min<uint32_t>(l, log2_world ? 24 + log2_world : 28);
 }
 
 uint32_t pick_passes(const dfk_ctx* c, uint64_t n_records, uint64_t n_inst)
@@ -613,8 +672,9 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         rc = partition_scatter<K>(c, in, T, 0, 0, log2_pass, pass, &P); if (rc) return rc;
         rc = in.bc ? stage_count<K, true>(c, P, R) : stage_count<K, false>(c, P, R);
         if (rc) return rc;
-        c->release(P.records);
+        release_pass(c, &P);
     }
+    c->release(T.acc);
     c->st.reserved[0] = 1u << log2_pass;
     rc = count_run_end(c, &R); if (rc) return rc;
     rc = stage_adjacency<K>(c); if (rc) return rc;

@@ -252,7 +252,8 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
 // each instance's canonical k-mer and context from the staged 2-bit stream and inserts it.
 // After the item, solid slots are compacted to the output and the spectrum is updated.
 
-struct CountItem { uint64_t rec_begin; uint64_t rec_end; };
+
+struct ItemRange { uint32_t b0, b1; };     // a work item: fine buckets [b0,b1) of the current pass
 
 struct CountParams {
     uint32_t min_freq, min_bc;
@@ -589,9 +590,9 @@ enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_CURSOR = 4, C
 
 template <int K, int LOG2S, int NWAVES, bool USE_BC>
 __global__ void __launch_bounds__(NWAVES * 64)
-k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, CountParams cp,
-        CountGlobals* __restrict__ g, uint4* __restrict__ out, uint32_t* __restrict__ seg_count,
-        unsigned long long* __restrict__ hist_global, uint32_t* __restrict__ overflow_items)
+k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, const uint64_t* __restrict__ rec_base,
+        CountParams cp, CountGlobals* __restrict__ g, uint4* __restrict__ out, uint32_t* __restrict__ seg_count,
+        unsigned long long* __restrict__ hist_global, ItemRange* __restrict__ overflow_items)
 {
     constexpr uint32_t S = 1u << LOG2S;
     constexpr int KW = KTraits<K>::KW;
@@ -619,7 +620,7 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
         ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0;
         const uint32_t it0 = atomicAdd(&g->next_item, 1u);
         uint64_t b0 = 0, e0 = 0;
-        if (it0 < cp.n_items) { b0 = items[it0].rec_begin; e0 = items[it0].rec_end; }
+        if (it0 < cp.n_items) { b0 = rec_base[items[it0].b0]; e0 = rec_base[items[it0].b1]; }
         ctl[CTL_ITEM] = it0; ctl[CTL_RB_LO] = (uint32_t)b0; ctl[CTL_RB_HI] = (uint32_t)(b0 >> 32);
         ctl[CTL_RE_LO] = (uint32_t)e0; ctl[CTL_RE_HI] = (uint32_t)(e0 >> 32);
     }
@@ -632,7 +633,7 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
         uint32_t nx = 0xFFFFFFFFu; uint64_t nb = 0, ne = 0;
         if (tid == 0) {
             nx = atomicAdd(&g->next_item, 1u);
-            if (nx < cp.n_items) { nb = items[nx].rec_begin; ne = items[nx].rec_end; }
+            if (nx < cp.n_items) { nb = rec_base[items[nx].b0]; ne = rec_base[items[nx].b1]; }
         }
         // Waves pull chunks of the item from an LDS ticket.  All loop control is made scalar
         // (readfirstlane) so the compiler emits uniform branches, and the trip count is bounded.
@@ -649,7 +650,7 @@ k_count(const uint4* __restrict__ records, const CountItem* __restrict__ items, 
         }
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(ctl[CTL_OVF])) {
-            if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = item;
+            if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = items[item];
             for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;         // abandon the table
             __syncthreads();                                           // everyone has read CTL_OVF before it is reset
         } else {
@@ -685,11 +686,11 @@ constexpr size_t count_lds_bytes()
 // Fallback: one workgroup per overflowed item, table in HBM (tab = [KW+3][S] words, zeroed by
 // the host), staging still in LDS.  Same insertion code; atomics resolve to global memory.
 // Output goes to the last segment through a global cursor.
-struct BigItem { uint64_t rec_begin, rec_end; uint64_t tab_off; uint32_t log2s; uint32_t pad; };
+struct BigItem { uint32_t b0, b1; uint64_t tab_off; uint32_t log2s; uint32_t pad; };
 
 template <int K, int NWAVES, bool USE_BC>
 __global__ void __launch_bounds__(NWAVES * 64)
-k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items, CountParams cp,
+k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items, const uint64_t* __restrict__ rec_base, CountParams cp,
             CountGlobals* __restrict__ g, uint4* __restrict__ out, unsigned long long* __restrict__ hist_global,
             uint32_t* __restrict__ tab_pool, uint32_t* __restrict__ failed)
 {
@@ -707,8 +708,9 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_NTASK] = 0; ctl[CTL_BOUNDARY] = 0; }
     __syncthreads();
-    for (uint64_t c = it.rec_begin + (uint64_t)COUNT_CHUNK * wave; c < it.rec_end; c += (uint64_t)COUNT_CHUNK * NWAVES)
-        wave_count_chunk<K, USE_BC>(records, c, it.rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[CTL_FILL], &ctl[CTL_OVF]);
+    const uint64_t rec_begin = rec_base[it.b0], rec_end = rec_base[it.b1];
+    for (uint64_t c = rec_begin + (uint64_t)COUNT_CHUNK * wave; c < rec_end; c += (uint64_t)COUNT_CHUNK * NWAVES)
+        wave_count_chunk<K, USE_BC>(records, c, rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[CTL_FILL], &ctl[CTL_OVF]);
     __threadfence();
     __syncthreads();
     if (ctl[CTL_OVF]) { if (tid == 0) atomicOr(failed, 1u); return; }
@@ -979,6 +981,93 @@ k_regroup(const uint4* __restrict__ in, uint64_t n, uint32_t local_mask, unsigne
         uint64_t dst = bucket_base[b] + atomicAdd(&bucket_cur[b], 1u);
         out[2 * dst] = a; out[2 * dst + 1] = in[2 * i + 1];
     }
+}
+
+
+// ============================================================================ device-side bucket tables
+// Everything that is O(number of fine buckets) stays on the GPU: a 30x human set has ~10^8 of them.
+
+// exclusive scan of u64, 2048 elements per block; block totals go to `sums` (scanned by the next level)
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8;
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_blocks(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t n, uint64_t* __restrict__ sums)
+{
+    __shared__ uint64_t wsum[SCAN_THREADS / 64];
+    const uint64_t base = ((uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS], run = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? in[base + i] : 0; run += v[i]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint64_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    uint64_t ex = woff + incl - run;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+    if (threadIdx.x == SCAN_THREADS - 1 && sums) sums[blockIdx.x] = woff + incl;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_scan_add(uint64_t* __restrict__ out, uint64_t n, const uint64_t* __restrict__ sums)
+{
+    const uint64_t add = sums[blockIdx.x];
+    const uint64_t base = ((uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) out[base + i] += add;
+}
+
+// one hash-slice pass's view of the global counters: local bucket j = global bucket j*P + pass
+__global__ void __launch_bounds__(256)
+k_slice(const unsigned long long* __restrict__ acc, uint32_t log2_pass, uint32_t pass, uint64_t nb_local,
+        uint64_t* __restrict__ rec, uint64_t* __restrict__ inst)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nb_local) return;
+    unsigned long long h = j < nb_local ? acc[(j << log2_pass) | pass] : 0ull;    // element nb_local = 0: the scans yield totals there
+    rec[j] = h >> 32; inst[j] = h & 0xFFFFFFFFull;
+}
+
+// items: consecutive fine buckets whose instance prefix falls in the same multiple of `budget`
+__global__ void __launch_bounds__(256)
+k_item_flags(const uint64_t* __restrict__ ipre, uint64_t nb, uint64_t budget, uint64_t* __restrict__ flags)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    flags[b] = b < nb && (b == 0 || ipre[b] / budget != ipre[b - 1] / budget) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_item_pairs(const uint64_t* __restrict__ flags, const uint64_t* __restrict__ idx, uint64_t nb, ItemRange* __restrict__ items)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb || !flags[b]) return;
+    const uint64_t k = idx[b];
+    items[k].b0 = (uint32_t)b;
+    if (k) items[k - 1].b1 = (uint32_t)b;
+    if (k + 1 == idx[nb]) items[k].b1 = (uint32_t)nb;
+}
+
+// totals of the global counters: out[0] += records, out[1] += instances
+__global__ void __launch_bounds__(256)
+k_sum_acc(const unsigned long long* __restrict__ acc, uint64_t nb, unsigned long long* __restrict__ out)
+{
+    unsigned long long r = 0, i = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x)
+    { r += acc[b] >> 32; i += acc[b] & 0xFFFFFFFFull; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { r += __shfl_down(r, d, 64); i += __shfl_down(i, d, 64); }
+    if ((threadIdx.x & 63) == 0) { if (r) atomicAdd(&out[0], r); if (i) atomicAdd(&out[1], i); }
+}
+
+__global__ void __launch_bounds__(256)
+k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, uint64_t* __restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
 }
 
 // ============================================================================ small utilities

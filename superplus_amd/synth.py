@@ -40,6 +40,9 @@ class ReadSet:
 
 
 def make_genome(size, seed, device="cpu", repeat_frac=0.0):
+    if torch.device(device).type != "cpu" and repeat_frac == 0:
+        g = torch.Generator(device=device).manual_seed(seed)
+        return torch.randint(0, 4, (size,), generator=g, dtype=torch.uint8, device=device)
     g = torch.Generator(device="cpu").manual_seed(seed)
     genome = torch.randint(0, 4, (size,), generator=g, dtype=torch.uint8)
     if repeat_frac > 0 and size > 4000:
@@ -56,75 +59,83 @@ def make_genome(size, seed, device="cpu", repeat_frac=0.0):
 def make_reads(genome, n_pairs, seed, read_len=100, err=0.005, unbar_frac=0.10,
                pairs_per_barcode=20, tails=(0, 0, 0, 5, 15), quals=(30, 35, 37),
                chunk=1 << 22):
-    """-> ReadSet on genome.device."""
+    """-> ReadSet on genome.device.  All random draws happen on that device (a seeded torch.Generator), so a
+    30x human-scale set is generated in HBM without touching the host."""
     dev = genome.device
     G = genome.numel()
     L = read_len
     assert G > 600 and L % 4 == 0
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ri = lambda lo, hi, n: torch.randint(lo, hi, (n,), generator=g, device=dev)
     n_unbar = int(n_pairs * unbar_frac)
     n_bar = n_pairs - n_unbar
     n_bc = max(1, n_bar // pairs_per_barcode) if n_bar else 0
 
-    # barcode of every barcoded pair, sorted so that reads are grouped by barcode
-    pair_bc = torch.sort(torch.randint(1, n_bc + 1, (n_bar,), generator=g))[0] if n_bar else torch.zeros(0, dtype=torch.int64)
-    pair_bc = torch.cat([torch.zeros(n_unbar, dtype=torch.int64), pair_bc])
-    counts = torch.bincount(pair_bc, minlength=n_bc + 1) * 2
-    bci = np.concatenate([[0], np.cumsum(counts.numpy())]).astype(np.int64)
-
-    # fragment start: unbarcoded uniform; barcoded inside one of 2 molecules of its barcode
-    insert = torch.randint(250, 450, (n_pairs,), generator=g)
-    frag = torch.randint(0, G - 450, (n_pairs,), generator=g)
+    # barcode of every pair, sorted so that reads are grouped by barcode (0 = unbarcoded, first)
+    pair_bc = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
     if n_bar:
-        mol_len = torch.randint(10000, 50000, (n_bc + 1, 2), generator=g).clamp(max=max(500, G - 500))
-        mol_start = (torch.rand((n_bc + 1, 2), generator=g) * (G - mol_len).clamp(min=1)).long()
-        which = torch.randint(0, 2, (n_pairs,), generator=g)
-        ms = mol_start[pair_bc, which]
-        ml = mol_len[pair_bc, which]
-        inside = ms + (torch.rand(n_pairs, generator=g) * (ml - 450).clamp(min=1)).long()
-        frag = torch.where(pair_bc > 0, inside.clamp(max=G - 451), frag)
-    strand = torch.randint(0, 2, (n_pairs,), generator=g)
+        pair_bc[n_unbar:] = torch.sort(ri(1, n_bc + 1, n_bar))[0].to(torch.int32)
+    counts = torch.bincount(pair_bc, minlength=n_bc + 1) * 2
+    bci = np.concatenate([[0], np.cumsum(counts.cpu().numpy())]).astype(np.int64)
+    del counts
+
+    # per-barcode molecules: 2 per barcode, 10-50 kb
+    if n_bar:
+        mol_len = torch.randint(10000, 50000, (n_bc + 1, 2), generator=g, device=dev).clamp(max=max(500, G - 500))
+        mol_start = (torch.rand((n_bc + 1, 2), generator=g, device=dev) * (G - mol_len).clamp(min=1)).long()
 
     n_reads = 2 * n_pairs
     nb = L // 4
     packed = torch.empty((n_reads, nb), dtype=torch.uint8, device=dev)
-    tail_choices = torch.tensor(tails, dtype=torch.int64)
-    qual_choices = torch.tensor(quals, dtype=torch.int64)
-    tail = tail_choices[torch.randint(0, len(tails), (n_reads,), generator=g)]
-    qbody = qual_choices[torch.randint(0, len(quals), (n_reads,), generator=g)]
     ar = torch.arange(L, device=dev)
     for a in range(0, n_pairs, chunk):
         b = min(n_pairs, a + chunk)
-        f = frag[a:b].to(dev); ins = insert[a:b].to(dev); st = strand[a:b].to(dev)
+        m = b - a
+        ins = ri(250, 450, m)
+        f = ri(0, G - 450, m)
+        st = ri(0, 2, m)
+        if n_bar:
+            pbc = pair_bc[a:b].long()
+            which = ri(0, 2, m)
+            ms = mol_start[pbc, which]; ml = mol_len[pbc, which]
+            inside = ms + (torch.rand(m, generator=g, device=dev) * (ml - 450).clamp(min=1)).long()
+            f = torch.where(pbc > 0, inside.clamp(max=G - 451), f)
+            del pbc, which, ms, ml, inside
         fw = genome[(f[:, None] + ar[None, :])]                                  # left read, forward
         rv = 3 - genome[(f + ins - 1)[:, None] - ar[None, :]]                    # right read, reverse-complement
         r1 = torch.where(st[:, None] == 0, fw, rv)
         r2 = torch.where(st[:, None] == 0, rv, fw)
+        del fw, rv
         both = torch.stack([r1, r2], dim=1).reshape(-1, L)
-        ge = torch.Generator(device=dev).manual_seed(seed * 1000003 + a)
-        hit = torch.rand(both.shape, device=dev, generator=ge) < err
-        sub = torch.randint(1, 4, both.shape, device=dev, generator=ge, dtype=torch.uint8)
+        del r1, r2
+        hit = torch.rand(both.shape, device=dev, generator=g) < err
+        sub = torch.randint(1, 4, both.shape, device=dev, generator=g, dtype=torch.uint8)
         both = torch.where(hit, (both + sub) & 3, both)
+        del hit, sub
         c = both.reshape(-1, nb, 4)
         packed[2 * a : 2 * b] = c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)
+        del both, c
 
-    # PQVec: [L-tail x Q][tail x Q2] as nBits=0 blocks: {nQs, minQ<<3 (lo), minQ>>5, } + 0 terminator
+    # PQVec: [L-tail x Q][tail x Q2] as nBits=0 blocks {nQs, minQ<<3 (low byte), minQ>>5} + the 0 terminator
+    tail_choices = torch.tensor(tails, dtype=torch.int64, device=dev)
+    qual_choices = torch.tensor(quals, dtype=torch.int64, device=dev)
+    tail = tail_choices[ri(0, len(tails), n_reads)]
+    qbody = qual_choices[ri(0, len(quals), n_reads)]
     has_tail = tail > 0
-    pq_len = torch.where(has_tail, 7, 4)
-    pq_off = torch.zeros(n_reads + 1, dtype=torch.int64)
-    pq_off[1:] = torch.cumsum(pq_len, 0)
-    pq = torch.zeros(int(pq_off[-1]), dtype=torch.uint8)
+    pq_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    pq_off[1:] = torch.cumsum(torch.where(has_tail, 7, 4), 0)
+    pq = torch.zeros(int(pq_off[-1]), dtype=torch.uint8, device=dev)
     o = pq_off[:-1]
     pq[o] = (L - tail).to(torch.uint8)
     pq[o + 1] = ((qbody << 3) & 0xFF).to(torch.uint8)
     pq[o + 2] = (qbody >> 5).to(torch.uint8)
     ot = o[has_tail]
     pq[ot + 3] = tail[has_tail].to(torch.uint8)
-    pq[ot + 4] = torch.full_like(ot, (2 << 3) & 0xFF).to(torch.uint8)
-    pq[ot + 5] = 0
-    bc = torch.repeat_interleave(pair_bc, 2).to(torch.int32)
+    pq[ot + 4] = (2 << 3) & 0xFF
+    del tail, qbody, has_tail, o, ot
+    bc = torch.repeat_interleave(pair_bc, 2)
     return ReadSet(
         packed=packed.reshape(-1),
-        base_off=(torch.arange(n_reads + 1, dtype=torch.int64) * nb).to(dev),
+        base_off=torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * nb,
         read_len=torch.full((n_reads,), L, dtype=torch.int32, device=dev),
-        pq_bytes=pq.to(dev), pq_off=pq_off.to(dev), bc=bc.to(dev), bci=bci, n_reads=n_reads)
+        pq_bytes=pq, pq_off=pq_off, bc=bc, bci=bci, n_reads=n_reads)
