@@ -66,6 +66,7 @@ struct dfk_ctx {
     std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
     unsigned seg_attempt = 0;                 // output segments are sized (estimate << seg_attempt)
+    unsigned extra_passes = 0;                // log2 of additional hash-slice passes after a run ran out of HBM
     std::vector<int64_t> hist;
     std::vector<dfk_entry32> sorted, sorted_pre;
     bool sorted_ok = false, sorted_pre_ok = false;
@@ -80,39 +81,54 @@ struct dfk_ctx {
     DevBuf set; uint64_t set_mask = 0;
     uint32_t shard_world = 1, shard_log2_nb = 0;
 
-    // Freed blocks are kept and reused (hipMalloc/hipFree of multi-GB blocks cost milliseconds each and
-    // hipFree synchronises the device); the pool counts against the same budget.
-    struct Block { void* p; size_t bytes; };
-    std::vector<Block> pool;
-    uint64_t pooled = 0;
+    // Device memory comes from a few large chunks that are kept for the life of the context and managed
+    // by first-fit free lists with coalescing.  hipMalloc/hipFree of multi-GB blocks cost milliseconds to
+    // seconds each (and hipFree synchronises the device); a 30x human run moves hundreds of GB per pass.
+    struct Free { uint64_t off, bytes; };
+    struct Chunk { char* p; uint64_t bytes; std::vector<Free> free_list; };     // free_list sorted by offset
+    std::vector<Chunk> chunks;
+    uint64_t reserved = 0;                           // sum of chunk sizes
 
-    void trim_pool(uint64_t need)
+    bool carve(Chunk& k, size_t bytes, DevBuf& b)
     {
-        while (!pool.empty() && held + pooled + need > budget) {
-            (void)hipFree(pool.back().p); pooled -= pool.back().bytes; pool.pop_back();
-        }
+        for (size_t i = 0; i < k.free_list.size(); ++i)
+            if (k.free_list[i].bytes >= bytes) {
+                b.p = k.p + k.free_list[i].off; b.bytes = bytes;
+                k.free_list[i].off += bytes; k.free_list[i].bytes -= bytes;
+                if (!k.free_list[i].bytes) k.free_list.erase(k.free_list.begin() + i);
+                return true;
+            }
+        return false;
+    }
+    void drop_empty_chunks()
+    {
+        for (size_t i = 0; i < chunks.size();)
+            if (chunks[i].free_list.size() == 1 && chunks[i].free_list[0].bytes == chunks[i].bytes)
+            { (void)hipFree(chunks[i].p); reserved -= chunks[i].bytes; chunks.erase(chunks.begin() + i); }
+            else ++i;
     }
     int alloc(DevBuf& b, size_t bytes, const char* what)
     {
         bytes = bytes ? (bytes + 255) & ~(size_t)255 : 256;
-        size_t best = pool.size();
-        for (size_t i = 0; i < pool.size(); ++i)
-            if (pool[i].bytes >= bytes && pool[i].bytes <= bytes + bytes / 2 + (1u << 20) &&
-                (best == pool.size() || pool[i].bytes < pool[best].bytes)) best = i;
-        if (best != pool.size()) {
-            b.p = pool[best].p; b.bytes = pool[best].bytes; pooled -= b.bytes;
-            pool.erase(pool.begin() + best);
-        } else {
-            if (held + bytes > budget)
-                return fail(DFK_E_NOMEM, "HBM budget exceeded allocating %zu bytes for %s (held %llu, budget %llu)",
-                            bytes, what, (unsigned long long)held, (unsigned long long)budget);
-            trim_pool(bytes);
-            hipError_t e = hipMalloc(&b.p, bytes);
-            if (e != hipSuccess && !pool.empty()) { trim_pool(budget); e = hipMalloc(&b.p, bytes); }
-            if (e != hipSuccess) return fail(DFK_E_NOMEM, "hipMalloc(%zu) for %s: %s", bytes, what, hipGetErrorString(e));
-            b.bytes = bytes;
+        if (held + bytes > budget)
+            return fail(DFK_E_NOMEM, "HBM budget exceeded allocating %zu bytes for %s (held %llu, budget %llu)",
+                        bytes, what, (unsigned long long)held, (unsigned long long)budget);
+        bool ok = false;
+        for (Chunk& k : chunks) if (carve(k, bytes, b)) { ok = true; break; }
+        if (!ok) {
+            // grow: twice the request (later requests reuse the slack), never past the budget
+            uint64_t want = std::max<uint64_t>(2 * (uint64_t)bytes, 64ull << 20);
+            if (reserved + want > budget) { drop_empty_chunks(); want = std::min<uint64_t>(want, budget > reserved ? budget - reserved : 0); }
+            if (want < bytes) return fail(DFK_E_NOMEM, "HBM budget exhausted by fragmentation allocating %zu bytes for %s", bytes, what);
+            void* p = nullptr;
+            hipError_t e = hipMalloc(&p, want);
+            if (e != hipSuccess && want > bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&p, want); }
+            if (e != hipSuccess) return fail(DFK_E_NOMEM, "hipMalloc(%llu) for %s: %s", (unsigned long long)want, what, hipGetErrorString(e));
+            chunks.push_back(Chunk{(char*)p, want, {Free{0, want}}});
+            reserved += want;
+            carve(chunks.back(), bytes, b);
         }
-        held += b.bytes; peak = std::max(peak, held);
+        held += bytes; peak = std::max(peak, held);
         owned.push_back(b.p);
         return 0;
     }
@@ -121,10 +137,20 @@ struct dfk_ctx {
         if (!b.p) return;
         auto it = std::find(owned.begin(), owned.end(), b.p);
         if (it != owned.end()) owned.erase(it);
-        pool.push_back(Block{b.p, b.bytes}); pooled += b.bytes;
+        for (Chunk& k : chunks)
+            if ((char*)b.p >= k.p && (char*)b.p < k.p + k.bytes) {
+                std::vector<Free>& fl = k.free_list;
+                const uint64_t off = (uint64_t)((char*)b.p - k.p);
+                size_t i = 0;
+                while (i < fl.size() && fl[i].off < off) ++i;
+                fl.insert(fl.begin() + i, Free{off, b.bytes});
+                if (i + 1 < fl.size() && fl[i].off + fl[i].bytes == fl[i + 1].off) { fl[i].bytes += fl[i + 1].bytes; fl.erase(fl.begin() + i + 1); }
+                if (i > 0 && fl[i - 1].off + fl[i - 1].bytes == fl[i].off) { fl[i - 1].bytes += fl[i].bytes; fl.erase(fl.begin() + i); }
+                break;
+            }
         held -= b.bytes; b.p = nullptr; b.bytes = 0;
     }
-    void drop_pool() { for (Block& k : pool) (void)hipFree(k.p); pool.clear(); pooled = 0; }
+    void drop_pool() { for (Chunk& k : chunks) (void)hipFree(k.p); chunks.clear(); reserved = 0; }
     void release_all()
     {
         // results of the previous run go back to the pool (sizes come from the DevBufs that own them)
@@ -132,8 +158,9 @@ struct dfk_ctx {
         for (DevBuf* d : live) release(*d);
         for (Part& pt : parts) { release(pt.buf); release(pt.pre); }
         parts.clear();
-        for (void* p : owned) (void)hipFree(p);                        // anything an aborted run left behind
+        // anything an aborted run left behind: the arena is simply declared empty again
         owned.clear(); held = 0;
+        for (Chunk& k : chunks) k.free_list.assign(1, Free{0, k.bytes});
         good_len = shard_records = adj_keys = adj_src = set = DevBuf{};
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
         n_solid = 0; adj_n = 0; shard_open = false;
@@ -641,7 +668,8 @@ uint32_t pick_passes(const dfk_ctx* c, uint64_t n_records, uint64_t n_inst)
     // one pass holds its records (32 B each) plus its output segments and dense part (~ n_inst/8 x 32 B x 2.3);
     // finished parts of earlier passes stay resident.  Keep a pass's working set under ~40 % of what is free.
     const uint64_t room = c->budget > c->held ? c->budget - c->held : 0;
-    const double solid_all = (double)n_inst / 8.0 * 32.0;            // generous estimate of the final dictionary
+    const double solid_all = (double)n_inst / 12.0 * 32.0;           // guess at the final dictionary (30x data: n_inst/15 entries);
+                                                                     // a run that still runs out of HBM is redone with more passes
     uint32_t l = 0;
     for (; l < 8; ++l) {
         const double pass_ws = ((double)n_records * 32.0 + solid_all * 1.3) / (double)(1u << l);
@@ -663,7 +691,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     c->st.n_reads = in.n_reads; c->st.n_inst = n_inst; c->n_reads = in.n_reads;
     BucketTable T; T.log2_nb = pick_log2_nb(n_inst, 0);
     rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
-    const uint32_t log2_pass = std::min<uint32_t>(pick_passes(c, T.n_records, n_inst), T.log2_nb > 4 ? T.log2_nb - 4 : 0);
+    const uint32_t log2_pass = std::min<uint32_t>(pick_passes(c, T.n_records, n_inst) + c->extra_passes, T.log2_nb > 4 ? T.log2_nb - 4 : 0);
     TRACE("%llu instances, %llu records, %u pass(es)", (unsigned long long)n_inst, (unsigned long long)T.n_records, 1u << log2_pass);
     CountRun R;
     rc = count_run_begin(c, &R); if (rc) return rc;
@@ -686,6 +714,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
 
 int run(dfk_ctx* c, const Inputs& in)
 {
+    c->extra_passes = 0;
     for (c->seg_attempt = 0;; ++c->seg_attempt) {
         int rc;
         switch (c->cfg.K) {
@@ -693,6 +722,13 @@ int run(dfk_ctx* c, const Inputs& in)
         case 48: rc = run_typed<48>(c, in); break;
         case 60: rc = run_typed<60>(c, in); break;
         default: return fail(DFK_E_ARG, "K must be 40, 48 or 60");
+        }
+        if (rc == DFK_E_NOMEM && !c->cfg.reserved[0] && c->extra_passes < 6) {
+            // the working set of a pass did not fit beside the dictionary built so far: halve the passes' size
+            ++c->extra_passes; --c->seg_attempt;
+            TRACE("out of HBM (%s): redoing the run with twice the passes", g_err.c_str());
+            c->release_all(); c->st = dfk_stats{};
+            continue;
         }
         if (rc != E_SEGMENT_FULL) return rc;
         // the spectrum and counters of the failed attempt cannot be unwound: start over with twice the room
@@ -739,7 +775,7 @@ int dfk_create(const dfk_config* cfg, dfk_ctx** out)
     if (cfg->K != 40 && cfg->K != 48 && cfg->K != 60) return fail(DFK_E_ARG, "K=%u: the reference instantiates 40, 48 and 60 only", cfg->K);
     if (cfg->min_bc > 2) return fail(DFK_E_ARG, "MIN_BC=%u: the GPU path tracks at most 2 distinct barcodes per k-mer", cfg->min_bc);
     if (cfg->min_freq == 0 || cfg->min_freq > 0xFFFFFFu) return fail(DFK_E_ARG, "MIN_FREQ out of range");
-    uint32_t M = cfg->minimizer_len ? cfg->minimizer_len : 14;
+    uint32_t M = cfg->minimizer_len ? cfg->minimizer_len : 16;
     if (M < 8 || M > 16 || M >= cfg->K) return fail(DFK_E_ARG, "minimizer_len must be in 8..16");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
