@@ -514,6 +514,7 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
     const uint32_t nseg = R.grid;
     uint64_t cap = P.n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
     if (R.inst_seen) cap = std::min<uint64_t>(cap, (uint64_t)(1.3 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
+    else cap = std::min<uint64_t>(cap, P.n_inst / 16 + (1u << 20));   // first pass: a prior (30x data: n_inst/15); too small -> redone
     const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
     // the dense part made afterwards needs room too: leave a third of what is left for it
     if (cap * 32 > room / 3 * 2) cap = room / 3 * 2 / 32;
@@ -665,16 +666,14 @@ uint32_t pick_passes(const dfk_ctx* c, uint64_t n_records, uint64_t n_inst)
         uint32_t l = 0; while ((1ull << l) < c->cfg.reserved[0]) ++l;
         return l;
     }
-    // one pass holds its records (32 B each) plus its output segments and dense part (~ n_inst/8 x 32 B x 2.3);
-    // finished parts of earlier passes stay resident.  Keep a pass's working set under ~40 % of what is free.
+    // One pass holds its records (32 B each), its output segments and its dense part; the parts of earlier
+    // passes stay resident.  The size of the dictionary is not known in advance (it is ~n_inst/15 entries at
+    // 30x, less at higher coverage), so the passes are sized from the records alone -- a pass's records may
+    // take a fifth of what is free -- and a run that still runs out of HBM is redone with twice the passes.
+    (void)n_inst;
     const uint64_t room = c->budget > c->held ? c->budget - c->held : 0;
-    const double solid_all = (double)n_inst / 12.0 * 32.0;           // guess at the final dictionary (30x data: n_inst/15 entries);
-                                                                     // a run that still runs out of HBM is redone with more passes
     uint32_t l = 0;
-    for (; l < 8; ++l) {
-        const double pass_ws = ((double)n_records * 32.0 + solid_all * 1.3) / (double)(1u << l);
-        if (pass_ws + solid_all < 0.9 * (double)room && pass_ws < 0.45 * (double)room) break;
-    }
+    while (l < 8 && (double)n_records * 32.0 / (double)(1u << l) > 0.2 * (double)room) ++l;
     return l;
 }
 
@@ -698,7 +697,16 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     for (uint32_t pass = 0; pass < (1u << log2_pass); ++pass) {
         Partition P;
         rc = partition_scatter<K>(c, in, T, 0, 0, log2_pass, pass, &P); if (rc) return rc;
-        rc = in.bc ? stage_count<K, true>(c, P, R) : stage_count<K, false>(c, P, R);
+        for (;;) {
+            rc = in.bc ? stage_count<K, true>(c, P, R) : stage_count<K, false>(c, P, R);
+            if (rc != E_SEGMENT_FULL || pass != 0 || c->seg_attempt >= 6) break;
+            // the first pass has nothing to unwind: clear the spectrum and counters and redo it with more room
+            ++c->seg_attempt;
+            TRACE("first pass: output segments too small, redoing it with twice the room");
+            HIP_TRY(hipMemsetAsync(R.d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
+            HIP_TRY(hipMemsetAsync(R.d_g.p, 0, sizeof(CountGlobals), c->stream));
+            c->st.n_items = 0; c->st.n_overflow_items = 0; c->st.ms_count = 0; c->st.ms_fallback = 0;
+        }
         if (rc) return rc;
         release_pass(c, &P);
     }
@@ -714,7 +722,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
 
 int run(dfk_ctx* c, const Inputs& in)
 {
-    c->extra_passes = 0;
+    // extra_passes is kept from earlier runs on this context: the same workload needs the same passes
     for (c->seg_attempt = 0;; ++c->seg_attempt) {
         int rc;
         switch (c->cfg.K) {
