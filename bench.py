@@ -9,12 +9,14 @@ read set that is already resident in HBM when the timed region starts.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload: BASELINE.json configs[1] is 30x human (~900 M pairs).  This round's pipeline keeps
-all super-k-mer records and the solid-set bound resident, which caps one GPU well below that;
-the default is therefore a SLICE of that configuration -- same read length, coverage, error
-rate, barcode structure and K, on a genome of --genome-mb (default 100 Mb, 1/31 of human) --
-and `config.workload` says so.  With N GPUs the genome and the read set grow N-fold (weak
-scaling): every rank samples the same number of pairs from the N-times larger genome.
+Workload = BASELINE.json configs[1]: synthetic human-scale stLFR, 900 M pairs of 2x100 bp over a
+3.1 Gb random genome (1.8 G reads, 8.8e10 k-mer instances, ~3.1e9 solid 48-mers), 0.5 % substitutions,
+10 % unbarcoded pairs, K=48, MIN_FREQ=3, MIN_BC=2, MIN_QUAL=7.  It is generated directly in HBM
+(torch, seeded) in ~20 s.  On one GPU the library counts it in hash-slice passes (the dictionary alone
+is 99 GB).  With N GPUs the SAME set is sharded by pair ranges (configs[2]; "scaling": "strong"): every
+rank generates and holds 900M/N pairs, records travel to the rank owning their minimizer bucket in one
+RCCL all-to-all per pass, and a second small exchange settles cross-rank adjacencies.
+--pairs / --genome-mb scale it down for quick runs.
 
 One JSON line on rank 0.  `roofline` is for the dominant kernel (k_count): algorithmic bytes
 = 64 B per k-mer instance (one 32-B sector read + one 32-B sector write of the
@@ -54,7 +56,7 @@ def profiled_traffic(n_inst):
         return None
     t = json.load(open(files[-1]))
     line = t.get("bench_line_under_profiler") or {}
-    if (line.get("counts") or {}).get("n_inst") != n_inst:
+    if (line.get("counts_rank0") or {}).get("n_inst") != n_inst:
         return None
     return t["hbm_bytes_per_launch"]
 
@@ -104,8 +106,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mb", type=float, default=100.0, help="genome size per GPU, Mb")
-    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--genome-mb", type=float, default=3100.0, help="genome size, Mb")
+    ap.add_argument("--pairs", type=int, default=900_000_000, help="read pairs in the whole set")
+    ap.add_argument("--coverage", type=float, default=0.0, help="if > 0: pairs = coverage * genome / 200")
     ap.add_argument("--passes", type=int, default=0, help="hash-slice passes (0 = sized from free HBM)")
     ap.add_argument("--K", type=int, default=48)
     ap.add_argument("--minimizer", type=int, default=0)
@@ -127,11 +130,17 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    G = int(args.genome_mb * 1e6) * world
-    pairs = int(args.coverage * args.genome_mb * 1e6 / 200.0)      # per GPU
-    genome = synth.make_genome(G, 20261004, device=dev)
-    rs = synth.make_reads(genome, pairs, 20261004 + 17 * (rank + 1))
+    G = int(args.genome_mb * 1e6)
+    total_pairs = int(args.coverage * G / 200.0) if args.coverage > 0 else args.pairs
+    lo, hi = rank * total_pairs // world, (rank + 1) * total_pairs // world          # this rank's pair range
+    genome = synth.make_genome(G, 20261004, device=dev)                               # same genome on every rank
+    rs = synth.make_reads(genome, hi - lo, 20261004 + 17 * (rank + 1))
     del genome
+    if world > 1:      # barcode ids must not collide between ranks
+        stride = int(rs.bc.max().item()) + 1
+        st = torch.tensor([stride], dtype=torch.int64, device=dev)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        rs.bc = torch.where(rs.bc > 0, rs.bc + rank * int(st.item()), rs.bc)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()          # the library sizes its HBM budget from what is free when the context is created
 
@@ -142,9 +151,9 @@ def main():
             return d.stats()
     else:
         from superplus_amd.dist import DistDfk
-        d = DistDfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item)
+        d = DistDfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes)
         def step():
-            d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc)
+            d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc, read_id0=2 * lo)
             return d.stats()
 
     def barrier():
@@ -174,25 +183,29 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         value = n_inst * args.steps / elapsed
         k_ms = st["ms_count"]
-        achieved = B_INST * st["n_inst"] / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        k_inst = n_inst // world                                   # instances this rank's k_count launches handled
+        achieved = B_INST * k_inst / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        full = G == 3_100_000_000 and total_pairs == 900_000_000
         out = {
             "metric": "k-mers/s (DF createDict stage: trim + canonical k-mer count + solid filter + spectrum + adjacency)",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"slice of BASELINE configs[1] (30x human stLFR): {args.coverage:g}x synthetic stLFR, "
-                                   f"genome {args.genome_mb:g} Mb per GPU, {pairs} pairs 2x100 bp per GPU, 0.5% subst., "
-                                   f"10% unbarcoded, K={args.K}, MIN_FREQ=3, MIN_BC=2, MIN_QUAL=7",
-                       "reads_per_gpu": rs.n_reads, "kmer_instances_total": n_inst, "K": args.K,
-                       "parallelism": "single GPU" if world == 1 else f"read shards x{world}, all-to-all by minimizer bucket"},
+            "config": {"workload": ("BASELINE configs[%d]: " % (1 if world == 1 else 2) if full else "scaled-down run: ") +
+                                   f"synthetic stLFR, {total_pairs} pairs 2x100 bp over a {args.genome_mb:g} Mb random genome "
+                                   f"({200.0 * total_pairs / G:.1f}x), 0.5% subst., 10% unbarcoded, K={args.K}, MIN_FREQ=3, MIN_BC=2, MIN_QUAL=7",
+                       "reads_total": 2 * total_pairs, "kmer_instances_total": n_inst, "K": args.K,
+                       "parallelism": "single GPU, hash-slice passes" if world == 1 else
+                                      f"{world} ranks: read shards, all-to-all of super-k-mer records by minimizer bucket"},
             "df_stage_wall_s": elapsed / args.steps,
-            "stage_ms": {k: round(st[k], 3) for k in ("ms_trim", "ms_part_count", "ms_part_scatter", "ms_count",
-                                                     "ms_fallback", "ms_adjacency", "ms_total")},
-            "counts": {k: st[k] for k in ("n_reads", "n_inst", "n_records", "n_buckets", "n_items", "n_overflow_items",
-                                          "n_distinct", "n_solid", "adj_probes", "hbm_bytes_peak", "n_passes")},
+            "stage_ms_rank0": {k: round(st[k], 3) for k in ("ms_trim", "ms_part_count", "ms_part_scatter", "ms_count",
+                                                           "ms_fallback", "ms_adjacency", "ms_total")},
+            "counts_rank0": {k: st[k] for k in ("n_reads", "n_inst", "n_records", "n_buckets", "n_items", "n_overflow_items",
+                                                "n_distinct", "n_solid", "adj_probes", "hbm_bytes_peak", "n_passes")},
             "roofline": {"bound": "hbm", "kernel": "k_count", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic(st["n_inst"]),
-                         "algorithmic_bytes_per_launch": B_INST * st["n_inst"], "kernel_ms": k_ms},
+                         "algorithmic_bytes_per_launch": B_INST * k_inst // max(1, st["n_passes"]),
+                         "kernel_ms_all_launches": k_ms, "launches_per_step": st["n_passes"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, args.K, args.cpu_sample_reads)

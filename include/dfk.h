@@ -149,10 +149,12 @@ int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
  *
  *   dfk_shard_begin       trim this rank's reads; returns its k-mer instance count
  *   <caller: all-reduce the instance counts so that every rank derives the same bucket count>
- *   dfk_shard_partition   kmerize into records grouped by destination rank
- *   <caller: all-to-all of send_counts, then of the record bytes, over RCCL/xGMI>
- *   dfk_shard_count       regroup the received records by fine bucket and count them: this
- *                         rank now holds the solid k-mers it owns, pre-adjacency
+ *   dfk_shard_plan        hash-slice passes this rank needs to fit its HBM (caller takes the max over ranks)
+ *   for pass in 0 .. 2^log2_passes - 1:
+ *     dfk_shard_partition   kmerize the pass's minimizer buckets into records grouped by destination rank
+ *     <caller: all-to-all of send_counts, then of the record bytes, over RCCL/xGMI>
+ *     dfk_shard_count       regroup the received records by fine bucket and count them; after the
+ *                           last pass this rank holds the solid k-mers it owns, pre-adjacency
  *   dfk_shard_adj_queries neighbour keys of the local solid k-mers, grouped by owner rank
  *   <caller: all-to-all of the 16-byte keys>
  *   dfk_shard_adj_answer  presence of each received key in the local solid set
@@ -168,9 +170,10 @@ int dfk_shard_begin(dfk_ctx* ctx,
               const void* d_pq_off, const void* d_bc, uint64_t n_reads,
               int64_t global_read_offset /* index of this shard's first read (ign_bc_below is global) */,
               uint64_t* n_inst_local);
-int dfk_shard_partition(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global,
+int dfk_shard_plan(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t* log2_passes);
+int dfk_shard_partition(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t log2_passes, uint32_t pass,
               const void** d_records, uint64_t* send_counts /* [world], in 32-byte records */);
-int dfk_shard_count(dfk_ctx* ctx, const void* d_records, uint64_t n_records);
+int dfk_shard_count(dfk_ctx* ctx, const void* d_records, uint64_t n_records, uint32_t pass);
 int dfk_shard_adj_queries(dfk_ctx* ctx, const void** d_keys,
               uint64_t* send_counts /* [world], in 16-byte keys */);
 int dfk_shard_adj_answer(dfk_ctx* ctx, const void* d_keys, uint64_t n_keys, void* d_present /* u8[n_keys] */);

@@ -32,6 +32,9 @@ struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
 };
 
+bool g_trace = getenv("DFK_TRACE") != nullptr;
+#define TRACE(...) do { if (g_trace) { fprintf(stderr, "[dfk] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
 // LDS table geometry per K (DESIGN.md "count kernel"): slots and waves per workgroup
 template <int K> struct CountCfg;
 #ifndef DFK_LOG2S
@@ -80,6 +83,8 @@ struct dfk_ctx {
     DevBuf adj_keys, adj_src; uint64_t adj_n = 0;
     DevBuf set; uint64_t set_mask = 0;
     uint32_t shard_world = 1, shard_log2_nb = 0;
+    void* shard_state = nullptr;              // bucket table + count state kept between the passes of a sharded run
+    void (*shard_state_free)(void*) = nullptr;
 
     // Device memory comes from a few large chunks that are kept for the life of the context and managed
     // by first-fit free lists with coalescing.  hipMalloc/hipFree of multi-GB blocks cost milliseconds to
@@ -89,8 +94,21 @@ struct dfk_ctx {
     std::vector<Chunk> chunks;
     uint64_t reserved = 0;                           // sum of chunk sizes
 
-    bool carve(Chunk& k, size_t bytes, DevBuf& b)
+    uint64_t first_chunk_hint = 0;                   // set from the input size before a run: one big chunk, no growth
+    // long-lived blocks (dictionary parts, goodLens, bucket counters) are carved from the top of a chunk,
+    // per-pass temporaries from the bottom, so that the two kinds do not fragment each other
+    bool carve(Chunk& k, size_t bytes, DevBuf& b, bool top)
     {
+        if (top) {
+            for (size_t i = k.free_list.size(); i-- > 0;)
+                if (k.free_list[i].bytes >= bytes) {
+                    k.free_list[i].bytes -= bytes;
+                    b.p = k.p + k.free_list[i].off + k.free_list[i].bytes; b.bytes = bytes;
+                    if (!k.free_list[i].bytes) k.free_list.erase(k.free_list.begin() + i);
+                    return true;
+                }
+            return false;
+        }
         for (size_t i = 0; i < k.free_list.size(); ++i)
             if (k.free_list[i].bytes >= bytes) {
                 b.p = k.p + k.free_list[i].off; b.bytes = bytes;
@@ -107,18 +125,21 @@ struct dfk_ctx {
             { (void)hipFree(chunks[i].p); reserved -= chunks[i].bytes; chunks.erase(chunks.begin() + i); }
             else ++i;
     }
-    int alloc(DevBuf& b, size_t bytes, const char* what)
+    int alloc(DevBuf& b, size_t bytes, const char* what, bool top = false)
     {
         bytes = bytes ? (bytes + 255) & ~(size_t)255 : 256;
         if (held + bytes > budget)
             return fail(DFK_E_NOMEM, "HBM budget exceeded allocating %zu bytes for %s (held %llu, budget %llu)",
                         bytes, what, (unsigned long long)held, (unsigned long long)budget);
         bool ok = false;
-        for (Chunk& k : chunks) if (carve(k, bytes, b)) { ok = true; break; }
+        for (Chunk& k : chunks) if (carve(k, bytes, b, top)) { ok = true; break; }
         if (!ok) {
-            // grow: twice the request (later requests reuse the slack), never past the budget
+            // grow: the first chunk is sized from the input (a run needs a few times its input), later ones
+            // twice the request (later requests reuse the slack); never past the budget
             uint64_t want = std::max<uint64_t>(2 * (uint64_t)bytes, 64ull << 20);
+            if (chunks.empty()) want = std::max<uint64_t>(want, std::min<uint64_t>(first_chunk_hint, budget));
             if (reserved + want > budget) { drop_empty_chunks(); want = std::min<uint64_t>(want, budget > reserved ? budget - reserved : 0); }
+            want &= ~(uint64_t)0xFFF;                  // blocks carved from the top of a chunk must stay aligned
             if (want < bytes) return fail(DFK_E_NOMEM, "HBM budget exhausted by fragmentation allocating %zu bytes for %s", bytes, what);
             void* p = nullptr;
             hipError_t e = hipMalloc(&p, want);
@@ -126,10 +147,12 @@ struct dfk_ctx {
             if (e != hipSuccess) return fail(DFK_E_NOMEM, "hipMalloc(%llu) for %s: %s", (unsigned long long)want, what, hipGetErrorString(e));
             chunks.push_back(Chunk{(char*)p, want, {Free{0, want}}});
             reserved += want;
-            carve(chunks.back(), bytes, b);
+            TRACE("new device chunk %p, %.2f GB (reserved %.2f of %.2f GB)", p, want / 1e9, (reserved) / 1e9, budget / 1e9);
+            carve(chunks.back(), bytes, b, top);
         }
         held += bytes; peak = std::max(peak, held);
         owned.push_back(b.p);
+        if (bytes >= (1ull << 30)) TRACE("alloc %-28s %8.2f GB at %p (%s), held %.2f GB", what, bytes / 1e9, b.p, top ? "top" : "bottom", held / 1e9);
         return 0;
     }
     void release(DevBuf& b)
@@ -164,6 +187,7 @@ struct dfk_ctx {
         good_len = shard_records = adj_keys = adj_src = set = DevBuf{};
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
         n_solid = 0; adj_n = 0; shard_open = false;
+        if (shard_state) { shard_state_free(shard_state); shard_state = nullptr; }
     }
 };
 
@@ -177,9 +201,6 @@ struct Timer {
     float stop() { (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 };
 
-bool g_trace = getenv("DFK_TRACE") != nullptr;
-#define TRACE(...) do { if (g_trace) { fprintf(stderr, "[dfk] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
-
 uint32_t ceil_log2(uint64_t v) { uint32_t b = 0; while ((1ull << b) < v) ++b; return b; }
 
 // ------------------------------------------------------------------ stage: trim (a1)
@@ -188,7 +209,7 @@ int stage_trim(dfk_ctx* c, const Inputs& in, uint64_t* n_inst)
 {
     DevBuf ctr; int rc = c->alloc(ctr, 32, "trim counters"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ctr.p, 0, 32, c->stream));
-    rc = c->alloc(c->good_len, sizeof(uint32_t) * in.n_reads, "goodLens"); if (rc) return rc;
+    rc = c->alloc(c->good_len, sizeof(uint32_t) * in.n_reads, "goodLens", true); if (rc) return rc;
     if (in.n_reads) {
         unsigned grid = (unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trim<K>), dim3(grid), dim3(256), 0, c->stream,
@@ -239,6 +260,7 @@ int device_scan(dfk_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n)
 struct BucketTable {
     uint32_t log2_nb = 0;                 // global
     DevBuf acc;                           // u64[nb] records<<32 | instances, global numbering
+    DevBuf read_mask;                     // u32[n_reads]: bucket classes (id & 31) each read has records in (multi-pass runs)
     uint64_t n_records = 0, n_inst = 0;
 };
 struct Partition {                        // one pass
@@ -274,7 +296,10 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
 {
     const PartParams pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 0);
     const uint64_t nb = 1ull << T->log2_nb;
-    int rc = c->alloc(T->acc, nb * 8, "bucket counters"); if (rc) return rc;
+    int rc = c->alloc(T->acc, nb * 8, "bucket counters", true); if (rc) return rc;
+    // per-read class masks let a hash-slice pass skip the reads that have nothing in it; worth 4 B/read
+    // only when there will be several passes (a set that needs them has >= 2^27 instances)
+    if (n_inst >= (1ull << 27) || c->cfg.reserved[0] > 1) { rc = c->alloc(T->read_mask, in.n_reads * 4, "read class masks", true); if (rc) return rc; }
     HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
     const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
     const size_t lds_a = sizeof(uint32_t) * pp.W * PART_THREADS;
@@ -284,7 +309,8 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p,
-                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint4*)nullptr);
+                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint4*)nullptr, (uint32_t*)T->read_mask.p,
+                           (const uint32_t*)nullptr, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     c->st.ms_part_count = t.stop();
     rc = table_totals(c, T->acc, nb, &T->n_records, &T->n_inst); if (rc) return rc;
@@ -350,17 +376,34 @@ int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32
     rc = c->alloc(cur, nb * 4, "bucket cursors"); if (rc) return rc;
     rc = c->alloc(P->records, P->n_records * 32, "super-k-mer records"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(cur.p, 0, nb * 4, c->stream));
-    const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
     const size_t lds_b = sizeof(uint32_t) * pp.W * PART_THREADS + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
     Timer t(c->stream);
     t.start();
+    // with several passes, first select the reads that have records in this one (class = bucket id & 31)
+    DevBuf list, d_nl; uint64_t n_work = in.n_reads;
+    if (log2_pass > 0 && T.read_mask.p && in.n_reads) {
+        uint32_t want = 0;
+        const uint32_t cm = (1u << std::min<uint32_t>(log2_pass, 5)) - 1;
+        for (uint32_t b = 0; b < 32; ++b) if ((b & cm) == (pass & cm)) want |= 1u << b;
+        rc = c->alloc(list, in.n_reads * 4, "pass read list"); if (rc) return rc;
+        rc = c->alloc(d_nl, 16, "pass read count"); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_nl.p, 0, 16, c->stream));
+        hipLaunchKernelGGL(k_select_reads, dim3((unsigned)((in.n_reads + 255) / 256)), dim3(256), 0, c->stream,
+                           (const uint32_t*)T.read_mask.p, in.n_reads, want, (uint32_t*)list.p, (unsigned long long*)d_nl.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&n_work, d_nl.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    const unsigned grid = (unsigned)((n_work + PART_THREADS - 1) / PART_THREADS);
     if (grid)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3(grid), dim3(PART_THREADS), lds_b, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr,
-                           (const uint64_t*)P->base.p, (uint32_t*)cur.p, (uint4*)P->records.p);
+                           (const uint64_t*)P->base.p, (uint32_t*)cur.p, (uint4*)P->records.p, (uint32_t*)nullptr,
+                           (const uint32_t*)list.p, n_work);
     HIP_TRY(hipGetLastError());
     c->st.ms_part_scatter += t.stop();
+    c->release(list); c->release(d_nl);
     TRACE("partition scatter pass %u/%u done (%llu records, %llu items)", pass + 1, 1u << log2_pass,
           (unsigned long long)P->n_records, (unsigned long long)P->n_items);
     c->release(cur);
@@ -380,8 +423,8 @@ struct CountRun {                     // device state shared by the count launch
 
 int count_run_begin(dfk_ctx* c, CountRun* R)
 {
-    int rc = c->alloc(R->d_hist, (uint64_t)HIST_GLOBAL_BINS * 8, "spectrum bins"); if (rc) return rc;
-    rc = c->alloc(R->d_g, sizeof(CountGlobals), "count globals"); if (rc) return rc;
+    int rc = c->alloc(R->d_hist, (uint64_t)HIST_GLOBAL_BINS * 8, "spectrum bins", true); if (rc) return rc;
+    rc = c->alloc(R->d_g, sizeof(CountGlobals), "count globals", true); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(R->d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
     HIP_TRY(hipMemsetAsync(R->d_g.p, 0, sizeof(CountGlobals), c->stream));
     R->g = (CountGlobals*)R->d_g.p; R->hist = (unsigned long long*)R->d_hist.p;
@@ -575,7 +618,7 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
     dfk_ctx::Part part;
     part.n = prefix[nseg] + hg.big_cursor;
     DevBuf d_prefix;
-    rc = c->alloc(part.buf, part.n * 32, "solid k-mer entries"); if (rc) return rc;
+    rc = c->alloc(part.buf, part.n * 32, "solid k-mer entries", true); if (rc) return rc;
     rc = c->alloc(d_prefix, 8ull * (nseg + 1), "segment prefix"); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_prefix.p, prefix.data(), 8ull * (nseg + 1), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_compact, dim3(8, nseg), dim3(256), 0, c->stream, (const uint4*)d_seg.p, seg_cap,
@@ -685,8 +728,10 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     Timer t(c->stream);
     uint64_t n_inst = 0;
     t.start();
+    TRACE("trim: %llu reads", (unsigned long long)in.n_reads);
     int rc = stage_trim<K>(c, in, &n_inst); if (rc) return rc;
     c->st.ms_trim = t.stop();
+    TRACE("trim done: %llu instances", (unsigned long long)n_inst);
     c->st.n_reads = in.n_reads; c->st.n_inst = n_inst; c->n_reads = in.n_reads;
     BucketTable T; T.log2_nb = pick_log2_nb(n_inst, 0);
     rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
@@ -710,7 +755,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         if (rc) return rc;
         release_pass(c, &P);
     }
-    c->release(T.acc);
+    c->release(T.acc); c->release(T.read_mask);
     c->st.reserved[0] = 1u << log2_pass;
     rc = count_run_end(c, &R); if (rc) return rc;
     rc = stage_adjacency<K>(c); if (rc) return rc;
@@ -825,6 +870,7 @@ int dfk_count_device(dfk_ctx* c, const void* d_packed, uint64_t packed_bytes, co
     HIP_TRY(hipSetDevice(c->device));
     c->release_all();
     c->st = dfk_stats{}; c->peak = 0;
+    c->first_chunk_hint = 8 * (packed_bytes + pq_nbytes + 28 * n_reads) + (1ull << 30);
     Inputs in{(const uint8_t*)d_packed, packed_bytes, (const uint64_t*)d_base_off, (const uint32_t*)d_read_len,
               (const uint8_t*)d_pq, pq_nbytes, (const uint64_t*)d_pq_off, (const int32_t*)d_bc, n_reads};
     int rc = run(c, in);

@@ -146,16 +146,21 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
             unsigned long long* __restrict__ bucket_acc,      // !WRITE: per fine bucket (records<<32 | instances)
             const uint64_t* __restrict__ bucket_base,         // WRITE: first record index of each fine bucket
             uint32_t* __restrict__ bucket_cur,                // WRITE: append cursors
-            uint4* __restrict__ records)
+            uint4* __restrict__ records,
+            uint32_t* __restrict__ read_mask,                 // !WRITE (optional): per read, which of 32 bucket classes it touches
+            const uint32_t* __restrict__ read_list,           // WRITE (optional): the reads this pass has records for
+            uint64_t n_list)
 {
     extern __shared__ uint32_t smem[];
     uint32_t* arr = smem;                                        // [W][PART_THREADS]
     uint32_t* queue = smem + pp.W * PART_THREADS;                // WRITE: [PART_QCAP][2][PART_THREADS]
     const int tid = threadIdx.x;
-    const uint64_t r = (uint64_t)blockIdx.x * PART_THREADS + tid;
+    uint64_t r = (uint64_t)blockIdx.x * PART_THREADS + tid;
+    if (WRITE && read_list) { if (r >= n_list) return; r = read_list[r]; }
     const uint32_t M = pp.M, W = pp.W;
     const uint32_t gl = r < n_reads ? good_len[r] : 0;
-    if (gl < (uint32_t)K + 1) return;                            // Kmerizer::map: len < K+1 emits nothing (:153)
+    if (gl < (uint32_t)K + 1) { if (!WRITE && read_mask && r < n_reads) read_mask[r] = 0; return; }   // Kmerizer::map: len < K+1 emits nothing (:153)
+    uint32_t classes = 0;
 
     const uint64_t byte0 = base_off[r];
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);   // hipMalloc'd: 4-byte aligned base
@@ -181,6 +186,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
         if (WRITE && cur_b == 0xFFFFFFFFu) return;                  // run belongs to another pass
         if (!WRITE) {
             atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
+            classes |= 1u << (cur_b & 31u);
         } else {
             if (qn == PART_QCAP) {        // rare: flush early
                 for (uint32_t e = 0; e < qn; ++e) {
@@ -235,6 +241,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
         }
     }
     close_run();
+    if (!WRITE && read_mask) read_mask[r] = classes;
     if (WRITE) {
         for (uint32_t e = 0; e < qn; ++e) {
             uint32_t a = queue[(2 * e) * PART_THREADS + tid], b = queue[(2 * e + 1) * PART_THREADS + tid];
@@ -983,6 +990,29 @@ k_regroup(const uint4* __restrict__ in, uint64_t n, uint32_t local_mask, unsigne
     }
 }
 
+
+// Reads that have at least one record in the current hash-slice pass (bucket id & 31 in `want`), in
+// (nearly) ascending order: lane-per-read work must be dense, so skipping is done by compaction.
+__global__ void __launch_bounds__(256)
+k_select_reads(const uint32_t* __restrict__ read_mask, uint64_t n_reads, uint32_t want, uint32_t* __restrict__ list,
+               unsigned long long* __restrict__ n_list)
+{
+    __shared__ unsigned long long base;
+    __shared__ uint32_t wcnt[4];
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool keep = r < n_reads && (read_mask[r] & want);
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]; base = t ? atomicAdd(n_list, (unsigned long long)t) : 0ull; }
+    __syncthreads();
+    if (keep) {
+        uint32_t off = 0;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        list[base + off + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)r;
+    }
+}
 
 // ============================================================================ device-side bucket tables
 // Everything that is O(number of fine buckets) stays on the GPU: a 30x human set has ~10^8 of them.

@@ -66,6 +66,11 @@ class TorchComm:
         self.dist.all_reduce(t, group=self.group)
         return int(t.item())
 
+    def all_reduce_max(self, value: int, device):
+        t = torch.tensor([value], dtype=torch.int64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
 
 def _view(ptr, nbytes, device):
     """A uint8 torch view of library-owned device memory (no copy)."""
@@ -97,14 +102,21 @@ class DistDfk(Dfk):
         self._device = packed.device
         return n.value
 
-    def partition(self, world, n_inst_global):
+    def plan(self, world, n_inst_global):
+        l = C.c_uint32()
+        _check(lib().dfk_shard_plan(self._ctx, C.c_uint32(world), C.c_uint64(n_inst_global), C.byref(l)))
+        return l.value
+
+    def partition(self, world, n_inst_global, log2_passes=0, pass_=0):
         ptr = C.c_void_p(); counts = (C.c_uint64 * world)()
-        _check(lib().dfk_shard_partition(self._ctx, C.c_uint32(world), C.c_uint64(n_inst_global), C.byref(ptr), counts))
+        _check(lib().dfk_shard_partition(self._ctx, C.c_uint32(world), C.c_uint64(n_inst_global), C.c_uint32(log2_passes),
+                                         C.c_uint32(pass_), C.byref(ptr), counts))
         counts = list(counts)
         return _view(ptr.value, 32 * sum(counts), self._device), counts
 
-    def count_records(self, recv):
-        _check(lib().dfk_shard_count(self._ctx, C.c_void_p(recv.data_ptr() if recv.numel() else 0), C.c_uint64(recv.numel() // 32)))
+    def count_records(self, recv, pass_=0):
+        _check(lib().dfk_shard_count(self._ctx, C.c_void_p(recv.data_ptr() if recv.numel() else 0), C.c_uint64(recv.numel() // 32),
+                                     C.c_uint32(pass_)))
 
     def adj_queries(self, world):
         ptr = C.c_void_p(); counts = (C.c_uint64 * world)()
@@ -132,10 +144,13 @@ class DistDfk(Dfk):
         if n_global == 0:
             raise _dfk.DfkError(-7, "Looks like your input data have almost no good bases.")
         self._n_inst_global = n_global
-        send, counts = self.partition(world, n_global)
-        recv, _ = exchange(send, counts, 32, comm)                        # the k-mer shuffle
-        self.count_records(recv)
-        del recv
+        log2_passes = comm.all_reduce_max(self.plan(world, n_global), packed.device)   # every rank runs the same passes
+        for p in range(1 << log2_passes):
+            send, counts = self.partition(world, n_global, log2_passes, p)
+            recv, _ = exchange(send, counts, 32, comm)                    # the k-mer shuffle, one hash slice at a time
+            del send
+            self.count_records(recv, p)
+            del recv
         keys, kcounts = self.adj_queries(world)
         rkeys, rcounts = exchange(keys, kcounts, 16, comm)                 # neighbour queries
         answers = self.adj_answer(rkeys)
@@ -172,12 +187,15 @@ def run_inprocess(ranks, shards):
     world = len(ranks)
     n_local = [ranks[r].begin(*shards[r]) for r in range(world)]
     n_global = sum(n_local)
-    sends = [ranks[r].partition(world, n_global) for r in range(world)]
-    recv, _ = _a2a([s[0] for s in sends], [s[1] for s in sends], 32)
-    recv = [x.clone() for x in recv]            # the send buffers are freed by count_records
-    for r in range(world):
-        ranks[r].count_records(recv[r])
-        ranks[r]._n_inst_global = n_global
+    log2_passes = max(ranks[r].plan(world, n_global) for r in range(world))
+    for p in range(1 << log2_passes):
+        sends = [ranks[r].partition(world, n_global, log2_passes, p) for r in range(world)]
+        recv, _ = _a2a([s[0] for s in sends], [s[1] for s in sends], 32)
+        recv = [x.clone() for x in recv]        # the send buffers are freed by count_records
+        del sends
+        for r in range(world):
+            ranks[r].count_records(recv[r], p)
+            ranks[r]._n_inst_global = n_global
     q = [ranks[r].adj_queries(world) for r in range(world)]
     rkeys, rcounts = _a2a([x[0] for x in q], [x[1] for x in q], 16)
     answers = [ranks[r].adj_answer(rkeys[r].contiguous()) for r in range(world)]

@@ -26,14 +26,14 @@ def _shards(rs, world, dev):
     return out
 
 
-@pytest.mark.parametrize("world,K,ign", [(2, 48, 0), (4, 48, 3000), (8, 60, 0), (2, 40, 0)])
-def test_sharded_equals_single(oracle, world, K, ign):
+@pytest.mark.parametrize("world,K,ign,passes", [(2, 48, 0, 0), (4, 48, 3000, 0), (8, 60, 0, 0), (2, 40, 0, 0), (2, 48, 0, 4), (4, 48, 0, 2)])
+def test_sharded_equals_single(oracle, world, K, ign, passes):
     from superplus_amd.dist import DistDfk, run_inprocess
     rs = util.make_set(51 + world, 80000, 9000)
     ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=K,
                      ign_bc_below=ign)
     dev = torch.device("cuda", 0)
-    ranks = [DistDfk(K=K, device=0, ign_bc_below=ign, keep_pre_adjacency=True) for _ in range(world)]
+    ranks = [DistDfk(K=K, device=0, ign_bc_below=ign, keep_pre_adjacency=True, passes=passes) for _ in range(world)]
     n_global = run_inprocess(ranks, _shards(rs, world, dev))
     assert n_global == ref["n_inst"]
     assert np.array_equal(np.concatenate([d.good_lens() for d in ranks]), ref["good_len"])

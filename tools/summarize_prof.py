@@ -50,16 +50,21 @@ with open(os.path.join(dst, f"{R}_hbm_counters.csv"), "w", newline="") as f:
         w.writerow([k, len(v["FETCH_SIZE"]), f"{fs:.1f}", f"{ws:.1f}", int(2 * fs * 1024), int(ws * 1024)])
 
 dom = [k for k in ctr if "k_count<" in k][0]
-fs = sum(ctr[dom]["FETCH_SIZE"]) / len(ctr[dom]["FETCH_SIZE"])
-ws = sum(ctr[dom]["WRITE_SIZE"]) / len(ctr[dom]["WRITE_SIZE"])
-avg_ns = [float(r["AverageNs"]) for r in stats if "k_count<" in r["Name"]][0]
 bench = [l for l in open(os.path.join(src, "bench_trace.log")) if l.startswith("{")]
-json.dump({"round": R, "kernel": dom, "avg_ns_rocprof": avg_ns,
-           "fetch_size_kib": fs, "write_size_kib": ws,
-           "hbm_bytes_per_launch": int(2 * fs * 1024 + ws * 1024),
+line = json.loads(bench[-1]) if bench else {}
+runs = int(line.get("steps", 3)) + int(line.get("warmup", 1))               # bench steps executed under the profiler
+passes = int((line.get("counts_rank0") or {}).get("n_passes", 1)) or 1
+# k_count is launched once per hash-slice pass (plus tiny relaunches for split items): total its traffic over the
+# whole run and divide by the number of main launches
+fs_tot, ws_tot = sum(ctr[dom]["FETCH_SIZE"]), sum(ctr[dom]["WRITE_SIZE"])
+main = runs * passes
+tot_ns = [float(r["TotalDurationNs"]) for r in stats if "k_count<" in r["Name"]][0]
+json.dump({"round": R, "kernel": dom, "main_launches": main, "avg_ns_per_main_launch_rocprof": tot_ns / main,
+           "fetch_size_kib_total": fs_tot, "write_size_kib_total": ws_tot,
+           "hbm_bytes_per_launch": int((2 * fs_tot + ws_tot) * 1024 / main),
            "correction": "read bytes = 2 x FETCH_SIZE KiB (gfx950, 16 B/lane coalesced stream); write bytes = WRITE_SIZE KiB",
            "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
-           "bench_line_under_profiler": json.loads(bench[-1]) if bench else None},
+           "bench_line_under_profiler": line or None},
           open(os.path.join(dst, f"{R}_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{R}_kernel_stats.csv")).read())
 print(open(os.path.join(dst, f"{R}_hbm_counters.csv")).read())
