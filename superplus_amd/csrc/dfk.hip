@@ -388,7 +388,7 @@ int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32
         rc = c->alloc(list, in.n_reads * 4, "pass read list"); if (rc) return rc;
         rc = c->alloc(d_nl, 16, "pass read count"); if (rc) return rc;
         HIP_TRY(hipMemsetAsync(d_nl.p, 0, 16, c->stream));
-        hipLaunchKernelGGL(k_select_reads, dim3((unsigned)((in.n_reads + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_select_reads, dim3((unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192)), dim3(256), 0, c->stream,
                            (const uint32_t*)T.read_mask.p, in.n_reads, want, (uint32_t*)list.p, (unsigned long long*)d_nl.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&n_work, d_nl.p, 8, hipMemcpyDeviceToHost, c->stream));

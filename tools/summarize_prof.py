@@ -28,7 +28,8 @@ def short(name):
     return name.split("(")[0]
 
 
-stats = list(csv.DictReader(open(glob.glob(src + "/trace/*/*_kernel_stats.csv")[0])))
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+stats = list(csv.DictReader(open(newest(src + "/trace/*/*_kernel_stats.csv"))))
 with open(os.path.join(dst, f"{R}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
@@ -38,7 +39,7 @@ with open(os.path.join(dst, f"{R}_kernel_stats.csv"), "w", newline="") as f:
 
 ctr = collections.defaultdict(lambda: collections.defaultdict(list))
 for which in ("fetch", "write"):
-    for r in csv.DictReader(open(glob.glob(src + f"/{which}/*/*_counter_collection.csv")[0])):
+    for r in csv.DictReader(open(newest(src + f"/{which}/*/*_counter_collection.csv"))):
         if "dfk::" in r["Kernel_Name"]:
             ctr[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(dst, f"{R}_hbm_counters.csv"), "w", newline="") as f:
