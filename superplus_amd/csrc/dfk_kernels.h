@@ -365,20 +365,34 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
     return ok;
 }
 
-// Rebuild instance q of a staged record and insert it.
+// One k-mer instance as read from the wave's staged chunk: header, barcode, the five payload words that
+// cover it, and its index inside the record.
+struct InstRegs { uint32_t hdr, tag, p0, p1, p2, p3, p4, q; };
+
+// LDS reads only (three dependent levels: mask/prefix -> run start -> record words); issued one iteration
+// ahead of the insertion that consumes them so that their latency overlaps the previous probe.
+template <int K>
+__device__ __forceinline__ InstRegs fetch_instance(const WaveStage<K>* __restrict__ st, uint32_t t)
+{
+    const uint32_t w = t >> 5;
+    const uint32_t bits = tld(&st->msk[w]) & (0xFFFFFFFFu >> (31u - (t & 31u)));
+    const uint32_t r = st->pc[w] + __popc(bits) - 1u;
+    const uint32_t q = t - st->starts[r];
+    const uint32_t* rec = st->rec + 8 * r;
+    const uint32_t* p = rec + 2 + (q >> 4);
+    return InstRegs{rec[0], rec[1], p[0], p[1], p[2], p[3], p[4], q};
+}
+
+// Rebuild the instance's canonical k-mer and context from the 2-bit stream and insert it.
 template <int K, bool USE_BC>
-__device__ __forceinline__ bool insert_instance(const uint32_t* __restrict__ rec /* 8 words of the record */, uint32_t q,
-                                                uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
+__device__ __forceinline__ bool insert_instance(const InstRegs& in, uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
                                                 uint32_t S, uint32_t* n_fill)
 {
-    const uint32_t hdr = rec[0];
-    const int32_t tag = (int32_t)rec[1];
+    const uint32_t hdr = in.hdr, q = in.q;
     const uint32_t nk = hdr & 63u;
     // bits [2q, 2q + 2(K+2)) of the payload: pred, K bases, succ
-    const uint32_t wi = q >> 4, sh = (2u * q) & 31u;
-    const uint32_t* p = rec + 2 + wi;
-    uint32_t p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
-    uint32_t x0 = alignbit(p1, p0, sh), x1 = alignbit(p2, p1, sh), x2 = alignbit(p3, p2, sh), x3 = alignbit(p4, p3, sh);
+    const uint32_t sh = (2u * q) & 31u;
+    uint32_t x0 = alignbit(in.p1, in.p0, sh), x1 = alignbit(in.p2, in.p1, sh), x2 = alignbit(in.p3, in.p2, sh), x3 = alignbit(in.p4, in.p3, sh);
     u128 X{(uint64_t)x0 | ((uint64_t)x1 << 32), (uint64_t)x2 | ((uint64_t)x3 << 32)};
     const uint32_t pred = x0 & 3u;
     u128 ks = shr128(X, 2);
@@ -391,7 +405,7 @@ __device__ __forceinline__ bool insert_instance(const uint32_t* __restrict__ rec
     if (q > 0 || (hdr & 64u)) ctx |= 0x10u << pred;
     if (q + 1 < nk || (hdr & 128u)) ctx |= 1u << succ;
     if (rev) ctx = ctx_rc(ctx);
-    return table_insert<KTraits<K>::KW, USE_BC>(keys, cnt, ctxs, bcw, S, c, ctx, tag, n_fill);
+    return table_insert<KTraits<K>::KW, USE_BC>(keys, cnt, ctxs, bcw, S, c, ctx, (int32_t)in.tag, n_fill);
 }
 
 // Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
@@ -420,12 +434,13 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     st->pc[lane] = wave_incl_scan(c0, lane) - c0;
     wave_sync();
     bool ok = true;
+    InstRegs cur{};
+    if ((uint32_t)lane < total) cur = fetch_instance<K>(st, lane);
     for (uint32_t t = lane; t < total; t += 64) {
-        const uint32_t w = t >> 5;
-        const uint32_t bits = tld(&st->msk[w]) & (0xFFFFFFFFu >> (31u - (t & 31u)));
-        const uint32_t r = st->pc[w] + __popc(bits) - 1u;
-        const uint32_t q = t - st->starts[r];
-        ok = insert_instance<K, USE_BC>(st->rec + 8 * r, q, keys, cnt, ctxs, bcw, S, n_fill) && ok;
+        InstRegs nxt{};
+        if (t + 64 < total) nxt = fetch_instance<K>(st, t + 64);     // software pipeline: next instance's LDS reads in flight
+        ok = insert_instance<K, USE_BC>(cur, keys, cnt, ctxs, bcw, S, n_fill) && ok;
+        cur = nxt;
     }
     if (!ok) atomicOr(overflow, 1u);
     wave_sync();

@@ -48,3 +48,24 @@ def test_sharded_equals_single(oracle, world, K, ign, passes):
         h = d.spectrum(); hist[: len(h)] += h
     assert np.array_equal(hist, ref["hist"])
     assert sum(d.stats()["n_distinct"] for d in ranks) == ref["n_distinct"]
+
+
+def test_rccl_path_single_rank(oracle):
+    """The real transport: torch.distributed with the nccl (= RCCL) backend, world size 1 on this GPU.
+    Exercises TorchComm, the zero-copy views of library buffers and all_to_all_single with byte splits."""
+    import os
+    import torch.distributed as dist
+    from superplus_amd.dist import DistDfk
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rs = util.make_set(71, 60000, 6000)
+        ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
+        d = DistDfk(K=48, device=0, passes=2)
+        d.count_device(*_shards(rs, 1, dev)[0][:6])
+        util.assert_same_solid(d.solid(), ref["solid"], "rccl world=1")
+        assert np.array_equal(d.spectrum(), ref["hist"])
+    finally:
+        dist.destroy_process_group()
