@@ -106,6 +106,10 @@ __device__ __forceinline__ uint32_t rec_header(uint32_t nk, bool hp, bool hs, ui
 { return nk | (hp ? 64u : 0u) | (hs ? 128u : 0u) | (bucket << 8); }
 
 constexpr uint32_t BCW_MULTI = 0x80000000u;   // barcode word: first barcode seen | MULTI once a second distinct one arrives
-constexpr uint32_t CNT_LOCK  = 0x80000000u;   // count word: slot being initialised
+// Count word of a table slot: fingerprint (8 bits, never 0) << 24 | count (24 bits).  0 = empty;
+// CNT_LOCK (fingerprint 0, count all ones: not a reachable state) = slot being initialised.
+constexpr uint32_t CNT_LOCK  = 0x00FFFFFFu;
+constexpr uint32_t CNT_MASK  = 0x00FFFFFFu;
+constexpr uint32_t CNT_NEAR_SAT = 0x00FFFF00u;  // above this the count is bumped by compare-and-swap so that it saturates exactly
 
 } // namespace dfk

@@ -303,66 +303,96 @@ __device__ __forceinline__ uint32_t tld(const uint32_t* p)
 __device__ __forceinline__ void tst(uint32_t* p, uint32_t v)
 { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// One insertion.  `c` = canonical 2K-bit value, ctx = context byte, tag = barcode.
-// Slot state lives in the count word: 0 = empty, CNT_LOCK = being initialised, else the count.
-// Returns false if the probe sequence got too long (table nearly full).
+// State of one key being inserted.  Slot state lives in the count word (see CNT_LOCK).  The 8-bit
+// fingerprint lets a probe skip a foreign slot on the value its CAS returned, without reading the key
+// words; the probe sequence is double hashing (odd step from the hash), which keeps the longest probe
+// of a wave short at 75 % load.
+struct Probe {
+    uint32_t k0, k1, k2, k3, ctx, fp, step, slot, probes, spins;
+    int32_t tag;
+    bool done, ok;
+};
+
+__device__ __forceinline__ Probe probe_begin(u128 c, uint32_t ctx, int32_t tag, uint32_t S, bool active)
+{
+    const uint32_t h = key_hash(c);
+    return Probe{(uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32), ctx, (h >> 24) | 1u,
+                 ((h >> 11) | 1u) & (S - 1), h & (S - 1), 0u, 0u, tag, !active, true};
+}
+
+// what a lane does with the value its CAS on cnt[slot] returned
+template <int KW, bool USE_BC>
+__device__ __forceinline__ void probe_step(Probe& P, bool won, uint32_t seen, uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
+                                           uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw, uint32_t S, uint32_t* n_fill)
+{
+    const uint32_t slot = P.slot;
+    if (won) {
+        tst(&keys[slot], P.k0); tst(&keys[S + slot], P.k1); tst(&keys[2 * S + slot], P.k2);
+        if (KW == 4) tst(&keys[3 * S + slot], P.k3);
+        tst(&ctxs[slot], P.ctx);
+        if (USE_BC) tst(&bcw[slot], P.tag > 0 ? (uint32_t)P.tag : (P.tag == -1 ? BCW_MULTI : 0u));
+        __hip_atomic_store(&cnt[slot], (P.fp << 24) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(n_fill, 1u);
+        P.done = true;
+    } else if (seen == CNT_LOCK) {
+        // another lane (or this lane's other key) is initialising the slot; it publishes inside its own
+        // iteration of the same loop, so try again -- a bounded number of times, so that every wave
+        // reaches the end of the kernel whatever happens
+        if (++P.spins > (1u << 20)) { P.ok = false; P.done = true; }
+    } else {
+        bool same = (seen >> 24) == P.fp;
+        if (same) {
+            same = tld(&keys[slot]) == P.k0 && tld(&keys[S + slot]) == P.k1 && tld(&keys[2 * S + slot]) == P.k2;
+            if (KW == 4) same = same && tld(&keys[3 * S + slot]) == P.k3;
+        }
+        if (same) {
+            if ((seen & CNT_MASK) < CNT_NEAR_SAT) atomicAdd(&cnt[slot], 1u);
+            else {                                                        // saturate exactly at 2^24-1 (KDef::setCount)
+                uint32_t cur = seen;
+                while ((cur & CNT_MASK) != CNT_MASK &&
+                       !__hip_atomic_compare_exchange_strong(&cnt[slot], &cur, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)) {}
+            }
+            if ((tld(&ctxs[slot]) & P.ctx) != P.ctx) atomicOr(&ctxs[slot], P.ctx);
+            if (USE_BC) {
+                uint32_t v = tld(&bcw[slot]);
+                if (!(v & BCW_MULTI)) {
+                    if (P.tag == -1) atomicOr(&bcw[slot], BCW_MULTI);
+                    else if (P.tag > 0) {
+                        uint32_t old = atomicCAS(&bcw[slot], 0u, (uint32_t)P.tag);
+                        if (old != 0u && old != (uint32_t)P.tag && !(old & BCW_MULTI)) atomicOr(&bcw[slot], BCW_MULTI);
+                    }
+                }
+            }
+            P.done = true;
+        } else {
+            P.slot = (slot + P.step) & (S - 1);
+            if (++P.probes > COUNT_MAX_PROBE) { P.ok = false; P.done = true; }
+        }
+    }
+}
+
+// Insert one key per lane.  (Two keys per lane in flight was tried and was slower: the loop is bound by
+// scalar/branch issue, not by LDS latency.)
+// The loop condition is wave-uniform (ballot) on purpose.  A lane that finds CNT_LOCK waits for the lane
+// initialising the slot, which may sit in the same wave.  With a per-lane `while (!done)` the compiler may
+// turn the winner's branch (it ends in the loop exit) into an exit block; the wave then runs it only after
+// every lane has left the loop and the waiters spin forever.  With the exit decided only at the header, the
+// winner's stores are inside the loop body.  Returns false if the probe sequence got too long.
 template <int KW, bool USE_BC>
 __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
                                              uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw,
-                                             uint32_t S, u128 c, uint32_t ctx, int32_t tag, uint32_t* n_fill)
+                                             uint32_t S, Probe& A, uint32_t* n_fill)
 {
-    const uint32_t k0 = (uint32_t)c.lo, k1 = (uint32_t)(c.lo >> 32), k2 = (uint32_t)c.hi, k3 = (uint32_t)(c.hi >> 32);
-    uint32_t slot = key_hash(c) & (S - 1);
-    uint32_t probes = 0;
-    bool done = false, ok = true;
-    uint32_t spins = 0;
-    // The loop condition is wave-uniform (ballot) on purpose.  A lane that finds CNT_LOCK waits for
-    // the lane initialising the slot, which may sit in the same wave.  With a per-lane `while (!done)`
-    // the compiler may turn the winner's branch (it ends in the loop exit) into an exit block; the
-    // wave then runs it only after every lane has left the loop and the waiters spin forever.  With
-    // the exit decided only at the header, the winner's stores are inside the loop body.
     do {
-      if (!done) {
-        uint32_t expect = 0;
-        bool won = __hip_atomic_compare_exchange_strong(&cnt[slot], &expect, CNT_LOCK, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-        if (won) {
-            tst(&keys[slot], k0); tst(&keys[S + slot], k1); tst(&keys[2 * S + slot], k2);
-            if (KW == 4) tst(&keys[3 * S + slot], k3);
-            tst(&ctxs[slot], ctx);
-            if (USE_BC) tst(&bcw[slot], tag > 0 ? (uint32_t)tag : (tag == -1 ? BCW_MULTI : 0u));
-            __hip_atomic_store(&cnt[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(n_fill, 1u);
-            done = true;
-        } else if (expect != CNT_LOCK) {
-            bool same = tld(&keys[slot]) == k0 && tld(&keys[S + slot]) == k1 && tld(&keys[2 * S + slot]) == k2;
-            if (KW == 4) same = same && tld(&keys[3 * S + slot]) == k3;
-            if (same) {
-                atomicAdd(&cnt[slot], 1u);
-                if ((tld(&ctxs[slot]) & ctx) != ctx) atomicOr(&ctxs[slot], ctx);
-                if (USE_BC) {
-                    uint32_t v = tld(&bcw[slot]);
-                    if (!(v & BCW_MULTI)) {
-                        if (tag == -1) atomicOr(&bcw[slot], BCW_MULTI);
-                        else if (tag > 0) {
-                            uint32_t old = atomicCAS(&bcw[slot], 0u, (uint32_t)tag);
-                            if (old != 0u && old != (uint32_t)tag && !(old & BCW_MULTI)) atomicOr(&bcw[slot], BCW_MULTI);
-                        }
-                    }
-                }
-                done = true;
-            } else {
-                slot = (slot + 1) & (S - 1);
-                if (++probes > COUNT_MAX_PROBE) { ok = false; done = true; }
-            }
+        if (!A.done) {
+            uint32_t ea = 0;
+            const bool wa = __hip_atomic_compare_exchange_strong(&cnt[A.slot], &ea, CNT_LOCK, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+            probe_step<KW, USE_BC>(A, wa, ea, keys, cnt, ctxs, bcw, S, n_fill);
         }
-        // expect == CNT_LOCK: another lane is initialising this slot; it finishes inside its own
-        // iteration of this same loop, so simply try the slot again -- a bounded number of times,
-        // so that every wave reaches the end of the kernel whatever happens.
-        else if (++spins > (1u << 20)) { ok = false; done = true; }
-      }
-    } while (__ballot(!done) != 0ull);
-    return ok;
+    } while (__ballot(!A.done) != 0ull);
+    return A.ok;
 }
 
 // One k-mer instance as read from the wave's staged chunk: header, barcode, the five payload words that
@@ -383,10 +413,9 @@ __device__ __forceinline__ InstRegs fetch_instance(const WaveStage<K>* __restric
     return InstRegs{rec[0], rec[1], p[0], p[1], p[2], p[3], p[4], q};
 }
 
-// Rebuild the instance's canonical k-mer and context from the 2-bit stream and insert it.
-template <int K, bool USE_BC>
-__device__ __forceinline__ bool insert_instance(const InstRegs& in, uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
-                                                uint32_t S, uint32_t* n_fill)
+// Rebuild the instance's canonical k-mer and context from the 2-bit stream.
+template <int K>
+__device__ __forceinline__ Probe make_probe(const InstRegs& in, uint32_t S, bool active)
 {
     const uint32_t hdr = in.hdr, q = in.q;
     const uint32_t nk = hdr & 63u;
@@ -405,7 +434,7 @@ __device__ __forceinline__ bool insert_instance(const InstRegs& in, uint32_t* ke
     if (q > 0 || (hdr & 64u)) ctx |= 0x10u << pred;
     if (q + 1 < nk || (hdr & 128u)) ctx |= 1u << succ;
     if (rev) ctx = ctx_rc(ctx);
-    return table_insert<KTraits<K>::KW, USE_BC>(keys, cnt, ctxs, bcw, S, c, ctx, (int32_t)in.tag, n_fill);
+    return probe_begin(c, ctx, (int32_t)in.tag, S, active);
 }
 
 // Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
@@ -434,13 +463,13 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     st->pc[lane] = wave_incl_scan(c0, lane) - c0;
     wave_sync();
     bool ok = true;
-    InstRegs cur{};
-    if ((uint32_t)lane < total) cur = fetch_instance<K>(st, lane);
     for (uint32_t t = lane; t < total; t += 64) {
-        InstRegs nxt{};
-        if (t + 64 < total) nxt = fetch_instance<K>(st, t + 64);     // software pipeline: next instance's LDS reads in flight
-        ok = insert_instance<K, USE_BC>(cur, keys, cnt, ctxs, bcw, S, n_fill) && ok;
-        cur = nxt;
+        Probe A = make_probe<K>(fetch_instance<K>(st, t), S, true);
+#ifdef DFK_ABLATE_INSERT        // timing experiment only: keep the extraction alive, skip the table
+        if ((A.k0 ^ A.k1 ^ A.ctx) == 0x12345u) atomicAdd(n_fill, 1u);
+#else
+        ok = table_insert<KTraits<K>::KW, USE_BC>(keys, cnt, ctxs, bcw, S, A, n_fill) && ok;
+#endif
     }
     if (!ok) atomicOr(overflow, 1u);
     wave_sync();
@@ -459,13 +488,19 @@ template <int KW>
 __device__ __forceinline__ uint32_t table_find(const uint32_t* keys, const uint32_t* cnt, uint32_t S, u128 c)
 {
     const uint32_t k0 = (uint32_t)c.lo, k1 = (uint32_t)(c.lo >> 32), k2 = (uint32_t)c.hi, k3 = (uint32_t)(c.hi >> 32);
-    uint32_t slot = key_hash(c) & (S - 1);
+    const uint32_t h = key_hash(c);
+    const uint32_t fp = (h >> 24) | 1u;
+    const uint32_t step = ((h >> 11) | 1u) & (S - 1);
+    uint32_t slot = h & (S - 1);
     for (uint32_t p = 0; p <= COUNT_MAX_PROBE + 1; ++p) {
-        if (tld(&cnt[slot]) == 0) return ~0u;
-        bool same = tld(&keys[slot]) == k0 && tld(&keys[S + slot]) == k1 && tld(&keys[2 * S + slot]) == k2;
-        if (KW == 4) same = same && tld(&keys[3 * S + slot]) == k3;
-        if (same) return slot;
-        slot = (slot + 1) & (S - 1);
+        const uint32_t cw = tld(&cnt[slot]);
+        if (cw == 0) return ~0u;
+        if ((cw >> 24) == fp) {
+            bool same = tld(&keys[slot]) == k0 && tld(&keys[S + slot]) == k1 && tld(&keys[2 * S + slot]) == k2;
+            if (KW == 4) same = same && tld(&keys[3 * S + slot]) == k3;
+            if (same) return slot;
+        }
+        slot = (slot + step) & (S - 1);
     }
     return ~0u;
 }
@@ -529,7 +564,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         const uint32_t c = tld(&cnt[slot]);
         if (!c) continue;
         ++n_occ;
-        const uint32_t count = c > 0xFFFFFFu ? 0xFFFFFFu : c;
+        const uint32_t count = c & CNT_MASK;                           // saturated at 2^24-1 by the insert (ReadPather.h:128-129)
         const bool solid = count >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&bcw[slot]) : 0u, cp.min_bc);
         if (solid && cp.do_adj) {
             const uint32_t ctx = tld(&ctxs[slot]) & 0xFFu;
@@ -583,7 +618,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         if (lane == 0) wbase = cursor32 ? (unsigned long long)atomicAdd(cursor32, n) : atomicAdd(cursor64, (unsigned long long)n);
         wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
         if (solid) {
-            const uint32_t count = c > 0xFFFFFFu ? 0xFFFFFFu : c;      // KDef::setCount saturation (ReadPather.h:128-129)
+            const uint32_t count = c & CNT_MASK;
             const uint32_t cw = tld(&ctxs[slot]);
             const uint32_t pending = flags & 0xFFu & cw;                // a bit cleared locally needs no further look-up
             boundary += pending != 0;
@@ -676,7 +711,14 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
             for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;         // abandon the table
             __syncthreads();                                           // everyone has read CTL_OVF before it is reset
         } else {
-            uint32_t occ = table_finish<K, USE_BC, true, S>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
+#ifdef DFK_ABLATE_FINISH        // timing experiment only: no solidity/adjacency/emit passes
+            for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;
+            uint32_t occ = 0;
+            if (false)
+#else
+            uint32_t occ =
+#endif
+            table_finish<K, USE_BC, true, S>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
                                                          &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
                                                          &ctl[CTL_BOUNDARY], tid, NT);
 #pragma unroll
