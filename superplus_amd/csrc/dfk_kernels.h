@@ -308,91 +308,102 @@ __device__ __forceinline__ void tst(uint32_t* p, uint32_t v)
 // words; the probe sequence is double hashing (odd step from the hash), which keeps the longest probe
 // of a wave short at 75 % load.
 struct Probe {
-    uint32_t k0, k1, k2, k3, ctx, fp, step, slot, probes, spins;
+    uint32_t k0, k1, k2, k3, ctx, fp, step, slot;
     int32_t tag;
-    bool done, ok;
+    bool active;
 };
 
 __device__ __forceinline__ Probe probe_begin(u128 c, uint32_t ctx, int32_t tag, uint32_t S, bool active)
 {
     const uint32_t h = key_hash(c);
     return Probe{(uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32), ctx, (h >> 24) | 1u,
-                 ((h >> 11) | 1u) & (S - 1), h & (S - 1), 0u, 0u, tag, !active, true};
+                 ((h >> 11) | 1u) & (S - 1), h & (S - 1), tag, active};
 }
 
-// what a lane does with the value its CAS on cnt[slot] returned
-template <int KW, bool USE_BC>
-__device__ __forceinline__ void probe_step(Probe& P, bool won, uint32_t seen, uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
-                                           uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw, uint32_t S, uint32_t* n_fill)
-{
-    const uint32_t slot = P.slot;
-    if (won) {
-        tst(&keys[slot], P.k0); tst(&keys[S + slot], P.k1); tst(&keys[2 * S + slot], P.k2);
-        if (KW == 4) tst(&keys[3 * S + slot], P.k3);
-        tst(&ctxs[slot], P.ctx);
-        if (USE_BC) tst(&bcw[slot], P.tag > 0 ? (uint32_t)P.tag : (P.tag == -1 ? BCW_MULTI : 0u));
-        __hip_atomic_store(&cnt[slot], (P.fp << 24) | 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(n_fill, 1u);
-        P.done = true;
-    } else if (seen == CNT_LOCK) {
-        // another lane (or this lane's other key) is initialising the slot; it publishes inside its own
-        // iteration of the same loop, so try again -- a bounded number of times, so that every wave
-        // reaches the end of the kernel whatever happens
-        if (++P.spins > (1u << 20)) { P.ok = false; P.done = true; }
-    } else {
-        bool same = (seen >> 24) == P.fp;
-        if (same) {
-            same = tld(&keys[slot]) == P.k0 && tld(&keys[S + slot]) == P.k1 && tld(&keys[2 * S + slot]) == P.k2;
-            if (KW == 4) same = same && tld(&keys[3 * S + slot]) == P.k3;
-        }
-        if (same) {
-            if ((seen & CNT_MASK) < CNT_NEAR_SAT) atomicAdd(&cnt[slot], 1u);
-            else {                                                        // saturate exactly at 2^24-1 (KDef::setCount)
-                uint32_t cur = seen;
-                while ((cur & CNT_MASK) != CNT_MASK &&
-                       !__hip_atomic_compare_exchange_strong(&cnt[slot], &cur, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT)) {}
-            }
-            if ((tld(&ctxs[slot]) & P.ctx) != P.ctx) atomicOr(&ctxs[slot], P.ctx);
-            if (USE_BC) {
-                uint32_t v = tld(&bcw[slot]);
-                if (!(v & BCW_MULTI)) {
-                    if (P.tag == -1) atomicOr(&bcw[slot], BCW_MULTI);
-                    else if (P.tag > 0) {
-                        uint32_t old = atomicCAS(&bcw[slot], 0u, (uint32_t)P.tag);
-                        if (old != 0u && old != (uint32_t)P.tag && !(old & BCW_MULTI)) atomicOr(&bcw[slot], BCW_MULTI);
-                    }
-                }
-            }
-            P.done = true;
-        } else {
-            P.slot = (slot + P.step) & (S - 1);
-            if (++P.probes > COUNT_MAX_PROBE) { P.ok = false; P.done = true; }
-        }
-    }
-}
-
-// Insert one key per lane.  (Two keys per lane in flight was tried and was slower: the loop is bound by
-// scalar/branch issue, not by LDS latency.)
+// Insert one key per lane: find or claim its slot (divergent loop), then count it (convergent).
+//
+// Loop body, per probe: CAS(cnt[slot], 0 -> CNT_LOCK) and, for the LDS table, the slot's key words in the
+// same batch of LDS operations -- the hardware runs a wave's LDS operations in order, so the key reads
+// see everything the slot's owner wrote before the count word the CAS returned (one round trip per probe
+// instead of two).  For the HBM table the reads follow the acquire.  A claimed slot gets its key words and
+// is published with count 0; its context and barcode words are zero already (every finish leaves the
+// table zeroed), so claimers and matchers do the same thing afterwards.
+//
 // The loop condition is wave-uniform (ballot) on purpose.  A lane that finds CNT_LOCK waits for the lane
 // initialising the slot, which may sit in the same wave.  With a per-lane `while (!done)` the compiler may
 // turn the winner's branch (it ends in the loop exit) into an exit block; the wave then runs it only after
 // every lane has left the loop and the waiters spin forever.  With the exit decided only at the header, the
-// winner's stores are inside the loop body.  Returns false if the probe sequence got too long.
-template <int KW, bool USE_BC>
+// winner's stores are inside the loop body.  Every spin is bounded, so every wave reaches the end of the
+// kernel whatever happens.  Returns false if the probe sequence got too long.
+// (Two keys per lane in flight was tried and was slower.)
+#define DFK_COMPILER_FENCE() asm volatile("" ::: "memory")
+
+// lane state in the probe loop
+enum : uint32_t { PS_PROBING = 0, PS_FOUND = 1, PS_FAILED = 2, PS_IDLE = 3 };
+// one counter bounds both the probe sequence (COUNT_MAX_PROBE steps) and the waits on a locked slot
+constexpr uint32_t PROBE_COST = 1u << 12, PROBE_LIMIT = (COUNT_MAX_PROBE + 1) * PROBE_COST;
+
+template <int KW, bool USE_BC, bool LDS_TABLE>
 __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
                                              uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw,
-                                             uint32_t S, Probe& A, uint32_t* n_fill)
+                                             uint32_t S, const Probe& A, uint32_t& n_claimed)
 {
-    do {
-        if (!A.done) {
-            uint32_t ea = 0;
-            const bool wa = __hip_atomic_compare_exchange_strong(&cnt[A.slot], &ea, CNT_LOCK, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
-                                                                 __HIP_MEMORY_SCOPE_AGENT);
-            probe_step<KW, USE_BC>(A, wa, ea, keys, cnt, ctxs, bcw, S, n_fill);
+    uint32_t state = A.active ? PS_PROBING : PS_IDLE, slot = A.slot, seen = 0, cost = 0;
+    while (__ballot(state == PS_PROBING) != 0ull) {
+        if (state == PS_PROBING) {
+            uint32_t e = 0, r0, r1, r2, r3 = A.k3;
+            if (LDS_TABLE) {
+                __hip_atomic_compare_exchange_strong(&cnt[slot], &e, CNT_LOCK, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                DFK_COMPILER_FENCE();
+                r0 = tld(&keys[slot]); r1 = tld(&keys[S + slot]); r2 = tld(&keys[2 * S + slot]);
+                if (KW == 4) r3 = tld(&keys[3 * S + slot]);
+            } else {
+                __hip_atomic_compare_exchange_strong(&cnt[slot], &e, CNT_LOCK, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                r0 = tld(&keys[slot]); r1 = tld(&keys[S + slot]); r2 = tld(&keys[2 * S + slot]);
+                if (KW == 4) r3 = tld(&keys[3 * S + slot]);
+            }
+            const bool won = e == 0u;                                    // the slot was empty and is ours now
+            if (won) {
+                tst(&keys[slot], A.k0); tst(&keys[S + slot], A.k1); tst(&keys[2 * S + slot], A.k2);
+                if (KW == 4) tst(&keys[3 * S + slot], A.k3);
+                if (LDS_TABLE) {
+                    DFK_COMPILER_FENCE();
+                    __hip_atomic_store(&cnt[slot], A.fp << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else __hip_atomic_store(&cnt[slot], A.fp << 24, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the rest is selects, no branches.  A locked slot (fingerprint 0) or an empty one never matches.
+            // (written as arithmetic on 0/1 words so that the compiler does not turn it back into control flow)
+            const uint32_t locked = e == CNT_LOCK;
+            const uint32_t match = ((e >> 24) == A.fp) & (r0 == A.k0) & (r1 == A.k1) & (r2 == A.k2) & (r3 == A.k3);
+            const uint32_t fin = (uint32_t)won | match;
+            n_claimed += (uint32_t)won;
+            seen |= e & (0u - match);                                    // 0 for the claimer
+            cost += PROBE_COST - (PROBE_COST - 1u) * locked;
+            slot = (slot + (A.step & ((fin | locked) - 1u))) & (S - 1);  // stay on a found or locked slot
+            state = fin | ((uint32_t)(cost >= PROBE_LIMIT) << 1);        // PS_FOUND, PS_FAILED or PS_PROBING
         }
-    } while (__ballot(!A.done) != 0ull);
-    return A.ok;
+    }
+    if (state == PS_FOUND) {
+        if ((seen & CNT_MASK) < CNT_NEAR_SAT) atomicAdd(&cnt[slot], 1u);
+        else {                                                            // saturate exactly at 2^24-1 (KDef::setCount)
+            uint32_t cur = tld(&cnt[slot]);
+            while ((cur & CNT_MASK) != CNT_MASK &&
+                   !__hip_atomic_compare_exchange_strong(&cnt[slot], &cur, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)) {}
+        }
+        atomicOr(&ctxs[slot], A.ctx);
+        if (USE_BC) {
+            // first barcode > 0 | BCW_MULTI once a second distinct one (or an ignored read, tag -1) arrives
+            if (A.tag == -1) atomicOr(&bcw[slot], BCW_MULTI);
+            else if (A.tag > 0) {
+                const uint32_t old = atomicCAS(&bcw[slot], 0u, (uint32_t)A.tag);
+                if (old != 0u && old != (uint32_t)A.tag && !(old & BCW_MULTI)) atomicOr(&bcw[slot], BCW_MULTI);
+            }
+        }
+    }
+    return state != PS_FAILED;
 }
 
 // One k-mer instance as read from the wave's staged chunk: header, barcode, the five payload words that
@@ -439,7 +450,7 @@ __device__ __forceinline__ Probe make_probe(const InstRegs& in, uint32_t S, bool
 
 // Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
 // block barriers).  Lanes load half a record each (1 KiB per wave, coalesced).
-template <int K, bool USE_BC>
+template <int K, bool USE_BC, bool LDS_TABLE>
 __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
                                                  WaveStage<K>* __restrict__ st, int lane,
                                                  uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
@@ -463,14 +474,20 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     st->pc[lane] = wave_incl_scan(c0, lane) - c0;
     wave_sync();
     bool ok = true;
-    for (uint32_t t = lane; t < total; t += 64) {
-        Probe A = make_probe<K>(fetch_instance<K>(st, t), S, true);
+    uint32_t n_claimed = 0;
+    const uint32_t total_u = __builtin_amdgcn_readfirstlane(total);     // scalar loop control
+    for (uint32_t t0 = 0; t0 < total_u; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        const Probe A = make_probe<K>(fetch_instance<K>(st, min(t, total_u - 1u)), S, t < total_u);
 #ifdef DFK_ABLATE_INSERT        // timing experiment only: keep the extraction alive, skip the table
-        if ((A.k0 ^ A.k1 ^ A.ctx) == 0x12345u) atomicAdd(n_fill, 1u);
+        if ((A.k0 ^ A.k1 ^ A.ctx) == 0x12345u) ++n_claimed;
 #else
-        ok = table_insert<KTraits<K>::KW, USE_BC>(keys, cnt, ctxs, bcw, S, A, n_fill) && ok;
+        ok = table_insert<KTraits<K>::KW, USE_BC, LDS_TABLE>(keys, cnt, ctxs, bcw, S, A, n_claimed) && ok;
 #endif
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_claimed += __shfl_down(n_claimed, d, 64);
+    if (lane == 0 && n_claimed) atomicAdd(n_fill, n_claimed);
     if (!ok) atomicOr(overflow, 1u);
     wave_sync();
 }
@@ -610,7 +627,8 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         const uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
         const uint32_t flags = c ? tld(&bcw[slot]) : 0u;
         const bool solid = (flags & FLAG_SOLID) != 0;
-        if (LDS_HIST && c) tst(&cnt[slot], 0u);                       // the LDS table is left empty for the next item
+        const uint32_t cw0 = (LDS_HIST && c) ? tld(&ctxs[slot]) : 0u;
+        if (LDS_HIST && c) { tst(&cnt[slot], 0u); tst(&ctxs[slot], 0u); tst(&bcw[slot], 0u); }   // the LDS table is left empty for the next item
         unsigned long long m = __ballot(solid);
         if (!m) continue;
         uint32_t n = __popcll(m);
@@ -619,7 +637,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
         if (solid) {
             const uint32_t count = c & CNT_MASK;
-            const uint32_t cw = tld(&ctxs[slot]);
+            const uint32_t cw = LDS_HIST ? cw0 : tld(&ctxs[slot]);
             const uint32_t pending = flags & 0xFFu & cw;                // a bit cleared locally needs no further look-up
             boundary += pending != 0;
             unsigned long long idx = wbase + __popcll(m & ((1ull << lane) - 1ull));
@@ -668,7 +686,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     uint4* seg_out = out + 2ull * cp.seg_cap * blockIdx.x;
 
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) hist[i] = 0;
-    for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;                 // slot state; the other words are written on claim
+    for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;             // count, context and barcode words; key words are written on claim
     // The item loop is software-pipelined: while the workgroup counts item i, thread 0 already holds the
     // ticket and the record range of item i+1 in registers (a returning global atomic plus a dependent
     // load are ~4 us of latency that every wave would otherwise wait for behind a barrier).
@@ -701,18 +719,18 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
             ci = __builtin_amdgcn_readfirstlane(ci);
             if (ci >= n_chunks) break;
             if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
-            wave_count_chunk<K, USE_BC>(records, rb + (uint64_t)ci * COUNT_CHUNK, re, st, lane, keys, cnt, ctxs, bcw, S,
+            wave_count_chunk<K, USE_BC, true>(records, rb + (uint64_t)ci * COUNT_CHUNK, re, st, lane, keys, cnt, ctxs, bcw, S,
                                         &ctl[CTL_FILL], &ctl[CTL_OVF]);
             if (lane == 0 && tld(&ctl[CTL_FILL]) > (S / 4) * 3) tst(&ctl[CTL_OVF], 1u);   // stop when 3/4 full
         }
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(ctl[CTL_OVF])) {
             if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = items[item];
-            for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;         // abandon the table
+            for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;     // abandon the table
             __syncthreads();                                           // everyone has read CTL_OVF before it is reset
         } else {
 #ifdef DFK_ABLATE_FINISH        // timing experiment only: no solidity/adjacency/emit passes
-            for (uint32_t i = tid; i < S; i += NT) cnt[i] = 0;
+            for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;
             uint32_t occ = 0;
             if (false)
 #else
@@ -774,7 +792,7 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     __syncthreads();
     const uint64_t rec_begin = rec_base[it.b0], rec_end = rec_base[it.b1];
     for (uint64_t c = rec_begin + (uint64_t)COUNT_CHUNK * wave; c < rec_end; c += (uint64_t)COUNT_CHUNK * NWAVES)
-        wave_count_chunk<K, USE_BC>(records, c, rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[CTL_FILL], &ctl[CTL_OVF]);
+        wave_count_chunk<K, USE_BC, false>(records, c, rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[CTL_FILL], &ctl[CTL_OVF]);
     __threadfence();
     __syncthreads();
     if (ctl[CTL_OVF]) { if (tid == 0) atomicOr(failed, 1u); return; }
