@@ -501,6 +501,7 @@ __device__ __forceinline__ bool bc_pass(uint32_t v, uint32_t min_bc)
 }
 
 // Look a canonical k-mer up in a finished table (no concurrent inserts).  Returns its slot or ~0.
+// One batch of reads per probe (count word and key words together), selects instead of branches.
 template <int KW>
 __device__ __forceinline__ uint32_t table_find(const uint32_t* keys, const uint32_t* cnt, uint32_t S, u128 c)
 {
@@ -508,18 +509,17 @@ __device__ __forceinline__ uint32_t table_find(const uint32_t* keys, const uint3
     const uint32_t h = key_hash(c);
     const uint32_t fp = (h >> 24) | 1u;
     const uint32_t step = ((h >> 11) | 1u) & (S - 1);
-    uint32_t slot = h & (S - 1);
-    for (uint32_t p = 0; p <= COUNT_MAX_PROBE + 1; ++p) {
+    uint32_t slot = h & (S - 1), found = ~0u, open = 1u;
+    for (uint32_t p = 0; p <= COUNT_MAX_PROBE + 1 && open; ++p) {
         const uint32_t cw = tld(&cnt[slot]);
-        if (cw == 0) return ~0u;
-        if ((cw >> 24) == fp) {
-            bool same = tld(&keys[slot]) == k0 && tld(&keys[S + slot]) == k1 && tld(&keys[2 * S + slot]) == k2;
-            if (KW == 4) same = same && tld(&keys[3 * S + slot]) == k3;
-            if (same) return slot;
-        }
+        const uint32_t r0 = tld(&keys[slot]), r1 = tld(&keys[S + slot]), r2 = tld(&keys[2 * S + slot]);
+        const uint32_t r3 = KW == 4 ? tld(&keys[3 * S + slot]) : k3;
+        const uint32_t match = (cw != 0u) & ((cw >> 24) == fp) & (r0 == k0) & (r1 == k1) & (r2 == k2) & (r3 == k3);
+        found = match ? slot : found;
+        open = (cw != 0u) & (match ^ 1u);
         slot = (slot + step) & (S - 1);
     }
-    return ~0u;
+    return found;
 }
 
 // canonical 2K-bit value of a k-mer given as a 2K-bit big-endian value
@@ -551,7 +551,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
                                                  unsigned long long* cursor64, uint32_t* cursor32, unsigned int* seg_overflow,
                                                  uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
                                                  uint32_t* tasks, uint32_t* n_tasks, uint32_t* n_boundary,
-                                                 int tid, int nthreads)
+                                                 uint16_t* solid_list, uint32_t* n_solid, int tid, int nthreads)
 {
     constexpr int KW = KTraits<K>::KW;
     const int lane = tid & 63;
@@ -583,6 +583,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         ++n_occ;
         const uint32_t count = c & CNT_MASK;                           // saturated at 2^24-1 by the insert (ReadPather.h:128-129)
         const bool solid = count >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&bcw[slot]) : 0u, cp.min_bc);
+        if (LDS_HIST && solid) solid_list[atomicAdd(n_solid, 1u)] = (uint16_t)slot;
         if (solid && cp.do_adj) {
             const uint32_t ctx = tld(&ctxs[slot]) & 0xFFu;
             if (cp.keep_pre) tst(&ctxs[slot], ctx | (ctx << 8));
@@ -622,35 +623,49 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
     }
     // ---- pass 3
     uint32_t boundary = 0;
-    for (uint32_t base = 0; base < S; base += nthreads) {
-        const uint32_t slot = base + tid;
-        const uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
-        const uint32_t flags = c ? tld(&bcw[slot]) : 0u;
-        const bool solid = (flags & FLAG_SOLID) != 0;
-        const uint32_t cw0 = (LDS_HIST && c) ? tld(&ctxs[slot]) : 0u;
-        if (LDS_HIST && c) { tst(&cnt[slot], 0u); tst(&ctxs[slot], 0u); tst(&bcw[slot], 0u); }   // the LDS table is left empty for the next item
-        unsigned long long m = __ballot(solid);
-        if (!m) continue;
-        uint32_t n = __popcll(m);
-        unsigned long long wbase = 0;
-        if (lane == 0) wbase = cursor32 ? (unsigned long long)atomicAdd(cursor32, n) : atomicAdd(cursor64, (unsigned long long)n);
-        wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
-        if (solid) {
-            const uint32_t count = c & CNT_MASK;
-            const uint32_t cw = LDS_HIST ? cw0 : tld(&ctxs[slot]);
-            const uint32_t pending = flags & 0xFFu & cw;                // a bit cleared locally needs no further look-up
-            boundary += pending != 0;
-            unsigned long long idx = wbase + __popcll(m & ((1ull << lane) - 1ull));
-            if (idx < cp.seg_cap) {
-                u128 v{(uint64_t)tld(&keys[slot]) | ((uint64_t)tld(&keys[S + slot]) << 32),
-                       (uint64_t)tld(&keys[2 * S + slot]) | (KW == 4 ? ((uint64_t)tld(&keys[3 * S + slot]) << 32) : 0ull)};
-                u128 kw = shl128(v, 128 - KTraits<K>::BITS);           // left-align: KMer<K> storage
-                seg_out[2 * idx] = uint4{(uint32_t)kw.hi, (uint32_t)(kw.hi >> 32), (uint32_t)kw.lo, (uint32_t)(kw.lo >> 32)};
-                // pad (word 3) carries the unresolved bits (and the original context for tests) until k_adjacency
-                seg_out[2 * idx + 1] = uint4{0xFFFFFFFFu, count | ((cw & 0xFFu) << 24), 0xFFFFFFFFu, pending | (cw & 0xFF00u)};
-            } else atomicOr(seg_overflow, 1u);
-            if (LDS_HIST && count < (uint32_t)COUNT_HIST_BINS) atomicAdd(&hist_lds[count], 1u);
-            else atomicAdd(&hist_global[count], 1ull);
+    auto emit = [&](uint32_t slot, uint32_t c, uint32_t flags, unsigned long long idx) {
+        const uint32_t count = c & CNT_MASK;
+        const uint32_t cw = tld(&ctxs[slot]);
+        const uint32_t pending = flags & 0xFFu & cw;                    // a bit cleared locally needs no further look-up
+        boundary += pending != 0;
+        if (idx < cp.seg_cap) {
+            u128 v{(uint64_t)tld(&keys[slot]) | ((uint64_t)tld(&keys[S + slot]) << 32),
+                   (uint64_t)tld(&keys[2 * S + slot]) | (KW == 4 ? ((uint64_t)tld(&keys[3 * S + slot]) << 32) : 0ull)};
+            u128 kw = shl128(v, 128 - KTraits<K>::BITS);               // left-align: KMer<K> storage
+            seg_out[2 * idx] = uint4{(uint32_t)kw.hi, (uint32_t)(kw.hi >> 32), (uint32_t)kw.lo, (uint32_t)(kw.lo >> 32)};
+            // pad (word 3) carries the unresolved bits (and the original context for tests) until k_adjacency
+            seg_out[2 * idx + 1] = uint4{0xFFFFFFFFu, count | ((cw & 0xFFu) << 24), 0xFFFFFFFFu, pending | (cw & 0xFF00u)};
+        } else atomicOr(seg_overflow, 1u);
+        if (LDS_HIST && count < (uint32_t)COUNT_HIST_BINS) atomicAdd(&hist_lds[count], 1u);
+        else atomicAdd(&hist_global[count], 1ull);
+    };
+    if constexpr (LDS_HIST) {
+        // LDS table: the solid slots were listed by pass 1, so the emit runs on dense lanes; the workgroup's
+        // segment cursor moves once; then the state words of the whole table are cleared with wide stores
+        // (key words are rewritten on claim).  cnt, ctxs and bcw are contiguous.
+        const uint32_t ns = __builtin_amdgcn_readfirstlane(tld(n_solid));
+        const uint32_t base = __builtin_amdgcn_readfirstlane(tld(cursor32));
+        for (uint32_t i = tid; i < ns; i += nthreads) {
+            const uint32_t slot = solid_list[i];
+            emit(slot, tld(&cnt[slot]), tld(&bcw[slot]), (unsigned long long)base + i);
+        }
+        __syncthreads();
+        if (tid == 0) { tst(cursor32, base + ns); tst(n_solid, 0u); }
+        uint4* z = reinterpret_cast<uint4*>(cnt);
+        for (uint32_t i = tid; i < 3 * S / 4; i += nthreads) z[i] = uint4{0, 0, 0, 0};
+    } else {
+        for (uint32_t base = 0; base < S; base += nthreads) {
+            const uint32_t slot = base + tid;
+            const uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
+            const uint32_t flags = c ? tld(&bcw[slot]) : 0u;
+            const bool solid = (flags & FLAG_SOLID) != 0;
+            unsigned long long m = __ballot(solid);
+            if (!m) continue;
+            uint32_t n = __popcll(m);
+            unsigned long long wbase = 0;
+            if (lane == 0) wbase = atomicAdd(cursor64, (unsigned long long)n);
+            wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
+            if (solid) emit(slot, c, flags, wbase + __popcll(m & ((1ull << lane) - 1ull)));
         }
     }
 #pragma unroll
@@ -661,7 +676,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
 
 // ctl words (LDS)
 enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_CURSOR = 4, CTL_DISTINCT = 5, CTL_NTASK = 6, CTL_BOUNDARY = 7,
-       CTL_RB_LO = 8, CTL_RB_HI = 9, CTL_RE_LO = 10, CTL_RE_HI = 11, CTL_N = 16 };
+       CTL_RB_LO = 8, CTL_RB_HI = 9, CTL_RE_LO = 10, CTL_RE_HI = 11, CTL_NSOLID = 12, CTL_N = 16 };
 
 template <int K, int LOG2S, int NWAVES, bool USE_BC>
 __global__ void __launch_bounds__(NWAVES * 64)
@@ -680,7 +695,8 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     uint32_t* hist = bcw + S;                       // [COUNT_HIST_BINS]
     uint32_t* ctl = hist + COUNT_HIST_BINS;         // [CTL_N]
     uint32_t* tasks = ctl + CTL_N;                  // [S] neighbour look-up queue
-    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(tasks + S);
+    uint16_t* solid_list = reinterpret_cast<uint16_t*>(tasks + S);     // [S] solid slots of the item being finished
+    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(tasks + S + S / 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WaveStage<K>* st = stages + wave;
     uint4* seg_out = out + 2ull * cp.seg_cap * blockIdx.x;
@@ -692,7 +708,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     // load are ~4 us of latency that every wave would otherwise wait for behind a barrier).
     if (tid == 0) {
         ctl[CTL_CURSOR] = seg_count[blockIdx.x]; ctl[CTL_DISTINCT] = 0; ctl[CTL_BOUNDARY] = 0;
-        ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0;
+        ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0; ctl[CTL_NSOLID] = 0;
         const uint32_t it0 = atomicAdd(&g->next_item, 1u);
         uint64_t b0 = 0, e0 = 0;
         if (it0 < cp.n_items) { b0 = rec_base[items[it0].b0]; e0 = rec_base[items[it0].b1]; }
@@ -738,7 +754,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
 #endif
             table_finish<K, USE_BC, true, S>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
                                                          &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
-                                                         &ctl[CTL_BOUNDARY], tid, NT);
+                                                         &ctl[CTL_BOUNDARY], solid_list, &ctl[CTL_NSOLID], tid, NT);
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
             if (lane == 0 && occ) atomicAdd(&ctl[CTL_DISTINCT], occ);
@@ -762,7 +778,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
 template <int K, int LOG2S, int NWAVES>
 constexpr size_t count_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + (1u << LOG2S)) + sizeof(WaveStage<K>) * NWAVES;
+    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + (1u << LOG2S) + (1u << LOG2S) / 2) + sizeof(WaveStage<K>) * NWAVES;
 }
 
 // Fallback: one workgroup per overflowed item, table in HBM (tab = [KW+3][S] words, zeroed by
@@ -799,7 +815,7 @@ k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items
     uint4* seg_out = out;                                             // the fallback's own buffer, cp.seg_cap entries
     uint32_t occ = table_finish<K, USE_BC, false, ADJ_TASKS_BIG>(keys, cnt, ctxs, bcw, S, cp, seg_out, &g->big_cursor, nullptr,
                                                   &g->solid_overflow, nullptr, hist_global, tasks, &ctl[CTL_NTASK],
-                                                  &ctl[CTL_BOUNDARY], tid, NT);
+                                                  &ctl[CTL_BOUNDARY], nullptr, nullptr, tid, NT);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
     if (lane == 0 && occ) atomicAdd(&g->n_distinct, (unsigned long long)occ);
