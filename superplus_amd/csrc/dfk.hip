@@ -260,7 +260,8 @@ int device_scan(dfk_ctx* c, const uint64_t* in, uint64_t* out, uint64_t n)
 struct BucketTable {
     uint32_t log2_nb = 0;                 // global
     DevBuf acc;                           // u64[nb] records<<32 | instances, global numbering
-    DevBuf read_mask;                     // u32[n_reads]: bucket classes (id & 31) each read has records in (multi-pass runs)
+    DevBuf summ;                          // uint4[n_reads]: run summaries (k_partition<K,false>), what the scatter passes work from
+    DevBuf ovf_list; uint64_t n_ovf = 0;  // reads with too many runs for a summary: scattered by scanning
     uint64_t n_records = 0, n_inst = 0;
 };
 struct Partition {                        // one pass
@@ -297,22 +298,40 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     const PartParams pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 0);
     const uint64_t nb = 1ull << T->log2_nb;
     int rc = c->alloc(T->acc, nb * 8, "bucket counters", true); if (rc) return rc;
-    // per-read class masks let a hash-slice pass skip the reads that have nothing in it; worth 4 B/read
-    // only when there will be several passes (a set that needs them has >= 2^27 instances)
-    if (n_inst >= (1ull << 27) || c->cfg.reserved[0] > 1) { rc = c->alloc(T->read_mask, in.n_reads * 4, "read class masks", true); if (rc) return rc; }
+    rc = c->alloc(T->summ, std::max<uint64_t>(1, in.n_reads) * 16, "run summaries", true); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
     const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
-    const size_t lds_a = sizeof(uint32_t) * pp.W * PART_THREADS;
+    const size_t lds_a = (sizeof(uint32_t) + 1) * pp.W * PART_THREADS + sizeof(uint16_t) * SUMMARY_RUNS * PART_THREADS;
     Timer t(c->stream);
     t.start();
     if (grid)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p,
-                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint4*)nullptr, (uint32_t*)T->read_mask.p,
+                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint4*)nullptr, (uint4*)T->summ.p,
                            (const uint32_t*)nullptr, (uint64_t)0);
     HIP_TRY(hipGetLastError());
+    // reads whose runs did not fit a summary
+    T->n_ovf = 0;
+    if (in.n_reads) {
+        DevBuf tmp, d_n;
+        rc = c->alloc(tmp, in.n_reads * 4, "overflow read list (scratch)"); if (rc) return rc;
+        rc = c->alloc(d_n, 16, "overflow read count"); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
+        hipLaunchKernelGGL(k_select_overflow, dim3((unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192)), dim3(256), 0, c->stream,
+                           (const uint4*)T->summ.p, in.n_reads, (uint32_t*)tmp.p, (unsigned long long*)d_n.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&T->n_ovf, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (T->n_ovf) {
+            rc = c->alloc(T->ovf_list, T->n_ovf * 4, "overflow read list", true); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(T->ovf_list.p, tmp.p, T->n_ovf * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        c->release(tmp); c->release(d_n);
+    }
     c->st.ms_part_count = t.stop();
+    TRACE("%llu of %llu reads have more than %d runs", (unsigned long long)T->n_ovf, (unsigned long long)in.n_reads, SUMMARY_RUNS);
     rc = table_totals(c, T->acc, nb, &T->n_records, &T->n_inst); if (rc) return rc;
     TRACE("partition count pass done (%llu buckets, %llu records)", (unsigned long long)nb, (unsigned long long)T->n_records);
     if (T->n_inst != n_inst)
@@ -379,31 +398,29 @@ int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32
     const size_t lds_b = sizeof(uint32_t) * pp.W * PART_THREADS + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
     Timer t(c->stream);
     t.start();
-    // with several passes, first select the reads that have records in this one (class = bucket id & 31)
-    DevBuf list, d_nl; uint64_t n_work = in.n_reads;
-    if (log2_pass > 0 && T.read_mask.p && in.n_reads) {
-        uint32_t want = 0;
-        const uint32_t cm = (1u << std::min<uint32_t>(log2_pass, 5)) - 1;
-        for (uint32_t b = 0; b < 32; ++b) if ((b & cm) == (pass & cm)) want |= 1u << b;
-        rc = c->alloc(list, in.n_reads * 4, "pass read list"); if (rc) return rc;
-        rc = c->alloc(d_nl, 16, "pass read count"); if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(d_nl.p, 0, 16, c->stream));
-        hipLaunchKernelGGL(k_select_reads, dim3((unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192)), dim3(256), 0, c->stream,
-                           (const uint32_t*)T.read_mask.p, in.n_reads, want, (uint32_t*)list.p, (unsigned long long*)d_nl.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&n_work, d_nl.p, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    const unsigned grid = (unsigned)((n_work + PART_THREADS - 1) / PART_THREADS);
-    if (grid)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3(grid), dim3(PART_THREADS), lds_b, c->stream,
+    DevBuf d_bad;
+    rc = c->alloc(d_bad, 16, "scatter check"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_bad.p, 0, 16, c->stream));
+    if (in.n_reads)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 255) / 256)), dim3(256), 0, c->stream,
+                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
+                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p,
+                           (const uint64_t*)P->base.p, (uint32_t*)cur.p, (uint4*)P->records.p, (unsigned int*)d_bad.p);
+    HIP_TRY(hipGetLastError());
+    // the few reads with more runs than a summary holds are scanned again
+    if (T.n_ovf)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3((unsigned)((T.n_ovf + PART_THREADS - 1) / PART_THREADS)),
+                           dim3(PART_THREADS), lds_b, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr,
-                           (const uint64_t*)P->base.p, (uint32_t*)cur.p, (uint4*)P->records.p, (uint32_t*)nullptr,
-                           (const uint32_t*)list.p, n_work);
+                           (const uint64_t*)P->base.p, (uint32_t*)cur.p, (uint4*)P->records.p, (uint4*)nullptr,
+                           (const uint32_t*)T.ovf_list.p, T.n_ovf);
     HIP_TRY(hipGetLastError());
+    unsigned int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, c->stream));
     c->st.ms_part_scatter += t.stop();
-    c->release(list); c->release(d_nl);
+    c->release(d_bad);
+    if (bad) return fail(DFK_E_HIP, "scatter: %u records fell outside their bucket (run summaries and bucket counters disagree)", bad);
     TRACE("partition scatter pass %u/%u done (%llu records, %llu items)", pass + 1, 1u << log2_pass,
           (unsigned long long)P->n_records, (unsigned long long)P->n_items);
     c->release(cur);
@@ -755,7 +772,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         if (rc) return rc;
         release_pass(c, &P);
     }
-    c->release(T.acc); c->release(T.read_mask);
+    c->release(T.acc); c->release(T.summ); c->release(T.ovf_list);
     c->st.reserved[0] = 1u << log2_pass;
     rc = count_run_end(c, &R); if (rc) return rc;
     rc = stage_adjacency<K>(c); if (rc) return rc;

@@ -102,6 +102,19 @@ struct PartParams {
 };
 
 constexpr int PART_THREADS = 256;
+// Per-read run summary written by the counting scan (16 bytes): bits 0-3 = number of runs (super-k-mers) or
+// SUMMARY_OVERFLOW, then from bit 8 twelve bits per run: nk (6) | offset of its minimizer from the run's
+// first k-mer (6, < W).  The scatter passes rebuild each run's bucket from the 2M bits at that offset
+// instead of scanning the read again.
+constexpr int SUMMARY_RUNS = 10;
+constexpr uint32_t SUMMARY_OVERFLOW = 15;
+
+// fine bucket of a minimizer hash: global id, owner-major (all fine buckets of one owner rank contiguous)
+__device__ __forceinline__ uint32_t bucket_of(uint32_t minhash, const PartParams& pp)
+{
+    const uint32_t b = (minhash * 0x9E3779B1u) >> (32 - pp.log2_nb);
+    return ((b & ((1u << pp.log2_world) - 1u)) << (pp.log2_nb - pp.log2_world)) | (b >> pp.log2_world);
+}
 constexpr int PART_QCAP = 8;          // queued records per lane before an early flush
 
 template <int K>
@@ -147,20 +160,22 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
             const uint64_t* __restrict__ bucket_base,         // WRITE: first record index of each fine bucket
             uint32_t* __restrict__ bucket_cur,                // WRITE: append cursors
             uint4* __restrict__ records,
-            uint32_t* __restrict__ read_mask,                 // !WRITE (optional): per read, which of 32 bucket classes it touches
-            const uint32_t* __restrict__ read_list,           // WRITE (optional): the reads this pass has records for
+            uint4* __restrict__ summaries,                    // !WRITE: per read, its runs (see RunSummary)
+            const uint32_t* __restrict__ read_list,           // WRITE (optional): the reads to process
             uint64_t n_list)
 {
     extern __shared__ uint32_t smem[];
-    uint32_t* arr = smem;                                        // [W][PART_THREADS]
+    uint32_t* arr = smem;                                        // [W][PART_THREADS] hashes -> suffix minima
     uint32_t* queue = smem + pp.W * PART_THREADS;                // WRITE: [PART_QCAP][2][PART_THREADS]
+    uint8_t* sidx = reinterpret_cast<uint8_t*>(smem + pp.W * PART_THREADS);              // !WRITE: [W][PART_THREADS] where each suffix minimum sits
+    uint16_t* rq = reinterpret_cast<uint16_t*>(sidx + pp.W * PART_THREADS);              // !WRITE: [SUMMARY_RUNS][PART_THREADS] run fields
     const int tid = threadIdx.x;
     uint64_t r = (uint64_t)blockIdx.x * PART_THREADS + tid;
     if (WRITE && read_list) { if (r >= n_list) return; r = read_list[r]; }
     const uint32_t M = pp.M, W = pp.W;
     const uint32_t gl = r < n_reads ? good_len[r] : 0;
-    if (gl < (uint32_t)K + 1) { if (!WRITE && read_mask && r < n_reads) read_mask[r] = 0; return; }   // Kmerizer::map: len < K+1 emits nothing (:153)
-    uint32_t classes = 0;
+    if (gl < (uint32_t)K + 1) { if (!WRITE && r < n_reads) summaries[r] = uint4{0, 0, 0, 0}; return; }   // Kmerizer::map: len < K+1 emits nothing (:153)
+    uint32_t Pi = 0, cur_rel = 0;                                // !WRITE: where the prefix minimum sits; minimizer offset of the open run
 
     const uint64_t byte0 = base_off[r];
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);   // hipMalloc'd: 4-byte aligned base
@@ -171,7 +186,6 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
 
     const uint32_t mmask = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * M)) - 1u);
     const uint32_t rsh = 2 * (M - 1);
-    const uint32_t bshift = 32 - pp.log2_nb;
     uint32_t f = 0, rc = 0;                 // forward / reverse-complement m-mer, big-endian
     uint32_t P = 0;                          // prefix minimum inside the current block
     uint32_t bi = 0;                         // index inside the current block of m-mer positions
@@ -186,7 +200,8 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
         if (WRITE && cur_b == 0xFFFFFFFFu) return;                  // run belongs to another pass
         if (!WRITE) {
             atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
-            classes |= 1u << (cur_b & 31u);
+            if (qn < (uint32_t)SUMMARY_RUNS) rq[qn * PART_THREADS + tid] = (uint16_t)(cur_nk | (cur_rel << 6));
+            ++qn;
         } else {
             if (qn == PART_QCAP) {        // rare: flush early
                 for (uint32_t e = 0; e < qn; ++e) {
@@ -210,43 +225,117 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
         rc = (rc >> 2) | ((3u - b) << rsh);
         if (j + 1 < M) continue;
         uint32_t h = mix32(f < rc ? f : rc);
-        P = bi == 0 ? h : (h < P ? h : P);
+        const bool newmin = bi == 0 || h < P;
+        P = newmin ? h : P;
+        if (!WRITE) Pi = newmin ? bi : Pi;
         const uint32_t t = j + 1 - M;                           // m-mer position
         if (t + 1 >= W) {                                        // k-mer s = t-W+1 is complete
             uint32_t mv = P;
-            if (bi != W - 1) { uint32_t sfx = arr[(bi + 1) * PART_THREADS + tid]; mv = sfx < mv ? sfx : mv; }
+            bool older = false;                                  // the minimum sits in the previous block
+            if (bi != W - 1) { uint32_t sfx = arr[(bi + 1) * PART_THREADS + tid]; older = sfx < mv; mv = older ? sfx : mv; }
             const uint32_t s = t + 1 - W;
-            uint32_t bucket = (mv * 0x9E3779B1u) >> bshift;
-            // owner-major position: all fine buckets of one owner rank are contiguous
-            bucket = ((bucket & ((1u << pp.log2_world) - 1u)) << (pp.log2_nb - pp.log2_world)) | (bucket >> pp.log2_world);
+            uint32_t bucket = bucket_of(mv, pp);
             if (WRITE) {                                          // hash-slice pass: foreign buckets become "no bucket"
                 const bool mine = (bucket & ((1u << pp.log2_pass) - 1u)) == pp.pass;
                 bucket = mine ? (bucket >> pp.log2_pass) : 0xFFFFFFFFu;
             }
-            if (s == 0) { cur_b = bucket; cur_s0 = 0; cur_nk = 1; }
-            else if (bucket != cur_b || cur_nk == (uint32_t)KTraits<K>::NK_MAX) {
-                close_run();
+            const bool open = s == 0 || bucket != cur_b || cur_nk == (uint32_t)KTraits<K>::NK_MAX;
+            if (open) {
+                if (s != 0) close_run();
                 cur_b = bucket; cur_s0 = s; cur_nk = 1;
+                // offset (from s) of an m-mer whose hash is the window minimum: block index i of the previous
+                // block is position s + i - bi - 1, index i of the current one is position s + W - 1 - bi + i
+                if (!WRITE) cur_rel = older ? (uint32_t)sidx[(bi + 1) * PART_THREADS + tid] - bi - 1u : W - 1u - bi + Pi;
             } else ++cur_nk;
         }
         arr[bi * PART_THREADS + tid] = h;
         if (++bi == W) {                                         // block complete: turn it into suffix minima
-            uint32_t run = h;
+            uint32_t run = h, ri = W - 1;
+            if (!WRITE) sidx[(W - 1) * PART_THREADS + tid] = (uint8_t)(W - 1);
             for (int i = (int)W - 2; i >= 0; --i) {
                 uint32_t v = arr[i * PART_THREADS + tid];
-                run = v < run ? v : run;
+                const bool lt = v < run;
+                run = lt ? v : run;
                 arr[i * PART_THREADS + tid] = run;
+                if (!WRITE) { ri = lt ? (uint32_t)i : ri; sidx[i * PART_THREADS + tid] = (uint8_t)ri; }
             }
             bi = 0;
         }
     }
     close_run();
-    if (!WRITE && read_mask) read_mask[r] = classes;
+    if (!WRITE) {
+        // pack the runs: bits 0-3 their number (SUMMARY_OVERFLOW: too many, the read goes through the scanning
+        // scatter), then 12 bits per run from bit 8
+        uint64_t lo = qn <= (uint32_t)SUMMARY_RUNS ? qn : SUMMARY_OVERFLOW, hi = 0;
+#pragma unroll
+        for (int i = 0; i < SUMMARY_RUNS; ++i) {
+            const uint64_t fld = (uint32_t)i < qn ? rq[i * PART_THREADS + tid] : 0u;
+            constexpr int B0 = 8;
+            const int b = B0 + 12 * i;
+            if (b + 12 <= 64) lo |= fld << b;
+            else if (b >= 64) hi |= fld << (b - 64);
+            else { lo |= fld << b; hi |= fld >> (64 - b); }
+        }
+        summaries[r] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+    }
     if (WRITE) {
         for (uint32_t e = 0; e < qn; ++e) {
             uint32_t a = queue[(2 * e) * PART_THREADS + tid], b = queue[(2 * e + 1) * PART_THREADS + tid];
             uint32_t slot = atomicAdd(&bucket_cur[b], 1u);
             emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, bucket_base[b] + slot, records);
+        }
+    }
+}
+
+// One hash-slice pass of the scatter, from the run summaries: a lane walks its read's runs, rebuilds each
+// run's bucket from the minimizer the summary points at (2M bits of the read, no scan), and writes the
+// records of the runs that belong to this pass.  `bad` counts records that would land outside their
+// bucket's range (summary and counters disagree: a bug, reported by the host, never written).
+template <int K>
+__global__ void __launch_bounds__(256)
+k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
+               const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
+               uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries,
+               const uint64_t* __restrict__ bucket_base, uint32_t* __restrict__ bucket_cur, uint4* __restrict__ records,
+               unsigned int* __restrict__ bad)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint4 sm = summaries[r];
+    const uint32_t n = sm.x & 15u;
+    if (n == 0 || n == SUMMARY_OVERFLOW) return;
+    const uint32_t gl = good_len[r];
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
+    const uint64_t n_words = (packed_bytes + 3) >> 2;
+    const uint64_t bit0 = base_off[r] * 8;
+    int32_t tag = -1;
+    if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
+    const uint32_t M = pp.M;
+    const uint32_t mmask = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * M)) - 1u);
+    const uint64_t lo = (uint64_t)sm.x | ((uint64_t)sm.y << 32), hi = (uint64_t)sm.z | ((uint64_t)sm.w << 32);
+    uint32_t s0 = 0;
+#pragma unroll
+    for (int i = 0; i < SUMMARY_RUNS; ++i) {
+        if ((uint32_t)i < n) {
+            constexpr int B0 = 8;
+            const int b = B0 + 12 * i;
+            const uint32_t fld = (uint32_t)(b + 12 <= 64 ? lo >> b : b >= 64 ? hi >> (b - 64) : (lo >> b) | (hi << (64 - b))) & 0xFFFu;
+            const uint32_t nk = fld & 63u, rel = fld >> 6;
+            const uint64_t bo = bit0 + 2ull * (s0 + rel);
+            const uint64_t wi = bo >> 5;
+            const uint32_t w0 = words[wi], w1 = wi + 1 < n_words ? words[wi + 1] : 0u;
+            const uint32_t x = alignbit(w1, w0, (uint32_t)bo & 31u) & mmask;     // the m-mer, first base in the low bits
+            uint32_t y = __brev(x);
+            y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+            const uint32_t f = y >> (32 - 2 * M), rcv = ~x & mmask;              // the scan's forward / reverse-complement values
+            const uint32_t bucket = bucket_of(mix32(f < rcv ? f : rcv), pp);
+            if ((bucket & ((1u << pp.log2_pass) - 1u)) == pp.pass) {
+                const uint32_t lb = bucket >> pp.log2_pass;
+                const uint64_t dst = bucket_base[lb] + atomicAdd(&bucket_cur[lb], 1u);
+                if (dst < bucket_base[lb + 1]) emit_record<K>(words, n_words, bit0, s0, nk, lb, gl, tag, dst, records);
+                else atomicAdd(bad, 1u);
+            }
+            s0 += nk;
         }
     }
 }
@@ -1082,31 +1171,33 @@ k_regroup(const uint4* __restrict__ in, uint64_t n, uint32_t local_mask, unsigne
 }
 
 
-// Reads that have at least one record in the current hash-slice pass (bucket id & 31 in `want`), in
-// (nearly) ascending order: lane-per-read work must be dense, so skipping is done by compaction.
+// Reads whose run summary overflowed (more than SUMMARY_RUNS runs), in ascending order: they go through the
+// scanning scatter, lane per read, so the list must be dense.
 __global__ void __launch_bounds__(256)
-k_select_reads(const uint32_t* __restrict__ read_mask, uint64_t n_reads, uint32_t want, uint32_t* __restrict__ list,
-               unsigned long long* __restrict__ n_list)
+k_select_overflow(const uint4* __restrict__ summaries, uint64_t n_reads, uint32_t* __restrict__ list,
+                  unsigned long long* __restrict__ n_list)
 {
     // each block owns one contiguous slice of the reads: count its keepers, reserve the range with ONE global
-    // atomic, then write them in order (one atomic per 256 reads on a single address cost 84 ms per pass)
+    // atomic, then write them in order (one atomic per 256 reads on a single address cost 84 ms)
     __shared__ unsigned long long base;
     __shared__ uint32_t wcnt[4];
+    const uint32_t* first = reinterpret_cast<const uint32_t*>(summaries);
     const uint64_t per = (n_reads + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n_reads ? lo + per : n_reads;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t mine = 0;
-    for (uint64_t r = lo + threadIdx.x; r < hi; r += blockDim.x) mine += (read_mask[r] & want) != 0;
+    for (uint64_t r = lo + threadIdx.x; r < hi; r += blockDim.x) mine += (first[4 * r] & 15u) == SUMMARY_OVERFLOW;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
     if (lane == 0) wcnt[wave] = mine;
     __syncthreads();
     if (threadIdx.x == 0) { uint32_t t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]; base = t ? atomicAdd(n_list, (unsigned long long)t) : 0ull; }
     __syncthreads();
+    if (wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3] == 0) return;             // the usual case: nothing to list (block-uniform)
     unsigned long long at = base;
     for (uint64_t r0 = lo; r0 < hi; r0 += blockDim.x) {
         const uint64_t r = r0 + threadIdx.x;
-        const bool keep = r < hi && (read_mask[r] & want);
+        const bool keep = r < hi && (first[4 * r] & 15u) == SUMMARY_OVERFLOW;
         const unsigned long long m = __ballot(keep);
         __syncthreads();
         if (lane == 0) wcnt[wave] = __popcll(m);
