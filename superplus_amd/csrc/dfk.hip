@@ -60,7 +60,9 @@ struct dfk_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
     uint64_t budget = 0, held = 0, peak = 0;
-    std::vector<void*> owned;                 // everything hipMalloc'd by this context for the current run
+    struct Owned { void* p; uint64_t bytes, seq; };
+    std::vector<Owned> owned;                 // live blocks of the arena, in allocation order
+    uint64_t alloc_seq = 0;
     // results of the last run
     bool have = false;
     uint64_t n_reads = 0;
@@ -69,7 +71,7 @@ struct dfk_ctx {
     std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
     unsigned seg_attempt = 0;                 // output segments are sized (estimate << seg_attempt)
-    unsigned extra_passes = 0;                // log2 of additional hash-slice passes after a run ran out of HBM
+    double plan_derate = 0.95;                // share of the free HBM a pass is planned into; lowered when a pass ran out (kept across runs)
     std::vector<int64_t> hist;
     std::vector<dfk_entry32> sorted, sorted_pre;
     bool sorted_ok = false, sorted_pre_ok = false;
@@ -151,14 +153,14 @@ struct dfk_ctx {
             carve(chunks.back(), bytes, b, top);
         }
         held += bytes; peak = std::max(peak, held);
-        owned.push_back(b.p);
+        owned.push_back(Owned{b.p, (uint64_t)bytes, ++alloc_seq});
         if (bytes >= (1ull << 30)) TRACE("alloc %-28s %8.2f GB at %p (%s), held %.2f GB", what, bytes / 1e9, b.p, top ? "top" : "bottom", held / 1e9);
         return 0;
     }
     void release(DevBuf& b)
     {
         if (!b.p) return;
-        auto it = std::find(owned.begin(), owned.end(), b.p);
+        auto it = std::find_if(owned.begin(), owned.end(), [&](const Owned& o) { return o.p == b.p; });
         if (it != owned.end()) owned.erase(it);
         for (Chunk& k : chunks)
             if ((char*)b.p >= k.p && (char*)b.p < k.p + k.bytes) {
@@ -172,6 +174,13 @@ struct dfk_ctx {
                 break;
             }
         held -= b.bytes; b.p = nullptr; b.bytes = 0;
+    }
+    // give back everything allocated after `mark` (= alloc_seq at some earlier moment): what an abandoned
+    // pass left behind.  The DevBufs that pointed at those blocks are dead; the caller resets them.
+    void release_since(uint64_t mark)
+    {
+        for (size_t i = owned.size(); i-- > 0;)
+            if (owned[i].seq > mark) { DevBuf b; b.p = owned[i].p; b.bytes = owned[i].bytes; release(b); }
     }
     void drop_pool() { for (Chunk& k : chunks) (void)hipFree(k.p); chunks.clear(); reserved = 0; }
     void release_all()
@@ -267,14 +276,14 @@ struct BucketTable {
 struct Partition {                        // one pass
     DevBuf records, base, ipre, items;    // records; u64 base[nb+1] (first record of each bucket); u64 ipre[nb+1]
     uint64_t n_records = 0, n_inst = 0, n_items = 0;   //   (instance prefix); ItemRange items[n_items]
-    uint32_t log2_nb = 0;                 // local (this pass)
+    uint64_t nb = 0;                      // fine buckets of this pass (world * sub_n)
 };
 
 template <int K>
-PartParams part_params(const dfk_ctx* c, uint32_t log2_nb, uint32_t log2_world, int64_t read_id0, uint32_t log2_pass, uint32_t pass)
+PartParams part_params(const dfk_ctx* c, uint32_t log2_nb, uint32_t log2_world, int64_t read_id0, uint32_t sub_lo, uint32_t sub_n)
 {
     const uint32_t M = c->cfg.minimizer_len;
-    return PartParams{M, (uint32_t)K - M + 1, log2_nb, log2_world, read_id0, log2_pass, pass};
+    return PartParams{M, (uint32_t)K - M + 1, log2_nb, log2_world, read_id0, sub_lo, sub_n};
 }
 
 // totals of a counter table (records, instances)
@@ -295,7 +304,7 @@ int table_totals(dfk_ctx* c, const DevBuf& acc, uint64_t nb, uint64_t* n_records
 template <int K>
 int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, BucketTable* T)
 {
-    const PartParams pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 0);
+    const PartParams pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 1u << (T->log2_nb - log2_world));
     const uint64_t nb = 1ull << T->log2_nb;
     int rc = c->alloc(T->acc, nb * 8, "bucket counters", true); if (rc) return rc;
     rc = c->alloc(T->summ, std::max<uint64_t>(1, in.n_reads) * 16, "run summaries", true); if (rc) return rc;
@@ -308,7 +317,7 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p,
-                           (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint4*)nullptr, (uint4*)T->summ.p,
+                           (unsigned long long*)nullptr, (uint64_t)0, (uint4*)nullptr, (uint4*)T->summ.p,
                            (const uint32_t*)nullptr, (uint64_t)0);
     HIP_TRY(hipGetLastError());
     // reads whose runs did not fit a summary
@@ -342,17 +351,17 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
 }
 
 // base[], ipre[] and the work items of one pass, all on the device
-int pass_tables(dfk_ctx* c, const DevBuf& acc, uint32_t log2_nb_global, uint32_t log2_pass, uint32_t pass, uint64_t budget, Partition* P)
+int pass_tables(dfk_ctx* c, const DevBuf& acc, uint32_t log2_sub, uint32_t world, uint32_t sub_lo, uint32_t sub_n, uint64_t budget, Partition* P)
 {
-    P->log2_nb = log2_nb_global - log2_pass;
-    const uint64_t nb = 1ull << P->log2_nb;
+    P->nb = (uint64_t)world * sub_n;
+    const uint64_t nb = P->nb;
     DevBuf rec, inst, flags, idx;
     int rc = c->alloc(rec, (nb + 1) * 8, "bucket record counts"); if (rc) return rc;
     rc = c->alloc(inst, (nb + 1) * 8, "bucket instance counts"); if (rc) return rc;
     rc = c->alloc(P->base, (nb + 1) * 8, "bucket bases"); if (rc) return rc;
     rc = c->alloc(P->ipre, (nb + 1) * 8, "bucket instance prefix"); if (rc) return rc;
     const unsigned g1 = (unsigned)((nb + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_slice, dim3(g1), dim3(256), 0, c->stream, (const unsigned long long*)acc.p, log2_pass, pass, nb,
+    hipLaunchKernelGGL(k_slice, dim3(g1), dim3(256), 0, c->stream, (const unsigned long long*)acc.p, log2_sub, sub_lo, sub_n, nb,
                        (uint64_t*)rec.p, (uint64_t*)inst.p);
     HIP_TRY(hipGetLastError());
     rc = device_scan(c, (const uint64_t*)rec.p, (uint64_t*)P->base.p, nb + 1); if (rc) return rc;
@@ -385,27 +394,26 @@ template <int K> constexpr uint64_t default_item_budget() { return (3ull << Coun
 
 template <int K>
 int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0,
-                      uint32_t log2_pass, uint32_t pass, Partition* P)
+                      uint32_t sub_lo, uint32_t sub_n, Partition* P)
 {
-    const PartParams pp = part_params<K>(c, T.log2_nb, log2_world, read_id0, log2_pass, pass);
+    const PartParams pp = part_params<K>(c, T.log2_nb, log2_world, read_id0, sub_lo, sub_n);
     const uint64_t budget = c->cfg.inst_per_item ? c->cfg.inst_per_item : default_item_budget<K>();
-    int rc = pass_tables(c, T.acc, T.log2_nb, log2_pass, pass, budget, P); if (rc) return rc;
-    const uint64_t nb = 1ull << P->log2_nb;
-    DevBuf cur;
-    rc = c->alloc(cur, nb * 4, "bucket cursors"); if (rc) return rc;
+    int rc = pass_tables(c, T.acc, T.log2_nb - log2_world, 1u << log2_world, sub_lo, sub_n, budget, P); if (rc) return rc;
+    const uint64_t nb = P->nb;
+    DevBuf cur, d_bad;
+    rc = c->alloc(cur, nb * 8, "bucket cursors"); if (rc) return rc;
     rc = c->alloc(P->records, P->n_records * 32, "super-k-mer records"); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(cur.p, 0, nb * 4, c->stream));
+    rc = c->alloc(d_bad, 16, "scatter check"); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(cur.p, P->base.p, nb * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_bad.p, 0, 16, c->stream));
     const size_t lds_b = sizeof(uint32_t) * pp.W * PART_THREADS + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
     Timer t(c->stream);
     t.start();
-    DevBuf d_bad;
-    rc = c->alloc(d_bad, 16, "scatter check"); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(d_bad.p, 0, 16, c->stream));
     if (in.n_reads)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 255) / 256)), dim3(256), 0, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p,
-                           (const uint64_t*)P->base.p, (uint32_t*)cur.p, (uint4*)P->records.p, (unsigned int*)d_bad.p);
+                           (unsigned long long*)cur.p, P->n_records, (uint4*)P->records.p);
     HIP_TRY(hipGetLastError());
     // the few reads with more runs than a summary holds are scanned again
     if (T.n_ovf)
@@ -413,15 +421,18 @@ int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32
                            dim3(PART_THREADS), lds_b, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr,
-                           (const uint64_t*)P->base.p, (uint32_t*)cur.p, (uint4*)P->records.p, (uint4*)nullptr,
+                           (unsigned long long*)cur.p, P->n_records, (uint4*)P->records.p, (uint4*)nullptr,
                            (const uint32_t*)T.ovf_list.p, T.n_ovf);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, (const unsigned long long*)cur.p,
+                       (const uint64_t*)P->base.p, nb, (unsigned int*)d_bad.p);
     HIP_TRY(hipGetLastError());
     unsigned int bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, c->stream));
     c->st.ms_part_scatter += t.stop();
     c->release(d_bad);
-    if (bad) return fail(DFK_E_HIP, "scatter: %u records fell outside their bucket (run summaries and bucket counters disagree)", bad);
-    TRACE("partition scatter pass %u/%u done (%llu records, %llu items)", pass + 1, 1u << log2_pass,
+    if (bad) return fail(DFK_E_HIP, "scatter: %u buckets did not receive the records counted for them (run summaries and bucket counters disagree)", bad);
+    TRACE("scatter of buckets [%u, %u) done (%llu records, %llu items)", sub_lo, sub_lo + sub_n,
           (unsigned long long)P->n_records, (unsigned long long)P->n_items);
     c->release(cur);
     return 0;
@@ -435,6 +446,7 @@ struct CountRun {                     // device state shared by the count launch
     CountParams cp{}; unsigned grid = 0;
     DevBuf big; uint64_t big_cap = 0;  // output of the HBM-table fallback (its own buffer)
     DevBuf d_hist, d_g;                // spectrum bins and counters: live across the passes of one run
+    DevBuf d_snap;                     // their state before the current pass (a pass that runs out of room is undone and redone)
     uint64_t solid_seen = 0, inst_seen = 0;   // totals of the passes done so far (sizes the next pass's output)
 };
 
@@ -445,6 +457,20 @@ int count_run_begin(dfk_ctx* c, CountRun* R)
     HIP_TRY(hipMemsetAsync(R->d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
     HIP_TRY(hipMemsetAsync(R->d_g.p, 0, sizeof(CountGlobals), c->stream));
     R->g = (CountGlobals*)R->d_g.p; R->hist = (unsigned long long*)R->d_hist.p;
+    return c->alloc(R->d_snap, (uint64_t)HIST_GLOBAL_BINS * 8 + 256, "spectrum snapshot", true);
+}
+
+int count_snapshot(dfk_ctx* c, CountRun* R, bool restore)
+{
+    char* snap = (char*)R->d_snap.p;
+    const uint64_t hb = (uint64_t)HIST_GLOBAL_BINS * 8;
+    if (!restore) {
+        HIP_TRY(hipMemcpyAsync(snap, R->d_hist.p, hb, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(snap + hb, R->d_g.p, sizeof(CountGlobals), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(R->d_hist.p, snap, hb, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(R->d_g.p, snap + hb, sizeof(CountGlobals), hipMemcpyDeviceToDevice, c->stream));
+    }
     return 0;
 }
 
@@ -454,6 +480,17 @@ int count_run_end(dfk_ctx* c, CountRun* R)
     CountGlobals hg{};
     HIP_TRY(hipMemcpy(&hg, R->d_g.p, sizeof hg, hipMemcpyDeviceToHost));
     c->st.n_distinct = hg.n_distinct; c->n_boundary = hg.n_boundary;
+#ifdef DFK_PROBE_STATS
+    {
+        unsigned long long ps[4] = {};
+        (void)hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_probe_stats), sizeof ps);
+        fprintf(stderr, "[dfk] probe stats: %.2f loop iterations per batch, %.3f probes and %.3f lock waits per instance (%llu batches)\n",
+                (double)ps[0] / (double)std::max(1ull, ps[1]), (double)ps[2] / (64.0 * std::max(1ull, ps[1])),
+                (double)ps[3] / (64.0 * std::max(1ull, ps[1])), ps[1]);
+        unsigned long long z[4] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_probe_stats), z, sizeof z);
+    }
+#endif
     DevBuf d_max; int rc = c->alloc(d_max, 16, "max bin"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_max.p, 0, 16, c->stream));
     hipLaunchKernelGGL(k_hist_max, dim3(1024), dim3(256), 0, c->stream, (const unsigned long long*)R->d_hist.p, HIST_GLOBAL_BINS,
@@ -464,7 +501,7 @@ int count_run_end(dfk_ctx* c, CountRun* R)
     c->hist.assign(nb, 0);
     if (nb) HIP_TRY(hipMemcpy(c->hist.data(), R->d_hist.p, 8ull * nb, hipMemcpyDeviceToHost));
     TRACE("spectrum read back: %u bins, %llu solid", nb, (unsigned long long)c->n_solid);
-    c->release(d_max); c->release(R->d_hist); c->release(R->d_g);
+    c->release(d_max); c->release(R->d_hist); c->release(R->d_g); c->release(R->d_snap);
     return 0;
 }
 
@@ -720,21 +757,25 @@ uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
     return std::min<uint32_t>(l, log2_world ? 24 + log2_world : 28);
 }
 
-uint32_t pick_passes(const dfk_ctx* c, uint64_t n_records, uint64_t n_inst)
+// How many fine buckets the next pass may take, from what is free now.  A pass holds its bucket tables, its
+// records (32 B each), its output segments and, at the end, its dense part of the dictionary; the parts of
+// earlier passes stay resident, so later passes are smaller.  Buckets are hash-distributed, so a range holds
+// its share of the records and instances to within a fraction of a percent.
+uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, uint32_t sub_nb, uint32_t lo)
 {
-    if (c->cfg.reserved[0]) {                                        // dfk_config.reserved[0] = forced number of passes (tests)
-        uint32_t l = 0; while ((1ull << l) < c->cfg.reserved[0]) ++l;
-        return l;
-    }
-    // One pass holds its records (32 B each), its output segments and its dense part; the parts of earlier
-    // passes stay resident.  The size of the dictionary is not known in advance (it is ~n_inst/15 entries at
-    // 30x, less at higher coverage), so the passes are sized from the records alone -- a pass's records may
-    // take a fifth of what is free -- and a run that still runs out of HBM is redone with twice the passes.
-    (void)n_inst;
-    const uint64_t room = c->budget > c->held ? c->budget - c->held : 0;
-    uint32_t l = 0;
-    while (l < 8 && (double)n_records * 32.0 / (double)(1u << l) > 0.2 * (double)room) ++l;
-    return l;
+    const double room = c->budget > c->held ? (double)(c->budget - c->held) : 0.0;
+    const double inst_per = (double)T.n_inst / sub_nb, rec_per = (double)T.n_records / sub_nb;
+    // solid k-mers per instance: observed on the passes done so far, else the prior stage_count starts from
+    double ratio = R.inst_seen ? 1.3 * (double)R.solid_seen / (double)R.inst_seen : 1.0 / 16.0;
+    ratio = std::min(ratio, 1.0 / std::max<uint32_t>(1, c->cfg.min_freq));
+    const double per_bucket = 60.0 + 32.0 * rec_per + 32.0 * ratio * inst_per * (1.25 * (double)(1u << c->seg_attempt) + 1.0);
+    const double fixed = 300e6;                                       // segment slack (8192 entries each), small tables
+    const double fit = room > fixed ? (room - fixed) / per_bucket : 0.0, left = (double)(sub_nb - lo);
+    double n = c->plan_derate * fit;
+    if (left <= 0.99 * fit && left < 1.06 * n) n = left;              // no sliver of a last pass if the rest (almost certainly) fits
+    else if (left > n && left < 1.3 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big and a small one
+    n = std::max(16.0, std::min(n, left));
+    return (uint32_t)n;
 }
 
 template <int K>
@@ -752,28 +793,45 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     c->st.n_reads = in.n_reads; c->st.n_inst = n_inst; c->n_reads = in.n_reads;
     BucketTable T; T.log2_nb = pick_log2_nb(n_inst, 0);
     rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
-    const uint32_t log2_pass = std::min<uint32_t>(pick_passes(c, T.n_records, n_inst) + c->extra_passes, T.log2_nb > 4 ? T.log2_nb - 4 : 0);
-    TRACE("%llu instances, %llu records, %u pass(es)", (unsigned long long)n_inst, (unsigned long long)T.n_records, 1u << log2_pass);
     CountRun R;
     rc = count_run_begin(c, &R); if (rc) return rc;
-    for (uint32_t pass = 0; pass < (1u << log2_pass); ++pass) {
+    // Passes over contiguous ranges of the fine buckets, each as large as the free HBM allows.  A pass that
+    // runs out of room (its estimate of the solid k-mers was too low) is undone and redone smaller.
+    const uint32_t sub_nb = 1u << T.log2_nb;
+    const uint32_t forced = (uint32_t)c->cfg.reserved[0];            // dfk_config.reserved[0] = forced number of passes (tests)
+    const uint32_t per_forced = forced ? std::max<uint32_t>(1, (sub_nb + forced - 1) / forced) : 0;
+    uint32_t lo = 0, n_passes = 0, retries = 0;
+    c->seg_attempt = 0;
+    while (lo < sub_nb) {
+        const uint32_t n = forced ? std::min(per_forced, sub_nb - lo) : plan_range(c, T, R, sub_nb, lo);
+        TRACE("pass %u: buckets [%u, %u) of %u (%.1f %%), %.2f GB held of %.2f", n_passes + 1, lo, lo + n, sub_nb, 100.0 * n / sub_nb,
+              c->held / 1e9, c->budget / 1e9);
+        const uint64_t mark = c->alloc_seq;
+        const dfk_stats st0 = c->st;
+        rc = count_snapshot(c, &R, false); if (rc) return rc;
         Partition P;
-        rc = partition_scatter<K>(c, in, T, 0, 0, log2_pass, pass, &P); if (rc) return rc;
-        for (;;) {
-            rc = in.bc ? stage_count<K, true>(c, P, R) : stage_count<K, false>(c, P, R);
-            if (rc != E_SEGMENT_FULL || pass != 0 || c->seg_attempt >= 6) break;
-            // the first pass has nothing to unwind: clear the spectrum and counters and redo it with more room
-            ++c->seg_attempt;
-            TRACE("first pass: output segments too small, redoing it with twice the room");
-            HIP_TRY(hipMemsetAsync(R.d_hist.p, 0, (uint64_t)HIST_GLOBAL_BINS * 8, c->stream));
-            HIP_TRY(hipMemsetAsync(R.d_g.p, 0, sizeof(CountGlobals), c->stream));
-            c->st.n_items = 0; c->st.n_overflow_items = 0; c->st.ms_count = 0; c->st.ms_fallback = 0;
+        rc = partition_scatter<K>(c, in, T, 0, 0, lo, n, &P);
+        if (!rc) rc = in.bc ? stage_count<K, true>(c, P, R) : stage_count<K, false>(c, P, R);
+        if (rc == DFK_E_NOMEM || rc == E_SEGMENT_FULL) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->release_since(mark);
+            int rc2 = count_snapshot(c, &R, true); if (rc2) return rc2;
+            const float ms_scatter = c->st.ms_part_scatter, ms_count = c->st.ms_count, ms_fb = c->st.ms_fallback;
+            c->st = st0;                                              // the time spent stays on the books
+            c->st.ms_part_scatter = ms_scatter; c->st.ms_count = ms_count; c->st.ms_fallback = ms_fb;
+            if (++retries > 12) return DFK_E_NOMEM;
+            if (rc == E_SEGMENT_FULL) { ++c->seg_attempt; TRACE("output segments too small: redoing the pass with twice the room"); }
+            else if (forced || n <= 16) return rc;
+            else { c->plan_derate *= 0.7; TRACE("out of HBM (%s): redoing the pass smaller", g_err.c_str()); }
+            continue;
         }
         if (rc) return rc;
         release_pass(c, &P);
+        lo += n; ++n_passes;
+        c->seg_attempt = 0;                                           // later passes size their output from the observed ratio
     }
     c->release(T.acc); c->release(T.summ); c->release(T.ovf_list);
-    c->st.reserved[0] = 1u << log2_pass;
+    c->st.reserved[0] = n_passes;
     rc = count_run_end(c, &R); if (rc) return rc;
     rc = stage_adjacency<K>(c); if (rc) return rc;
     c->st.ms_total = total.stop();
@@ -784,28 +842,14 @@ int run_typed(dfk_ctx* c, const Inputs& in)
 
 int run(dfk_ctx* c, const Inputs& in)
 {
-    // extra_passes is kept from earlier runs on this context: the same workload needs the same passes
-    for (c->seg_attempt = 0;; ++c->seg_attempt) {
-        int rc;
-        switch (c->cfg.K) {
-        case 40: rc = run_typed<40>(c, in); break;
-        case 48: rc = run_typed<48>(c, in); break;
-        case 60: rc = run_typed<60>(c, in); break;
-        default: return fail(DFK_E_ARG, "K must be 40, 48 or 60");
-        }
-        if (rc == DFK_E_NOMEM && !c->cfg.reserved[0] && c->extra_passes < 6) {
-            // the working set of a pass did not fit beside the dictionary built so far: halve the passes' size
-            ++c->extra_passes; --c->seg_attempt;
-            TRACE("out of HBM (%s): redoing the run with twice the passes", g_err.c_str());
-            c->release_all(); c->st = dfk_stats{};
-            continue;
-        }
-        if (rc != E_SEGMENT_FULL) return rc;
-        // the spectrum and counters of the failed attempt cannot be unwound: start over with twice the room
-        if (c->seg_attempt >= 4) return DFK_E_NOMEM;
-        TRACE("output segment full: redoing the run with larger segments");
-        c->release_all(); c->st = dfk_stats{};
+    int rc;
+    switch (c->cfg.K) {
+    case 40: rc = run_typed<40>(c, in); break;
+    case 48: rc = run_typed<48>(c, in); break;
+    case 60: rc = run_typed<60>(c, in); break;
+    default: return fail(DFK_E_ARG, "K must be 40, 48 or 60");
     }
+    return rc == E_SEGMENT_FULL ? DFK_E_NOMEM : rc;
 }
 
 int fetch_sorted(dfk_ctx* c, bool pre, std::vector<dfk_entry32>** out)

@@ -97,8 +97,8 @@ struct PartParams {
     uint32_t log2_nb;      // fine buckets = 1 << log2_nb
     uint32_t log2_world;   // fine buckets are laid out owner-major: owner rank = bucket & (world-1)
     int64_t  read_id0;     // global index of this shard's first read (ignBcBelow compares global read ids)
-    uint32_t log2_pass;    // hash-slice passes: this launch keeps fine buckets with (id & (P-1)) == pass ...
-    uint32_t pass;         // ... and numbers them id >> log2_pass (WRITE launches only; the count launch sees all)
+    uint32_t sub_lo;       // pass: fine buckets whose rank-local id (global id without the owner bits) is in
+    uint32_t sub_n;        // [sub_lo, sub_lo + sub_n); numbered owner * sub_n + (id - sub_lo) inside the pass
 };
 
 constexpr int PART_THREADS = 256;
@@ -108,6 +108,14 @@ constexpr int PART_THREADS = 256;
 // instead of scanning the read again.
 constexpr int SUMMARY_RUNS = 10;
 constexpr uint32_t SUMMARY_OVERFLOW = 15;
+
+// pass-local number of a global fine bucket id, or ~0 if the bucket is not in this pass
+__device__ __forceinline__ uint32_t pass_local(uint32_t bucket, const PartParams& pp)
+{
+    const uint32_t ls = pp.log2_nb - pp.log2_world;
+    const uint32_t d = (bucket & ((1u << ls) - 1u)) - pp.sub_lo;
+    return d < pp.sub_n ? (bucket >> ls) * pp.sub_n + d : 0xFFFFFFFFu;
+}
 
 // fine bucket of a minimizer hash: global id, owner-major (all fine buckets of one owner rank contiguous)
 __device__ __forceinline__ uint32_t bucket_of(uint32_t minhash, const PartParams& pp)
@@ -157,8 +165,8 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
             const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
             uint64_t n_reads, PartParams pp,
             unsigned long long* __restrict__ bucket_acc,      // !WRITE: per fine bucket (records<<32 | instances)
-            const uint64_t* __restrict__ bucket_base,         // WRITE: first record index of each fine bucket
-            uint32_t* __restrict__ bucket_cur,                // WRITE: append cursors
+            unsigned long long* __restrict__ bucket_cur,      // WRITE: append cursors, start at each fine bucket's first record index
+            uint64_t n_out,                                   // WRITE: records the pass holds (nothing is written beyond)
             uint4* __restrict__ records,
             uint4* __restrict__ summaries,                    // !WRITE: per read, its runs (see RunSummary)
             const uint32_t* __restrict__ read_list,           // WRITE (optional): the reads to process
@@ -206,8 +214,8 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
             if (qn == PART_QCAP) {        // rare: flush early
                 for (uint32_t e = 0; e < qn; ++e) {
                     uint32_t a = queue[(2 * e) * PART_THREADS + tid], b = queue[(2 * e + 1) * PART_THREADS + tid];
-                    uint32_t slot = atomicAdd(&bucket_cur[b], 1u);
-                    emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, bucket_base[b] + slot, records);
+                    const uint64_t dst = atomicAdd(&bucket_cur[b], 1ull);
+                    if (dst < n_out) emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, dst, records);
                 }
                 qn = 0;
             }
@@ -235,10 +243,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
             if (bi != W - 1) { uint32_t sfx = arr[(bi + 1) * PART_THREADS + tid]; older = sfx < mv; mv = older ? sfx : mv; }
             const uint32_t s = t + 1 - W;
             uint32_t bucket = bucket_of(mv, pp);
-            if (WRITE) {                                          // hash-slice pass: foreign buckets become "no bucket"
-                const bool mine = (bucket & ((1u << pp.log2_pass) - 1u)) == pp.pass;
-                bucket = mine ? (bucket >> pp.log2_pass) : 0xFFFFFFFFu;
-            }
+            if (WRITE) bucket = pass_local(bucket, pp);           // buckets of other passes become "no bucket"
             const bool open = s == 0 || bucket != cur_b || cur_nk == (uint32_t)KTraits<K>::NK_MAX;
             if (open) {
                 if (s != 0) close_run();
@@ -281,23 +286,22 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     if (WRITE) {
         for (uint32_t e = 0; e < qn; ++e) {
             uint32_t a = queue[(2 * e) * PART_THREADS + tid], b = queue[(2 * e + 1) * PART_THREADS + tid];
-            uint32_t slot = atomicAdd(&bucket_cur[b], 1u);
-            emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, bucket_base[b] + slot, records);
+            const uint64_t dst = atomicAdd(&bucket_cur[b], 1ull);
+            if (dst < n_out) emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, dst, records);
         }
     }
 }
 
 // One hash-slice pass of the scatter, from the run summaries: a lane walks its read's runs, rebuilds each
 // run's bucket from the minimizer the summary points at (2M bits of the read, no scan), and writes the
-// records of the runs that belong to this pass.  `bad` counts records that would land outside their
-// bucket's range (summary and counters disagree: a bug, reported by the host, never written).
+// records of the runs that belong to this pass.  The cursors start at the buckets' first record indices;
+// afterwards cursor[b] must equal base[b+1] (k_check_cursors).
 template <int K>
 __global__ void __launch_bounds__(256)
 k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
                const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
                uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries,
-               const uint64_t* __restrict__ bucket_base, uint32_t* __restrict__ bucket_cur, uint4* __restrict__ records,
-               unsigned int* __restrict__ bad)
+               unsigned long long* __restrict__ bucket_cur, uint64_t n_out, uint4* __restrict__ records)
 {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_reads) return;
@@ -329,11 +333,10 @@ k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const 
             y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
             const uint32_t f = y >> (32 - 2 * M), rcv = ~x & mmask;              // the scan's forward / reverse-complement values
             const uint32_t bucket = bucket_of(mix32(f < rcv ? f : rcv), pp);
-            if ((bucket & ((1u << pp.log2_pass) - 1u)) == pp.pass) {
-                const uint32_t lb = bucket >> pp.log2_pass;
-                const uint64_t dst = bucket_base[lb] + atomicAdd(&bucket_cur[lb], 1u);
-                if (dst < bucket_base[lb + 1]) emit_record<K>(words, n_words, bit0, s0, nk, lb, gl, tag, dst, records);
-                else atomicAdd(bad, 1u);
+            const uint32_t lb = pass_local(bucket, pp);
+            if (lb != 0xFFFFFFFFu) {
+                const uint64_t dst = atomicAdd(&bucket_cur[lb], 1ull);         // one random access for base and rank
+                if (dst < n_out) emit_record<K>(words, n_words, bit0, s0, nk, lb, gl, tag, dst, records);
             }
             s0 += nk;
         }
@@ -426,6 +429,9 @@ __device__ __forceinline__ Probe probe_begin(u128 c, uint32_t ctx, int32_t tag, 
 // kernel whatever happens.  Returns false if the probe sequence got too long.
 // (Two keys per lane in flight was tried and was slower.)
 #define DFK_COMPILER_FENCE() asm volatile("" ::: "memory")
+#ifdef DFK_PROBE_STATS   // experiment only: [0] loop iterations, [1] batches, [2] lane probes, [3] waits on a locked slot
+__device__ unsigned long long g_probe_stats[4];
+#endif
 
 // lane state in the probe loop
 enum : uint32_t { PS_PROBING = 0, PS_FOUND = 1, PS_FAILED = 2, PS_IDLE = 3 };
@@ -438,7 +444,13 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
                                              uint32_t S, const Probe& A, uint32_t& n_claimed)
 {
     uint32_t state = A.active ? PS_PROBING : PS_IDLE, slot = A.slot, seen = 0, cost = 0;
+#ifdef DFK_PROBE_STATS
+    uint32_t dbg_iter = 0;
+#endif
     while (__ballot(state == PS_PROBING) != 0ull) {
+#ifdef DFK_PROBE_STATS
+        ++dbg_iter;
+#endif
         if (state == PS_PROBING) {
             uint32_t e = 0, r0, r1, r2, r3 = A.k3;
             if (LDS_TABLE) {
@@ -474,6 +486,16 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
             state = fin | ((uint32_t)(cost >= PROBE_LIMIT) << 1);        // PS_FOUND, PS_FAILED or PS_PROBING
         }
     }
+#ifdef DFK_PROBE_STATS
+    {
+        uint32_t pr = cost / PROBE_COST, sp = cost % PROBE_COST;
+        for (int d = 32; d > 0; d >>= 1) { pr += __shfl_down(pr, d, 64); sp += __shfl_down(sp, d, 64); }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g_probe_stats[0], (unsigned long long)dbg_iter); atomicAdd(&g_probe_stats[1], 1ull);
+            atomicAdd(&g_probe_stats[2], (unsigned long long)pr); atomicAdd(&g_probe_stats[3], (unsigned long long)sp);
+        }
+    }
+#endif
     if (state == PS_FOUND) {
         if ((seen & CNT_MASK) < CNT_NEAR_SAT) atomicAdd(&cnt[slot], 1u);
         else {                                                            // saturate exactly at 2^24-1 (KDef::setCount)
@@ -1245,14 +1267,24 @@ k_scan_add(uint64_t* __restrict__ out, uint64_t n, const uint64_t* __restrict__ 
     for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) out[base + i] += add;
 }
 
-// one hash-slice pass's view of the global counters: local bucket j = global bucket j*P + pass
+// after a scatter: every bucket received exactly the records the counting scan saw for it
 __global__ void __launch_bounds__(256)
-k_slice(const unsigned long long* __restrict__ acc, uint32_t log2_pass, uint32_t pass, uint64_t nb_local,
+k_check_cursors(const unsigned long long* __restrict__ cur, const uint64_t* __restrict__ base, uint64_t nb, unsigned int* __restrict__ bad)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool wrong = b < nb && cur[b] != base[b + 1];
+    if (__ballot(wrong) && wrong) atomicAdd(bad, 1u);
+}
+
+// one pass's view of the global counters: local bucket owner * sub_n + d = global bucket (owner << log2_sub) + sub_lo + d
+__global__ void __launch_bounds__(256)
+k_slice(const unsigned long long* __restrict__ acc, uint32_t log2_sub, uint32_t sub_lo, uint32_t sub_n, uint64_t nb_local,
         uint64_t* __restrict__ rec, uint64_t* __restrict__ inst)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j > nb_local) return;
-    unsigned long long h = j < nb_local ? acc[(j << log2_pass) | pass] : 0ull;    // element nb_local = 0: the scans yield totals there
+    const uint64_t owner = j / sub_n, d = j - owner * sub_n;
+    unsigned long long h = j < nb_local ? acc[(owner << log2_sub) + sub_lo + d] : 0ull;   // element nb_local = 0: the scans yield totals there
     rec[j] = h >> 32; inst[j] = h & 0xFFFFFFFFull;
 }
 
