@@ -200,9 +200,13 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     uint32_t cur_b = 0, cur_s0 = 0, cur_nk = 0;
     uint32_t qn = 0;
 
+    // the word after the current one is always in flight (a load issued when it is needed costs a full
+    // memory latency every 16 bases)
     uint64_t wi = bit0 >> 5;
     uint32_t wbits = wi < n_words ? words[wi] : 0u;
+    uint32_t wnext = wi + 1 < n_words ? words[wi + 1] : 0u;
     uint32_t wpos = (uint32_t)bit0 & 31u;
+    uint32_t sfx_next = 0xFFFFFFFFu;        // arr[bi + 1] of the previous block, read one position ahead
 
     auto close_run = [&]() {
         if (WRITE && cur_b == 0xFFFFFFFFu) return;                  // run belongs to another pass
@@ -228,7 +232,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     for (uint32_t j = 0; j < gl; ++j) {
         uint32_t b = (wbits >> wpos) & 3u;
         wpos += 2;
-        if (wpos == 32) { wpos = 0; ++wi; wbits = wi < n_words ? words[wi] : 0u; }
+        if (wpos == 32) { wpos = 0; ++wi; wbits = wnext; wnext = wi + 1 < n_words ? words[wi + 1] : 0u; }
         f = ((f << 2) | b) & mmask;
         rc = (rc >> 2) | ((3u - b) << rsh);
         if (j + 1 < M) continue;
@@ -240,7 +244,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
         if (t + 1 >= W) {                                        // k-mer s = t-W+1 is complete
             uint32_t mv = P;
             bool older = false;                                  // the minimum sits in the previous block
-            if (bi != W - 1) { uint32_t sfx = arr[(bi + 1) * PART_THREADS + tid]; older = sfx < mv; mv = older ? sfx : mv; }
+            if (bi != W - 1) { const uint32_t sfx = sfx_next; older = sfx < mv; mv = older ? sfx : mv; }
             const uint32_t s = t + 1 - W;
             uint32_t bucket = bucket_of(mv, pp);
             if (WRITE) bucket = pass_local(bucket, pp);           // buckets of other passes become "no bucket"
@@ -257,15 +261,27 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
         if (++bi == W) {                                         // block complete: turn it into suffix minima
             uint32_t run = h, ri = W - 1;
             if (!WRITE) sidx[(W - 1) * PART_THREADS + tid] = (uint8_t)(W - 1);
-            for (int i = (int)W - 2; i >= 0; --i) {
-                uint32_t v = arr[i * PART_THREADS + tid];
-                const bool lt = v < run;
-                run = lt ? v : run;
-                arr[i * PART_THREADS + tid] = run;
-                if (!WRITE) { ri = lt ? (uint32_t)i : ri; sidx[i * PART_THREADS + tid] = (uint8_t)ri; }
+            // eight reads in flight at a time: read-compare-write one element after the other is a chain of
+            // LDS latencies
+            for (int i0 = (int)W - 2; i0 >= 0; i0 -= 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = i0 - k >= 0 ? arr[(i0 - k) * PART_THREADS + tid] : 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 - k;
+                    if (i >= 0) {
+                        const bool lt = v[k] < run;
+                        run = lt ? v[k] : run;
+                        arr[i * PART_THREADS + tid] = run;
+                        if (!WRITE) { ri = lt ? (uint32_t)i : ri; sidx[i * PART_THREADS + tid] = (uint8_t)ri; }
+                    }
+                }
             }
             bi = 0;
         }
+        // the suffix minimum the next position needs (index bi + 1 of the block before the current one)
+        if (bi + 1 < W) sfx_next = arr[(bi + 1) * PART_THREADS + tid];
     }
     close_run();
     if (!WRITE) {
