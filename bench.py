@@ -12,7 +12,7 @@ read set that is already resident in HBM when the timed region starts.
 Workload = BASELINE.json configs[1]: synthetic human-scale stLFR, 900 M pairs of 2x100 bp over a
 3.1 Gb random genome (1.8 G reads, 8.8e10 k-mer instances, ~3.1e9 solid 48-mers), 0.5 % substitutions,
 10 % unbarcoded pairs, K=48, MIN_FREQ=3, MIN_BC=2, MIN_QUAL=7.  It is generated directly in HBM
-(torch, seeded) in ~20 s.  On one GPU the library counts it in hash-slice passes (the dictionary alone
+(torch, seeded) in ~20 s.  On one GPU the library counts it in passes over ranges of its minimizer buckets (the dictionary alone
 is 99 GB).  With N GPUs the SAME set is sharded by pair ranges (configs[2]; "scaling": "strong"): every
 rank generates and holds 900M/N pairs, records travel to the rank owning their minimizer bucket in one
 RCCL all-to-all per pass, and a second small exchange settles cross-rank adjacencies.
@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--genome-mb", type=float, default=3100.0, help="genome size, Mb")
     ap.add_argument("--pairs", type=int, default=900_000_000, help="read pairs in the whole set")
     ap.add_argument("--coverage", type=float, default=0.0, help="if > 0: pairs = coverage * genome / 200")
-    ap.add_argument("--passes", type=int, default=0, help="hash-slice passes (0 = sized from free HBM)")
+    ap.add_argument("--passes", type=int, default=0, help="number of bucket-range passes (0 = sized from free HBM)")
     ap.add_argument("--K", type=int, default=48)
     ap.add_argument("--minimizer", type=int, default=0)
     ap.add_argument("--inst-per-item", type=int, default=0)
@@ -195,7 +195,7 @@ def main():
                                    f"synthetic stLFR, {total_pairs} pairs 2x100 bp over a {args.genome_mb:g} Mb random genome "
                                    f"({200.0 * total_pairs / G:.1f}x), 0.5% subst., 10% unbarcoded, K={args.K}, MIN_FREQ=3, MIN_BC=2, MIN_QUAL=7",
                        "reads_total": 2 * total_pairs, "kmer_instances_total": n_inst, "K": args.K,
-                       "parallelism": "single GPU, hash-slice passes" if world == 1 else
+                       "parallelism": "single GPU, bucket-range passes" if world == 1 else
                                       f"{world} ranks: read shards, all-to-all of super-k-mer records by minimizer bucket"},
             "df_stage_wall_s": elapsed / args.steps,
             "stage_ms_rank0": {k: round(st[k], 3) for k in ("ms_trim", "ms_part_count", "ms_part_scatter", "ms_count",

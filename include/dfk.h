@@ -54,7 +54,7 @@ typedef struct dfk_config {
     uint32_t minimizer_len;     /* 0 = default; 8..16 */
     uint32_t flags;             /* DFK_F_* */
     uint64_t inst_per_item;     /* 0 = default; k-mer instances packed into one LDS table pass */
-    uint64_t reserved[4];       /* [0] = hash-slice passes (power of two), 0 = sized from the HBM budget */
+    uint64_t reserved[4];       /* [0] = forced number of bucket-range passes, 0 = sized from the free HBM */
 } dfk_config;
 
 #define DFK_F_KEEP_PRE_ADJ   1u   /* also keep contexts before recomputeAdjacencies (kmers.kvec view) */
@@ -85,7 +85,7 @@ typedef struct dfk_stats {
      * context's stream */
     float ms_upload, ms_trim, ms_part_count, ms_part_scatter, ms_count, ms_fallback, ms_adjacency, ms_total;
     uint64_t hbm_bytes_peak;    /* peak device bytes held by the context */
-    uint64_t reserved[8];       /* [0] = hash-slice passes used */
+    uint64_t reserved[8];       /* [0] = passes used */
 } dfk_stats;
 
 typedef struct dfk_ctx dfk_ctx;
@@ -149,7 +149,7 @@ int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
  *
  *   dfk_shard_begin       trim this rank's reads; returns its k-mer instance count
  *   <caller: all-reduce the instance counts so that every rank derives the same bucket count>
- *   dfk_shard_plan        hash-slice passes this rank needs to fit its HBM (caller takes the max over ranks)
+ *   dfk_shard_plan        passes (equal bucket ranges) this rank needs to fit its HBM (caller takes the max over ranks)
  *   for pass in 0 .. 2^log2_passes - 1:
  *     dfk_shard_partition   kmerize the pass's minimizer buckets into records grouped by destination rank
  *     <caller: all-to-all of send_counts, then of the record bytes, over RCCL/xGMI>

@@ -67,7 +67,7 @@ struct dfk_ctx {
     bool have = false;
     uint64_t n_reads = 0;
     DevBuf good_len;                          // u32[n_reads]
-    struct Part { DevBuf buf, pre; uint64_t n = 0; };   // dfk_entry32[n]: one per hash-slice pass
+    struct Part { DevBuf buf, pre; uint64_t n = 0; };   // dfk_entry32[n]: one per pass
     std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
     unsigned seg_attempt = 0;                 // output segments are sized (estimate << seg_attempt)

@@ -308,7 +308,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     }
 }
 
-// One hash-slice pass of the scatter, from the run summaries: a lane walks its read's runs, rebuilds each
+// One pass of the scatter, from the run summaries: a lane walks its read's runs, rebuilds each
 // run's bucket from the minimizer the summary points at (2M bits of the read, no scan), and writes the
 // records of the runs that belong to this pass.  The cursors start at the buckets' first record indices;
 // afterwards cursor[b] must equal base[b+1] (k_check_cursors).
@@ -723,7 +723,11 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
     }
     sync();
     // ---- pass 2
+#ifdef DFK_ABLATE_PASS2
+    if (false) {
+#else
     if (cp.do_adj) {
+#endif
         const uint32_t total = __builtin_amdgcn_readfirstlane(tld(n_tasks));
         if (total <= ADJ_TASKS) {
             for (uint32_t t = tid; t < total; t += nthreads) resolve(tasks[t]);
@@ -772,7 +776,11 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         // (key words are rewritten on claim).  cnt, ctxs and bcw are contiguous.
         const uint32_t ns = __builtin_amdgcn_readfirstlane(tld(n_solid));
         const uint32_t base = __builtin_amdgcn_readfirstlane(tld(cursor32));
+#ifdef DFK_ABLATE_EMIT
+        for (uint32_t i = tid; i < 0 * ns; i += nthreads) {
+#else
         for (uint32_t i = tid; i < ns; i += nthreads) {
+#endif
             const uint32_t slot = solid_list[i];
             emit(slot, tld(&cnt[slot]), tld(&bcw[slot]), (unsigned long long)base + i);
         }

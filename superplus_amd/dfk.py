@@ -93,7 +93,7 @@ class Dfk:
         cfg = Config(abi_version=ABI_VERSION, K=K, min_qual=min_qual, min_freq=min_freq, min_bc=min_bc, device=device,
                      ign_bc_below=ign_bc_below, hbm_budget_bytes=hbm_budget_bytes, minimizer_len=minimizer_len,
                      flags=F_KEEP_PRE_ADJ if keep_pre_adjacency else 0, inst_per_item=inst_per_item)
-        cfg.reserved[0] = passes          # hash-slice passes (power of two); 0 = sized from the HBM budget
+        cfg.reserved[0] = passes          # forced number of bucket-range passes; 0 = sized from the free HBM
         self._ctx = C.c_void_p()
         _check(lib().dfk_create(C.byref(cfg), C.byref(self._ctx)))
         self.K = K

@@ -55,7 +55,7 @@ bench = [l for l in open(os.path.join(src, "bench_trace.log")) if l.startswith("
 line = json.loads(bench[-1]) if bench else {}
 runs = int(line.get("steps", 3)) + int(line.get("warmup", 1))               # bench steps executed under the profiler
 passes = int((line.get("counts_rank0") or {}).get("n_passes", 1)) or 1
-# k_count is launched once per hash-slice pass (plus tiny relaunches for split items): total its traffic over the
+# k_count is launched once per bucket-range pass (plus tiny relaunches for split items): total its traffic over the
 # whole run and divide by the number of main launches
 fs_tot, ws_tot = sum(ctr[dom]["FETCH_SIZE"]), sum(ctr[dom]["WRITE_SIZE"])
 main = runs * passes
