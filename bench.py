@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--inst-per-item", type=int, default=0)
     ap.add_argument("--cpu-sample-reads", type=int, default=600000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="rehearsal on one GPU: run rank 0 of this many ranks against replicas of itself (not a benchmark result)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,6 +135,8 @@ def main():
     G = int(args.genome_mb * 1e6)
     total_pairs = int(args.coverage * G / 200.0) if args.coverage > 0 else args.pairs
     lo, hi = rank * total_pairs // world, (rank + 1) * total_pairs // world          # this rank's pair range
+    if args.emulate_world > 1:
+        lo, hi = 0, total_pairs // args.emulate_world
     genome = synth.make_genome(G, 20261004, device=dev)                               # same genome on every rank
     rs = synth.make_reads(genome, hi - lo, 20261004 + 17 * (rank + 1))
     del genome
@@ -144,7 +148,14 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()          # the library sizes its HBM budget from what is free when the context is created
 
-    if world == 1:
+    if args.emulate_world > 1:
+        from superplus_amd.dist import DistDfk, ReplicaComm
+        d = DistDfk(comm=ReplicaComm(args.emulate_world), K=args.K, device=local, minimizer_len=args.minimizer,
+                    inst_per_item=args.inst_per_item, passes=args.passes)
+        def step():
+            d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc, read_id0=0)
+            return d.stats()
+    elif world == 1:
         d = Dfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes)
         def step():
             d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc)
@@ -198,6 +209,8 @@ def main():
                        "parallelism": "single GPU, bucket-range passes" if world == 1 else
                                       f"{world} ranks: read shards, all-to-all of super-k-mer records by minimizer bucket"},
             "df_stage_wall_s": elapsed / args.steps,
+            **({"rehearsal": f"rank 0 of {args.emulate_world} against replicas of itself; per-rank time without the transfers"}
+               if args.emulate_world > 1 else {}),
             "stage_ms_rank0": {k: round(st[k], 3) for k in ("ms_trim", "ms_part_count", "ms_part_scatter", "ms_count",
                                                            "ms_fallback", "ms_adjacency", "ms_total")},
             "counts_rank0": {k: st[k] for k in ("n_reads", "n_inst", "n_records", "n_buckets", "n_items", "n_overflow_items",

@@ -152,7 +152,7 @@ int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
  *   dfk_shard_plan        passes (equal bucket ranges) this rank needs to fit its HBM (caller takes the max over ranks)
  *   for pass in 0 .. 2^log2_passes - 1:
  *     dfk_shard_partition   kmerize the pass's minimizer buckets into records grouped by destination rank
- *     <caller: all-to-all of send_counts, then of the record bytes, over RCCL/xGMI>
+ *     <caller: all-to-all of send_counts; dfk_shard_recv_buffer; all-to-all of the record bytes, over RCCL/xGMI>
  *     dfk_shard_count       regroup the received records by fine bucket and count them; after the
  *                           last pass this rank holds the solid k-mers it owns, pre-adjacency
  *   dfk_shard_adj_queries neighbour keys of the local solid k-mers, grouped by owner rank
@@ -173,6 +173,10 @@ int dfk_shard_begin(dfk_ctx* ctx,
 int dfk_shard_plan(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t* log2_passes);
 int dfk_shard_partition(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t log2_passes, uint32_t pass,
               const void** d_records, uint64_t* send_counts /* [world], in 32-byte records */);
+/* Room for the records this rank is about to receive, from the library's own HBM budget (so that the
+ * send, receive and regroup buffers of a pass are all planned in one place); dfk_shard_count frees it.
+ * Optional: dfk_shard_count accepts any device pointer. */
+int dfk_shard_recv_buffer(dfk_ctx* ctx, uint64_t n_records, void** d_buf);
 int dfk_shard_count(dfk_ctx* ctx, const void* d_records, uint64_t n_records, uint32_t pass);
 int dfk_shard_adj_queries(dfk_ctx* ctx, const void** d_keys,
               uint64_t* send_counts /* [world], in 16-byte keys */);

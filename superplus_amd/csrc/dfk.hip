@@ -81,7 +81,8 @@ struct dfk_ctx {
     const void* sh_in[7] = {};                // caller's device arrays, valid until dfk_shard_partition returns
     uint64_t sh_packed_bytes = 0, sh_pq_bytes = 0, sh_n_reads = 0, sh_n_inst_local = 0;
     int64_t sh_read_id0 = 0;
-    DevBuf shard_records;
+    DevBuf shard_records;                     // send buffer of the current pass (records grouped by destination rank)
+    DevBuf shard_recv;                        // receive buffer handed to the caller by dfk_shard_recv_buffer
     DevBuf adj_keys, adj_src; uint64_t adj_n = 0;
     DevBuf set; uint64_t set_mask = 0;
     uint32_t shard_world = 1, shard_log2_nb = 0;
@@ -186,14 +187,14 @@ struct dfk_ctx {
     void release_all()
     {
         // results of the previous run go back to the pool (sizes come from the DevBufs that own them)
-        DevBuf* live[] = {&good_len, &shard_records, &adj_keys, &adj_src, &set};
+        DevBuf* live[] = {&good_len, &shard_records, &shard_recv, &adj_keys, &adj_src, &set};
         for (DevBuf* d : live) release(*d);
         for (Part& pt : parts) { release(pt.buf); release(pt.pre); }
         parts.clear();
         // anything an aborted run left behind: the arena is simply declared empty again
         owned.clear(); held = 0;
         for (Chunk& k : chunks) k.free_list.assign(1, Free{0, k.bytes});
-        good_len = shard_records = adj_keys = adj_src = set = DevBuf{};
+        good_len = shard_records = shard_recv = adj_keys = adj_src = set = DevBuf{};
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
         n_solid = 0; adj_n = 0; shard_open = false;
         if (shard_state) { shard_state_free(shard_state); shard_state = nullptr; }
@@ -271,6 +272,8 @@ struct BucketTable {
     DevBuf acc;                           // u64[nb] records<<32 | instances, global numbering
     DevBuf summ;                          // uint4[n_reads]: run summaries (k_partition<K,false>), what the scatter passes work from
     DevBuf ovf_list; uint64_t n_ovf = 0;  // reads with too many runs for a summary: scattered by scanning
+    DevBuf class_hist;                    // sharded runs: u64[2][world * PART_CLASSES] records | instances per owner and class (no per-bucket counters)
+    std::vector<uint64_t> h_class;        //   ... and its host copy
     uint64_t n_records = 0, n_inst = 0;
 };
 struct Partition {                        // one pass
@@ -302,23 +305,27 @@ int table_totals(dfk_ctx* c, const DevBuf& acc, uint64_t nb, uint64_t* n_records
 }
 
 template <int K>
-int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, BucketTable* T)
+int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, BucketTable* T, bool by_class = false)
 {
     const PartParams pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 1u << (T->log2_nb - log2_world));
     const uint64_t nb = 1ull << T->log2_nb;
-    int rc = c->alloc(T->acc, nb * 8, "bucket counters", true); if (rc) return rc;
+    int rc = 0;
+    const uint64_t n_bins = 2ull * (PART_CLASSES << log2_world);
+    if (by_class) { rc = c->alloc(T->class_hist, n_bins * 8, "class counters", true); if (rc) return rc; HIP_TRY(hipMemsetAsync(T->class_hist.p, 0, n_bins * 8, c->stream)); }
+    else { rc = c->alloc(T->acc, nb * 8, "bucket counters", true); if (rc) return rc; }
     rc = c->alloc(T->summ, std::max<uint64_t>(1, in.n_reads) * 16, "run summaries", true); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
-    const unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
-    const size_t lds_a = (sizeof(uint32_t) + 1) * pp.W * PART_THREADS + sizeof(uint16_t) * SUMMARY_RUNS * PART_THREADS;
+    if (!by_class) HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
+    unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
+    if (by_class) grid = std::min<unsigned>(grid, 12u * (unsigned)c->prop.multiProcessorCount);   // grid-stride: class counts are flushed once per block
+    const size_t lds_a = (sizeof(uint32_t) + 1) * pp.W * PART_THREADS + sizeof(uint16_t) * SUMMARY_RUNS * PART_THREADS + (by_class ? n_bins * 4 : 0);
     Timer t(c->stream);
     t.start();
     if (grid)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
-                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p,
+                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p,
                            (unsigned long long*)nullptr, (uint64_t)0, (uint4*)nullptr, (uint4*)T->summ.p,
-                           (const uint32_t*)nullptr, (uint64_t)0);
+                           (const uint32_t*)nullptr, (uint64_t)0, (const uint64_t*)nullptr);
     HIP_TRY(hipGetLastError());
     // reads whose runs did not fit a summary
     T->n_ovf = 0;
@@ -341,7 +348,13 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     }
     c->st.ms_part_count = t.stop();
     TRACE("%llu of %llu reads have more than %d runs", (unsigned long long)T->n_ovf, (unsigned long long)in.n_reads, SUMMARY_RUNS);
-    rc = table_totals(c, T->acc, nb, &T->n_records, &T->n_inst); if (rc) return rc;
+    if (by_class) {
+        T->h_class.assign(n_bins, 0);
+        HIP_TRY(hipMemcpyAsync(T->h_class.data(), T->class_hist.p, n_bins * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        T->n_records = T->n_inst = 0;
+        for (uint64_t i = 0; i < n_bins / 2; ++i) { T->n_records += T->h_class[i]; T->n_inst += T->h_class[n_bins / 2 + i]; }
+    } else { rc = table_totals(c, T->acc, nb, &T->n_records, &T->n_inst); if (rc) return rc; }
     TRACE("partition count pass done (%llu buckets, %llu records)", (unsigned long long)nb, (unsigned long long)T->n_records);
     if (T->n_inst != n_inst)
         return fail(DFK_E_HIP, "partition count pass saw %llu instances, trim saw %llu",
@@ -420,9 +433,9 @@ int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3((unsigned)((T.n_ovf + PART_THREADS - 1) / PART_THREADS)),
                            dim3(PART_THREADS), lds_b, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
-                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr,
+                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
                            (unsigned long long*)cur.p, P->n_records, (uint4*)P->records.p, (uint4*)nullptr,
-                           (const uint32_t*)T.ovf_list.p, T.n_ovf);
+                           (const uint32_t*)T.ovf_list.p, T.n_ovf, (const uint64_t*)nullptr);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, (const unsigned long long*)cur.p,
                        (const uint64_t*)P->base.p, nb, (unsigned int*)d_bad.p);
@@ -751,10 +764,11 @@ int stage_adjacency(dfk_ctx* c)
 uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
 {
     // fine buckets of ~256-512 instances; an item packs several of them up to its instance budget.
-    // The record header keeps 24 bits of the (rank-local) bucket id for the multi-GPU regroup.
+    // (When sharded, the record header keeps 24 bits of the bucket id inside the pass for the receiver's
+    // regroup: dfk_shard_plan asks for enough passes that a pass has <= 2^24 buckets per owner.)
     uint32_t l = ceil_log2(n_inst / 512 + 1);
     l = std::max<uint32_t>(l, 4 + log2_world);
-    return std::min<uint32_t>(l, log2_world ? 24 + log2_world : 28);
+    return std::min<uint32_t>(l, 28);
 }
 
 // How many fine buckets the next pass may take, from what is free now.  A pass holds its bucket tables, its
@@ -830,7 +844,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         lo += n; ++n_passes;
         c->seg_attempt = 0;                                           // later passes size their output from the observed ratio
     }
-    c->release(T.acc); c->release(T.summ); c->release(T.ovf_list);
+    c->release(T.acc); c->release(T.summ); c->release(T.ovf_list); c->release(T.class_hist);
     c->st.reserved[0] = n_passes;
     rc = count_run_end(c, &R); if (rc) return rc;
     rc = stage_adjacency<K>(c); if (rc) return rc;

@@ -159,26 +159,40 @@ __device__ __forceinline__ void emit_record(const uint32_t* __restrict__ words, 
     records[2 * dst_index + 1] = b;
 }
 
-template <int K, bool WRITE>
-__global__ void __launch_bounds__(PART_THREADS)
-k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
-            const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
-            uint64_t n_reads, PartParams pp,
-            unsigned long long* __restrict__ bucket_acc,      // !WRITE: per fine bucket (records<<32 | instances)
-            unsigned long long* __restrict__ bucket_cur,      // WRITE: append cursors, start at each fine bucket's first record index
-            uint64_t n_out,                                   // WRITE: records the pass holds (nothing is written beyond)
-            uint4* __restrict__ records,
-            uint4* __restrict__ summaries,                    // !WRITE: per read, its runs (see RunSummary)
-            const uint32_t* __restrict__ read_list,           // WRITE (optional): the reads to process
-            uint64_t n_list)
+// Sharded runs do not need per-bucket counts on the sending side (the owner regroups what it receives), only
+// how many records go to each owner in each pass: bucket space of an owner cut into PART_CLASSES equal
+// classes; a pass is a whole number of classes.
+constexpr uint32_t PART_CLASSES = 64;
+__device__ __forceinline__ uint32_t class_bin(uint32_t bucket, const PartParams& pp)
 {
-    extern __shared__ uint32_t smem[];
+    const uint32_t ls = pp.log2_nb - pp.log2_world;
+    const uint32_t sub = bucket & ((1u << ls) - 1u);
+    return (bucket >> ls) * PART_CLASSES + (ls > 6 ? sub >> (ls - 6) : sub);
+}
+
+// the scan of one read (lane per read; no block barriers inside)
+template <int K, bool WRITE>
+__device__ __forceinline__ void
+partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
+            const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
+            const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
+            uint64_t n_reads, const PartParams& pp,
+            unsigned long long* __restrict__ bucket_acc, unsigned long long* __restrict__ bucket_cur, uint64_t n_out,
+            uint4* __restrict__ records, uint4* __restrict__ summaries, const uint32_t* __restrict__ read_list, uint64_t n_list,
+            const uint64_t* __restrict__ slice_base)
+{
+    // where a record of pass-local bucket b goes: its bucket's cursor, or (sharded) its owner's slice
+    auto place = [&](uint32_t b) -> uint64_t {
+        if (!slice_base) { const uint64_t d = atomicAdd(&bucket_cur[b], 1ull); return d < n_out ? d : ~0ull; }
+        const uint32_t owner = b / pp.sub_n;
+        const uint64_t d = slice_base[owner] + atomicAdd(&bucket_cur[owner], 1ull);
+        return d < slice_base[owner + 1] ? d : ~0ull;
+    };
     uint32_t* arr = smem;                                        // [W][PART_THREADS] hashes -> suffix minima
     uint32_t* queue = smem + pp.W * PART_THREADS;                // WRITE: [PART_QCAP][2][PART_THREADS]
     uint8_t* sidx = reinterpret_cast<uint8_t*>(smem + pp.W * PART_THREADS);              // !WRITE: [W][PART_THREADS] where each suffix minimum sits
     uint16_t* rq = reinterpret_cast<uint16_t*>(sidx + pp.W * PART_THREADS);              // !WRITE: [SUMMARY_RUNS][PART_THREADS] run fields
     const int tid = threadIdx.x;
-    uint64_t r = (uint64_t)blockIdx.x * PART_THREADS + tid;
     if (WRITE && read_list) { if (r >= n_list) return; r = read_list[r]; }
     const uint32_t M = pp.M, W = pp.W;
     const uint32_t gl = r < n_reads ? good_len[r] : 0;
@@ -211,15 +225,16 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     auto close_run = [&]() {
         if (WRITE && cur_b == 0xFFFFFFFFu) return;                  // run belongs to another pass
         if (!WRITE) {
-            atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
+            if (lh) { const uint32_t bin = class_bin(cur_b, pp); atomicAdd(&lh[bin], 1u); atomicAdd(&lh[(PART_CLASSES << pp.log2_world) + bin], cur_nk); }
+            else atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
             if (qn < (uint32_t)SUMMARY_RUNS) rq[qn * PART_THREADS + tid] = (uint16_t)(cur_nk | (cur_rel << 6));
             ++qn;
         } else {
             if (qn == PART_QCAP) {        // rare: flush early
                 for (uint32_t e = 0; e < qn; ++e) {
                     uint32_t a = queue[(2 * e) * PART_THREADS + tid], b = queue[(2 * e + 1) * PART_THREADS + tid];
-                    const uint64_t dst = atomicAdd(&bucket_cur[b], 1ull);
-                    if (dst < n_out) emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, dst, records);
+                    const uint64_t dst = place(b);
+                    if (dst != ~0ull) emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, dst, records);
                 }
                 qn = 0;
             }
@@ -302,34 +317,63 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     if (WRITE) {
         for (uint32_t e = 0; e < qn; ++e) {
             uint32_t a = queue[(2 * e) * PART_THREADS + tid], b = queue[(2 * e + 1) * PART_THREADS + tid];
-            const uint64_t dst = atomicAdd(&bucket_cur[b], 1ull);
-            if (dst < n_out) emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, dst, records);
+            const uint64_t dst = place(b);
+            if (dst != ~0ull) emit_record<K>(words, n_words, bit0, a & 0xFFFFu, a >> 16, b, gl, tag, dst, records);
         }
     }
 }
 
-// One pass of the scatter, from the run summaries: a lane walks its read's runs, rebuilds each
-// run's bucket from the minimizer the summary points at (2M bits of the read, no scan), and writes the
-// records of the runs that belong to this pass.  The cursors start at the buckets' first record indices;
-// afterwards cursor[b] must equal base[b+1] (k_check_cursors).
-template <int K>
-__global__ void __launch_bounds__(256)
-k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
-               const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
-               uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries,
-               unsigned long long* __restrict__ bucket_cur, uint64_t n_out, uint4* __restrict__ records)
+template <int K, bool WRITE>
+__global__ void __launch_bounds__(PART_THREADS)
+k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
+            const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
+            uint64_t n_reads, PartParams pp,
+            unsigned long long* __restrict__ bucket_acc,      // !WRITE: per fine bucket (records<<32 | instances) ...
+            unsigned long long* __restrict__ class_hist,      // ... or (sharded) per owner and class: [records | instances][world * PART_CLASSES]
+            unsigned long long* __restrict__ bucket_cur,      // WRITE: append cursors, start at each fine bucket's first record index
+            uint64_t n_out,                                   // WRITE: records the pass holds (nothing is written beyond)
+            uint4* __restrict__ records,
+            uint4* __restrict__ summaries,                    // !WRITE: per read, its runs (see SUMMARY_RUNS)
+            const uint32_t* __restrict__ read_list,           // WRITE (optional): the reads to process
+            uint64_t n_list,
+            const uint64_t* __restrict__ slice_base)          // WRITE, sharded: records go to owner slices; bucket_cur = fill of each slice
 {
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_reads) return;
+    extern __shared__ uint32_t smem[];
+    // class counts are gathered in LDS by a grid-stride launch (a few thousand blocks) and flushed once per
+    // block: one global atomic per run on a handful of addresses would serialise
+    uint32_t* lh = nullptr;
+    const uint32_t n_bins = 2u * (PART_CLASSES << pp.log2_world);
+    if (!WRITE && class_hist) {
+        lh = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + 5 * pp.W * PART_THREADS + 2 * SUMMARY_RUNS * PART_THREADS);
+        for (uint32_t i = threadIdx.x; i < n_bins; i += PART_THREADS) lh[i] = 0;
+        __syncthreads();
+    }
+    const uint64_t n_work = (WRITE && read_list) ? n_list : n_reads;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * PART_THREADS; r0 < n_work; r0 += (uint64_t)gridDim.x * PART_THREADS)
+        partition_read<K, WRITE>(r0 + threadIdx.x, smem, lh, packed, packed_bytes, base_off, good_len, bc, ign_bc_below, n_reads, pp,
+                                 bucket_acc, bucket_cur, n_out, records, summaries, read_list, n_list, slice_base);
+    if (lh) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_bins; i += PART_THREADS) if (lh[i]) atomicAdd(&class_hist[i], (unsigned long long)lh[i]);
+    }
+}
+
+// Sharded scatter: the records of one pass go into one slice per owner rank, in no particular order inside
+// the slice (the owner regroups them by the bucket id in the header).  A block handles SLICE_READS reads per
+// thread: first it counts its records per owner (LDS), reserves room in every slice with one global atomic
+// per owner, then writes.
+constexpr int SLICE_READS = 16;
+template <int K, bool EMIT, typename F>
+__device__ __forceinline__ void for_each_run_in_pass(uint64_t r, const uint8_t* __restrict__ packed, uint64_t packed_bytes,
+                                                     const uint64_t* __restrict__ base_off, const PartParams& pp,
+                                                     const uint4* __restrict__ summaries, F&& f)
+{
     const uint4 sm = summaries[r];
     const uint32_t n = sm.x & 15u;
     if (n == 0 || n == SUMMARY_OVERFLOW) return;
-    const uint32_t gl = good_len[r];
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
     const uint64_t n_words = (packed_bytes + 3) >> 2;
     const uint64_t bit0 = base_off[r] * 8;
-    int32_t tag = -1;
-    if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
     const uint32_t M = pp.M;
     const uint32_t mmask = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * M)) - 1u);
     const uint64_t lo = (uint64_t)sm.x | ((uint64_t)sm.y << 32), hi = (uint64_t)sm.z | ((uint64_t)sm.w << 32);
@@ -347,16 +391,82 @@ k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const 
             const uint32_t x = alignbit(w1, w0, (uint32_t)bo & 31u) & mmask;     // the m-mer, first base in the low bits
             uint32_t y = __brev(x);
             y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
-            const uint32_t f = y >> (32 - 2 * M), rcv = ~x & mmask;              // the scan's forward / reverse-complement values
-            const uint32_t bucket = bucket_of(mix32(f < rcv ? f : rcv), pp);
+            const uint32_t fw = y >> (32 - 2 * M), rcv = ~x & mmask;             // the scan's forward / reverse-complement values
+            const uint32_t bucket = bucket_of(mix32(fw < rcv ? fw : rcv), pp);
             const uint32_t lb = pass_local(bucket, pp);
-            if (lb != 0xFFFFFFFFu) {
-                const uint64_t dst = atomicAdd(&bucket_cur[lb], 1ull);         // one random access for base and rank
-                if (dst < n_out) emit_record<K>(words, n_words, bit0, s0, nk, lb, gl, tag, dst, records);
-            }
+            if (lb != 0xFFFFFFFFu) f(s0, nk, lb, bucket >> (pp.log2_nb - pp.log2_world), bit0);
             s0 += nk;
         }
     }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
+                 const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
+                 uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries,
+                 const uint64_t* __restrict__ slice_base,        // [world + 1] first record index of every owner's slice
+                 unsigned long long* __restrict__ slice_fill,    // [world] records reserved so far in every slice
+                 uint4* __restrict__ records)
+{
+    __shared__ uint32_t cnt[256];                                 // per owner: records of this block, then its write cursor
+    __shared__ unsigned long long at[256];
+    const uint32_t world = 1u << pp.log2_world;
+    const uint64_t r_first = (uint64_t)blockIdx.x * 256 * SLICE_READS + threadIdx.x;   // reads r_first + 256 j: neighbouring lanes, neighbouring reads
+    if (threadIdx.x < world) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int j = 0; j < SLICE_READS; ++j) {
+        const uint64_t r = r_first + 256ull * j;
+        if (r < n_reads)
+            for_each_run_in_pass<K, false>(r, packed, packed_bytes, base_off, pp, summaries,
+                                           [&](uint32_t, uint32_t, uint32_t, uint32_t owner, uint64_t) { atomicAdd(&cnt[owner], 1u); });
+    }
+    __syncthreads();
+    if (threadIdx.x < world) {
+        const uint32_t n = cnt[threadIdx.x];
+        at[threadIdx.x] = slice_base[threadIdx.x] + (n ? atomicAdd(&slice_fill[threadIdx.x], (unsigned long long)n) : 0ull);
+        cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
+    const uint64_t n_words = (packed_bytes + 3) >> 2;
+    for (int j = 0; j < SLICE_READS; ++j) {
+        const uint64_t r = r_first + 256ull * j;
+        if (r >= n_reads) continue;
+        const uint32_t gl = good_len[r];
+        int32_t tag = -1;
+        if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
+        for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
+            [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t owner, uint64_t bit0) {
+                const uint64_t dst = at[owner] + atomicAdd(&cnt[owner], 1u);
+                if (dst < slice_base[owner + 1]) emit_record<K>(words, n_words, bit0, s0, nk, lb, gl, tag, dst, records);
+            });
+    }
+}
+
+// One pass of the scatter, from the run summaries: a lane walks its read's runs, rebuilds each
+// run's bucket from the minimizer the summary points at (2M bits of the read, no scan), and writes the
+// records of the runs that belong to this pass.  The cursors start at the buckets' first record indices;
+// afterwards cursor[b] must equal base[b+1] (k_check_cursors).
+template <int K>
+__global__ void __launch_bounds__(256)
+k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
+               const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
+               uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries,
+               unsigned long long* __restrict__ bucket_cur, uint64_t n_out, uint4* __restrict__ records)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t gl = good_len[r];
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
+    const uint64_t n_words = (packed_bytes + 3) >> 2;
+    int32_t tag = -1;
+    if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
+    for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
+        [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t, uint64_t bit0) {
+            const uint64_t dst = atomicAdd(&bucket_cur[lb], 1ull);             // one random access for base and rank
+            if (dst < n_out) emit_record<K>(words, n_words, bit0, s0, nk, lb, gl, tag, dst, records);
+        });
 }
 
 // ============================================================================ a2 (second half) + a3 + a4 + a5: count

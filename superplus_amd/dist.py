@@ -20,15 +20,17 @@ from . import dfk as _dfk
 from .dfk import Dfk, _check, lib
 
 
-def exchange(send: torch.Tensor, send_counts, unit: int, comm):
+def exchange(send: torch.Tensor, send_counts, unit: int, comm, recv_alloc=None):
     """All-to-all of variable-size slices.  `send` is a flat byte tensor holding, rank after rank,
-    send_counts[r] units of `unit` bytes for rank r.  Returns (recv bytes, recv_counts)."""
+    send_counts[r] units of `unit` bytes for rank r.  Returns (recv bytes, recv_counts).
+    recv_alloc(n_units) -> byte tensor lets the caller supply the receive buffer (the record
+    exchange receives into the library's own HBM budget)."""
     world = comm.world
     sc = torch.tensor(list(send_counts), dtype=torch.int64, device=send.device)
     rc = torch.empty_like(sc)
     comm.all_to_all_single(rc, sc, None, None)
     rcl = [int(x) for x in rc.tolist()]
-    recv = torch.empty(sum(rcl) * unit, dtype=torch.uint8, device=send.device)
+    recv = recv_alloc(sum(rcl)) if recv_alloc else torch.empty(sum(rcl) * unit, dtype=torch.uint8, device=send.device)
     comm.all_to_all_single(recv, send, [x * unit for x in rcl], [int(x) * unit for x in send_counts])
     return recv, rcl
 
@@ -70,6 +72,34 @@ class TorchComm:
         t = torch.tensor([value], dtype=torch.int64, device=device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
+
+
+class ReplicaComm:
+    """One rank of `world`, alone on its GPU: every peer is taken to hold the same reads as this rank, so
+    each of them sends this rank exactly what this rank sends to itself.  For rehearsing one rank's memory
+    plan and compute time at full scale on a single GPU (bench.py --emulate-world): the owned k-mers get
+    their full coverage, the volumes received are those of a real run; the transfers themselves cost a
+    device copy.  Answers to this rank's neighbour queries to other ranks are made up (all present)."""
+    rehearsal = True
+
+    def __init__(self, world):
+        self.rank, self.world = 0, world
+
+    def all_to_all_single(self, out, inp, out_split, in_split):
+        if in_split is None:                       # the counts: everybody sends what we send to ourselves
+            out.copy_(inp[:1].expand_as(out))
+            return
+        mine = inp[: in_split[0]]
+        at = 0
+        for n in out_split:
+            out[at : at + n].copy_(mine[:n])
+            at += n
+
+    def all_reduce_sum(self, value, device):
+        return value * self.world
+
+    def all_reduce_max(self, value, device):
+        return value
 
 
 def _view(ptr, nbytes, device):
@@ -114,6 +144,11 @@ class DistDfk(Dfk):
         counts = list(counts)
         return _view(ptr.value, 32 * sum(counts), self._device), counts
 
+    def recv_buffer(self, n_records):
+        ptr = C.c_void_p()
+        _check(lib().dfk_shard_recv_buffer(self._ctx, C.c_uint64(n_records), C.byref(ptr)))
+        return _view(ptr.value, 32 * n_records, self._device)
+
     def count_records(self, recv, pass_=0):
         _check(lib().dfk_shard_count(self._ctx, C.c_void_p(recv.data_ptr() if recv.numel() else 0), C.c_uint64(recv.numel() // 32),
                                      C.c_uint32(pass_)))
@@ -147,14 +182,17 @@ class DistDfk(Dfk):
         log2_passes = comm.all_reduce_max(self.plan(world, n_global), packed.device)   # every rank runs the same passes
         for p in range(1 << log2_passes):
             send, counts = self.partition(world, n_global, log2_passes, p)
-            recv, _ = exchange(send, counts, 32, comm)                    # the k-mer shuffle, one hash slice at a time
+            recv, _ = exchange(send, counts, 32, comm, self.recv_buffer)  # the k-mer shuffle, one bucket range at a time
             del send
             self.count_records(recv, p)
             del recv
         keys, kcounts = self.adj_queries(world)
         rkeys, rcounts = exchange(keys, kcounts, 16, comm)                 # neighbour queries
         answers = self.adj_answer(rkeys)
-        back, _ = exchange(answers, rcounts, 1, comm)                      # answers return in query order
+        if getattr(comm, "rehearsal", False):                              # no peers to answer: see ReplicaComm
+            back = torch.ones(sum(kcounts), dtype=torch.uint8, device=packed.device)
+        else:
+            back, _ = exchange(answers, rcounts, 1, comm)                  # answers return in query order
         self.adj_apply(back)
 
     def stats(self):
