@@ -4,6 +4,7 @@
 #include "dfk_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>

@@ -1222,65 +1222,122 @@ __device__ __forceinline__ uint32_t kmer_bucket(u128 F, const PartParams& pp)
 }
 
 // Neighbour look-ups the local tables could not settle, grouped by the rank that owns each neighbour.
-//   WRITE == false: per_owner[o] += number of queries for rank o
-//   WRITE == true : keys[base[o] + cursor[o]++] = canonical neighbour; src[...] = entry index << 3 | context bit
-// Each block handles slices of 256 entries: it counts per owner in LDS, reserves its ranges with one global
-// atomic per owner, then writes (same-address global atomics are far too slow to issue per wave).
-template <int K, bool WRITE>
-__global__ void __launch_bounds__(256)
-k_adj_queries(const uint4* __restrict__ entries, uint64_t n, PartParams pp, unsigned long long* __restrict__ per_owner,
-              const uint64_t* __restrict__ base, SetSlot* __restrict__ keys, uint64_t* __restrict__ src)
+// Three dense steps (about one solid k-mer in ten has such a look-up, and finding the owner of a neighbour
+// means sliding a minimizer window over it: done on sparse lanes that was most of a sharded run's adjacency
+// time):
+//   k_adj_list   entries -> list of (entry index << 3 | context bit)
+//   k_adj_owner  list -> canonical neighbour key and owner rank of every item; items per owner
+//   k_adj_place  keys and sources written grouped by owner
+// Blocks work in rounds of ADJ_ROUND items and touch a global counter once per round and owner
+// (same-address global atomics run at ~88 per microsecond chip-wide).
+constexpr int ADJ_PER_THREAD = 8, ADJ_ROUND = 256 * ADJ_PER_THREAD;
+
+// exclusive prefix of v over the 256 threads of a block; *total = block sum.  scratch: 8 words of LDS
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* scratch, uint32_t* total)
 {
-    __shared__ unsigned int cnt[64];
-    __shared__ unsigned long long start[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += scratch[w];
+    *total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return off + incl - v;
+}
+
+__global__ void __launch_bounds__(256)
+k_adj_list(const uint4* __restrict__ entries, uint64_t n, unsigned long long* __restrict__ n_items, uint64_t* __restrict__ list)
+{
+    __shared__ uint32_t scratch[8];
+    __shared__ unsigned long long base;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * ADJ_ROUND; i0 < n; i0 += (uint64_t)gridDim.x * ADJ_ROUND) {
+        uint32_t pend[ADJ_PER_THREAD], mine = 0;
+#pragma unroll
+        for (int k = 0; k < ADJ_PER_THREAD; ++k) {
+            const uint64_t i = i0 + 256ull * k + threadIdx.x;
+            pend[k] = i < n ? entries[2 * i + 1].w & 0xFFu : 0u;
+            mine += __popc(pend[k]);
+        }
+        uint32_t total;
+        uint32_t at = block_excl_scan_256(mine, scratch, &total);
+        if (threadIdx.x == 0) base = total && list ? atomicAdd(n_items, (unsigned long long)total) : 0ull;
+        if (!list) { if (threadIdx.x == 0 && total) atomicAdd(n_items, (unsigned long long)total); continue; }   // counting launch
+        __syncthreads();
+        const unsigned long long b = base;
+#pragma unroll
+        for (int k = 0; k < ADJ_PER_THREAD; ++k) {
+            const uint64_t i = i0 + 256ull * k + threadIdx.x;
+            for (uint32_t p = pend[k]; p; p &= p - 1) list[b + at++] = (i << 3) | (uint32_t)(__ffs(p) - 1);
+        }
+        __syncthreads();
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_adj_owner(const uint4* __restrict__ entries, const uint64_t* __restrict__ list, uint64_t n_items, PartParams pp,
+            SetSlot* __restrict__ tmp_keys, uint8_t* __restrict__ owner, unsigned long long* __restrict__ per_owner)
+{
+    __shared__ unsigned int cnt[256];
     const uint32_t world = 1u << pp.log2_world;
     const u128 m = KTraits<K>::mask();
-    auto neighbour = [&](u128 F, uint32_t bit) {
+    if (threadIdx.x < world) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < n_items; j += (uint64_t)gridDim.x * 256) {
+        const uint64_t s = list[j];
+        const uint32_t bit = (uint32_t)s & 7u;
+        const uint4 a = entries[2 * (s >> 3)];
+        const u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
+        const u128 F = shr128(kw, 128 - KTraits<K>::BITS);
         u128 v;
-        if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }
-        else {
+        if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }                // kmer[1:] + base
+        else {                                                                                      // base + kmer[:-1]
             v = shr128(F, 2);
             constexpr int TOP = KTraits<K>::BITS - 2;
             if (TOP >= 64) v.hi |= (uint64_t)(bit - 4) << (TOP - 64); else v.lo |= (uint64_t)(bit - 4) << TOP;
         }
-        return v;
-    };
-    const uint64_t n_round = (n + 255) / 256 * 256;
-    for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n_round; i0 += (uint64_t)gridDim.x * 256) {
-        const uint64_t i = i0 + threadIdx.x;
-        if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+        const uint32_t o = kmer_bucket<K>(v, pp) & (world - 1);
+        uint64_t w0, w1; canon_words<K>(v, &w0, &w1);
+        tmp_keys[j] = SetSlot{w0, w1};
+        owner[j] = (uint8_t)o;
+        atomicAdd(&cnt[o], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < world && cnt[threadIdx.x]) atomicAdd(&per_owner[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256)
+k_adj_place(const uint64_t* __restrict__ list, const SetSlot* __restrict__ tmp_keys, const uint8_t* __restrict__ owner, uint64_t n_items,
+            uint32_t world, const uint64_t* __restrict__ base, unsigned long long* __restrict__ fill,
+            SetSlot* __restrict__ keys, uint64_t* __restrict__ src)
+{
+    __shared__ unsigned int cnt[256];
+    __shared__ unsigned long long start[256];
+    for (uint64_t j0 = (uint64_t)blockIdx.x * ADJ_ROUND; j0 < n_items; j0 += (uint64_t)gridDim.x * ADJ_ROUND) {
+        if (threadIdx.x < world) cnt[threadIdx.x] = 0;
         __syncthreads();
-        uint32_t pending = 0; u128 F{0, 0};
-        if (i < n) {
-            pending = entries[2 * i + 1].w & 0xFFu;
-            if (pending) {
-                uint4 a = entries[2 * i];
-                u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
-                F = shr128(kw, 128 - KTraits<K>::BITS);
-            }
+        uint32_t own[ADJ_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < ADJ_PER_THREAD; ++k) {
+            const uint64_t j = j0 + 256ull * k + threadIdx.x;
+            own[k] = j < n_items ? owner[j] : 0xFFFFFFFFu;
+            if (own[k] != 0xFFFFFFFFu) atomicAdd(&cnt[own[k]], 1u);
         }
-        uint32_t owners = 0;                                          // 8 x 4-bit... owner ids can need 6 bits: keep per bit in a loop
-        for (uint32_t bit = 0; bit < 8; ++bit) if (pending & (1u << bit)) {
-            const uint32_t o = kmer_bucket<K>(neighbour(F, bit), pp) & (world - 1);
-            atomicAdd(&cnt[o], 1u);
-        }
-        (void)owners;
         __syncthreads();
         if (threadIdx.x < world) {
             const unsigned int c = cnt[threadIdx.x];
-            start[threadIdx.x] = c ? atomicAdd(&per_owner[threadIdx.x], (unsigned long long)c) : 0ull;
+            start[threadIdx.x] = base[threadIdx.x] + (c ? atomicAdd(&fill[threadIdx.x], (unsigned long long)c) : 0ull);
             cnt[threadIdx.x] = 0;
         }
         __syncthreads();
-        if (WRITE) {
-            for (uint32_t bit = 0; bit < 8; ++bit) if (pending & (1u << bit)) {
-                u128 v = neighbour(F, bit);
-                const uint32_t o = kmer_bucket<K>(v, pp) & (world - 1);
-                const uint64_t pos = base[o] + start[o] + atomicAdd(&cnt[o], 1u);
-                uint64_t w0, w1; canon_words<K>(v, &w0, &w1);
-                keys[pos] = SetSlot{w0, w1};
-                src[pos] = (i << 3) | bit;
-            }
+#pragma unroll
+        for (int k = 0; k < ADJ_PER_THREAD; ++k) {
+            const uint64_t j = j0 + 256ull * k + threadIdx.x;
+            if (own[k] == 0xFFFFFFFFu) continue;
+            const uint64_t pos = start[own[k]] + atomicAdd(&cnt[own[k]], 1u);
+            keys[pos] = tmp_keys[j];
+            src[pos] = list[j];
         }
         __syncthreads();
     }
