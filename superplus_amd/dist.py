@@ -31,7 +31,11 @@ def exchange(send: torch.Tensor, send_counts, unit: int, comm, recv_alloc=None):
     comm.all_to_all_single(rc, sc, None, None)
     rcl = [int(x) for x in rc.tolist()]
     recv = recv_alloc(sum(rcl)) if recv_alloc else torch.empty(sum(rcl) * unit, dtype=torch.uint8, device=send.device)
+    if send.is_cuda:
+        torch.cuda.synchronize(send.device)       # the library filled `send` on its own stream
     comm.all_to_all_single(recv, send, [x * unit for x in rcl], [int(x) * unit for x in send_counts])
+    if send.is_cuda:
+        torch.cuda.synchronize(send.device)       # ... and reads `recv` on it: the collective must have finished
     return recv, rcl
 
 
