@@ -72,6 +72,7 @@ struct dfk_ctx {
     std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
     unsigned seg_attempt = 0;                 // output segments are sized (estimate << seg_attempt)
+    double distinct_per_inst = 0.0;           // observed on the passes of the current run (sizes the work items)
     double plan_derate = 0.95;                // share of the free HBM a pass is planned into; lowered when a pass ran out (kept across runs)
     std::vector<int64_t> hist;
     std::vector<dfk_entry32> sorted, sorted_pre;
@@ -404,14 +405,24 @@ int pass_tables(dfk_ctx* c, const DevBuf& acc, uint32_t log2_sub, uint32_t world
 void release_pass(dfk_ctx* c, Partition* P)
 { c->release(P->records); c->release(P->base); c->release(P->ipre); c->release(P->items); }
 
-template <int K> constexpr uint64_t default_item_budget() { return (3ull << CountCfg<K>::LOG2S) / 2; }
+// Instances per work item: 1.5 x the table's slots to start with; once a pass has shown how many distinct
+// k-mers an instance brings (0.25 at K=48 and 58x, more at lower coverage or larger K), the next passes aim at
+// tables a good third full, which keeps the share of items that overflow their table near 0.3 %.
+template <int K> uint64_t item_budget(const dfk_ctx* c)
+{
+    constexpr uint64_t S = 1ull << CountCfg<K>::LOG2S;
+    if (c->cfg.inst_per_item) return c->cfg.inst_per_item;
+    if (c->distinct_per_inst <= 0.0) return 3 * S / 2;
+    const double b = 0.367 * (double)S / c->distinct_per_inst;
+    return (uint64_t)std::min(std::max(b, 0.5 * (double)S), 3.0 * (double)S);
+}
 
 template <int K>
 int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0,
                       uint32_t sub_lo, uint32_t sub_n, Partition* P)
 {
     const PartParams pp = part_params<K>(c, T.log2_nb, log2_world, read_id0, sub_lo, sub_n);
-    const uint64_t budget = c->cfg.inst_per_item ? c->cfg.inst_per_item : default_item_budget<K>();
+    const uint64_t budget = item_budget<K>(c);
     int rc = pass_tables(c, T.acc, T.log2_nb - log2_world, 1u << log2_world, sub_lo, sub_n, budget, P); if (rc) return rc;
     const uint64_t nb = P->nb;
     DevBuf cur, d_bad;
@@ -699,6 +710,7 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
     c->parts.push_back(part);
     c->n_solid += part.n; c->st.n_solid = c->n_solid;
     R.solid_seen += part.n; R.inst_seen += P.n_inst;
+    if (R.inst_seen) c->distinct_per_inst = (double)hg.n_distinct / (double)R.inst_seen;
     return 0;
 }
 
@@ -816,7 +828,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     const uint32_t forced = (uint32_t)c->cfg.reserved[0];            // dfk_config.reserved[0] = forced number of passes (tests)
     const uint32_t per_forced = forced ? std::max<uint32_t>(1, (sub_nb + forced - 1) / forced) : 0;
     uint32_t lo = 0, n_passes = 0, retries = 0;
-    c->seg_attempt = 0;
+    c->seg_attempt = 0; c->distinct_per_inst = 0.0;
     while (lo < sub_nb) {
         const uint32_t n = forced ? std::min(per_forced, sub_nb - lo) : plan_range(c, T, R, sub_nb, lo);
         TRACE("pass %u: buckets [%u, %u) of %u (%.1f %%), %.2f GB held of %.2f", n_passes + 1, lo, lo + n, sub_nb, 100.0 * n / sub_nb,

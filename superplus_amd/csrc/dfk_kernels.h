@@ -499,7 +499,7 @@ struct CountGlobals {                // device-resident counters
     unsigned long long n_boundary;   // solid entries left with unresolved (cross-item) context bits
 };
 
-constexpr int COUNT_HIST_BINS = 1024;
+constexpr int COUNT_HIST_BINS = 256;             // spectrum bins kept in LDS; higher counts go straight to the global bins
 constexpr uint32_t COUNT_MAX_PROBE = 96;
 constexpr uint32_t HIST_GLOBAL_BINS = 1u << 24;   // KDef count saturates at 2^24-1 (ReadPather.h:128-129)
 constexpr int COUNT_CHUNK = 32;                   // records a wave stages at a time
@@ -940,8 +940,8 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     uint32_t* hist = bcw + S;                       // [COUNT_HIST_BINS]
     uint32_t* ctl = hist + COUNT_HIST_BINS;         // [CTL_N]
     uint32_t* tasks = ctl + CTL_N;                  // [S] neighbour look-up queue
-    uint16_t* solid_list = reinterpret_cast<uint16_t*>(tasks + S);     // [S] solid slots of the item being finished
-    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(tasks + S + S / 2);
+    uint16_t* solid_list = reinterpret_cast<uint16_t*>(tasks + S / 2); // [S] solid slots of the item being finished  (tasks: [S/2])
+    WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(tasks + S / 2 + S / 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WaveStage<K>* st = stages + wave;
     uint4* seg_out = out + 2ull * cp.seg_cap * blockIdx.x;
@@ -997,7 +997,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
 #else
             uint32_t occ =
 #endif
-            table_finish<K, USE_BC, true, S>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
+            table_finish<K, USE_BC, true, S / 2>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
                                                          &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
                                                          &ctl[CTL_BOUNDARY], solid_list, &ctl[CTL_NSOLID], tid, NT);
 #pragma unroll
@@ -1023,7 +1023,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
 template <int K, int LOG2S, int NWAVES>
 constexpr size_t count_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + (1u << LOG2S) + (1u << LOG2S) / 2) + sizeof(WaveStage<K>) * NWAVES;
+    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + (1u << LOG2S) / 2 + (1u << LOG2S) / 2) + sizeof(WaveStage<K>) * NWAVES;
 }
 
 // Fallback: one workgroup per overflowed item, table in HBM (tab = [KW+3][S] words, zeroed by
