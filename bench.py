@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--inst-per-item", type=int, default=0)
     ap.add_argument("--cpu-sample-reads", type=int, default=600000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--family-copies", type=int, default=0,
+                    help="plant this many diverged copies of one 300-bp element in the genome (hot minimizer buckets)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="rehearsal on one GPU: run rank 0 of this many ranks against replicas of itself (not a benchmark result)")
     args = ap.parse_args()
@@ -137,7 +139,7 @@ def main():
     lo, hi = rank * total_pairs // world, (rank + 1) * total_pairs // world          # this rank's pair range
     if args.emulate_world > 1:
         lo, hi = 0, total_pairs // args.emulate_world
-    genome = synth.make_genome(G, 20261004, device=dev)                               # same genome on every rank
+    genome = synth.make_genome(G, 20261004, device=dev, family_copies=args.family_copies)   # same genome on every rank
     rs = synth.make_reads(genome, hi - lo, 20261004 + 17 * (rank + 1))
     del genome
     if world > 1:      # barcode ids must not collide between ranks
@@ -204,7 +206,8 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[%d]: " % (1 if world == 1 else 2) if full else "scaled-down run: ") +
                                    f"synthetic stLFR, {total_pairs} pairs 2x100 bp over a {args.genome_mb:g} Mb random genome "
-                                   f"({200.0 * total_pairs / G:.1f}x), 0.5% subst., 10% unbarcoded, K={args.K}, MIN_FREQ=3, MIN_BC=2, MIN_QUAL=7",
+                                   f"({200.0 * total_pairs / G:.1f}x), 0.5% subst., 10% unbarcoded, K={args.K}, MIN_FREQ=3, MIN_BC=2, MIN_QUAL=7" +
+                                   (f", {args.family_copies} copies of a 300-bp repeat family" if args.family_copies else ""),
                        "reads_total": 2 * total_pairs, "kmer_instances_total": n_inst, "K": args.K,
                        "parallelism": "single GPU, bucket-range passes" if world == 1 else
                                       f"{world} ranks: read shards, all-to-all of super-k-mer records by minimizer bucket"},

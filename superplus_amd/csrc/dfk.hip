@@ -594,31 +594,62 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->release(d_idx); c->release(d_val);
     std::vector<BigItem> items; uint64_t words = 0, tot_inst = 0;
+    std::vector<uint64_t> chunk_pre(n + 1, 0), slot_pre(n + 1, 0), rec(2 * n);
+    // record ranges of the items (for the chunk tickets)
+    {
+        DevBuf d_i2, d_v2;
+        rc = c->alloc(d_i2, 8ull * n, "gather index"); if (rc) return rc;
+        rc = c->alloc(d_v2, 16ull * n, "gather values"); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(d_i2.p, idx.data(), 8ull * n, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_u64, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, (const uint64_t*)P.base.p,
+                           (const uint32_t*)d_i2.p, 2 * n, (uint64_t*)d_v2.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(rec.data(), d_v2.p, 16ull * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->release(d_i2); c->release(d_v2);
+    }
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t inst = val[2 * i + 1] - val[2 * i];
         tot_inst += inst;
         uint32_t l2 = std::max<uint32_t>(13, ceil_log2(2 * inst + 64));
         items.push_back(BigItem{singles[i].b0, singles[i].b1, words, l2, 0});
         words += (uint64_t)(KW + 3) << l2;
+        chunk_pre[i + 1] = chunk_pre[i] + (rec[2 * i + 1] - rec[2 * i] + COUNT_CHUNK - 1) / COUNT_CHUNK;
+        slot_pre[i + 1] = slot_pre[i] + (1ull << l2);
     }
-    DevBuf pool, d_items, d_fail;
+    DevBuf pool, d_items, d_fail, d_pre;
     R.big_cap = tot_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;   // every solid k-mer has >= min_freq instances
     rc = c->alloc(R.big, R.big_cap * 32, "fallback solid entries"); if (rc) return rc;
     rc = c->alloc(pool, words * 4, "HBM fallback tables"); if (rc) return rc;
     rc = c->alloc(d_items, items.size() * sizeof(BigItem), "fallback items"); if (rc) return rc;
+    rc = c->alloc(d_pre, 16ull * (n + 1), "fallback prefixes"); if (rc) return rc;
     rc = c->alloc(d_fail, 16, "fallback flag"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(pool.p, 0, words * 4, c->stream));
     HIP_TRY(hipMemsetAsync(d_fail.p, 0, 16, c->stream));
     HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice, c->stream));
+    uint64_t* d_chunk_pre = (uint64_t*)d_pre.p; uint64_t* d_slot_pre = d_chunk_pre + (n + 1);
+    HIP_TRY(hipMemcpyAsync(d_chunk_pre, chunk_pre.data(), 8ull * (n + 1), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_slot_pre, slot_pre.data(), 8ull * (n + 1), hipMemcpyHostToDevice, c->stream));
     CountParams cpb = R.cp; cpb.seg_cap = R.big_cap; cpb.n_segments = 1;   // one segment: the fallback's own buffer
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_big<K, NW, USE_BC>), dim3((unsigned)items.size()), dim3(NW * 64), 0, c->stream,
-                       (const uint4*)P.records.p, (const BigItem*)d_items.p, (const uint64_t*)P.base.p, cpb, R.g, (uint4*)R.big.p, R.hist,
-                       (uint32_t*)pool.p, (uint32_t*)d_fail.p);
+    // the whole grid works on the fallback tables together (d_fail + 8: the chunk ticket)
+    const unsigned cus = (unsigned)c->prop.multiProcessorCount;
+    const unsigned g_ins = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + NW * BIG_TICKET_CHUNKS - 1) / (NW * BIG_TICKET_CHUNKS), 4ull * cus));
+    const unsigned g_slot = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((slot_pre[n] + 255) / 256, 16ull * cus));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_insert<K, NW, USE_BC>), dim3(g_ins), dim3(NW * 64), 0, c->stream,
+                       (const uint4*)P.records.p, (const BigItem*)d_items.p, (const uint64_t*)P.base.p, (const uint64_t*)d_chunk_pre, n,
+                       (uint32_t*)pool.p, (unsigned long long*)d_fail.p + 1, (uint32_t*)d_fail.p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_flags<K, USE_BC>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
+                       (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p, cpb, R.g);
+    if (cpb.do_adj)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_resolve<K>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
+                           (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_emit<K>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
+                       (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p, cpb, R.g, (uint4*)R.big.p, R.hist);
     HIP_TRY(hipGetLastError());
     uint32_t failed = 0;
     HIP_TRY(hipMemcpyAsync(&failed, d_fail.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->release(pool); c->release(d_items); c->release(d_fail);
+    c->release(pool); c->release(d_items); c->release(d_fail); c->release(d_pre);
     if (failed) return fail(DFK_E_HIP, "HBM fallback table overflowed (should be impossible at load <= 0.5)");
     return 0;
 }

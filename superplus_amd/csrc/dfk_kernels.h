@@ -491,7 +491,7 @@ struct CountParams {
 
 struct CountGlobals {                // device-resident counters
     unsigned long long n_distinct;
-    unsigned long long big_cursor;   // entries written to the last segment by k_count_big
+    unsigned long long big_cursor;   // entries written to the fallback buffer by k_big_emit
     unsigned int next_item;
     unsigned int n_overflow;         // items that overflowed their table
     unsigned int solid_overflow;     // an output segment ran out of room
@@ -1026,46 +1026,165 @@ constexpr size_t count_lds_bytes()
     return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + (1u << LOG2S) / 2 + (1u << LOG2S) / 2) + sizeof(WaveStage<K>) * NWAVES;
 }
 
-// Fallback: one workgroup per overflowed item, table in HBM (tab = [KW+3][S] words, zeroed by
-// the host), staging still in LDS.  Same insertion code; atomics resolve to global memory.
-// Output goes to the last segment through a global cursor.
+// Fallback for a fine bucket that cannot fit an LDS table: its table lives in HBM (tab = [KW+3][S] words,
+// zeroed by the host, load <= 0.5) and the WHOLE GRID works on it -- a single minimizer can own a sizeable
+// share of a real genome's k-mers (low-complexity and repeat-derived m-mers), so one workgroup per such
+// bucket would serialise the run.  Four launches over all fallback items of a pass together:
+//   k_big_insert   waves pull chunks of 32 records through a global ticket and insert with the same code
+//                  as k_count (atomics at agent scope on the HBM table)
+//   k_big_flags    per slot: solid or not
+//   k_big_resolve  per solid slot and context bit: neighbour in the same table?  (as table_finish pass 2)
+//   k_big_emit     solid slots to the fallback's output buffer through a global cursor, spectrum, counters
 struct BigItem { uint32_t b0, b1; uint64_t tab_off; uint32_t log2s; uint32_t pad; };
+constexpr int BIG_TICKET_CHUNKS = 4;                 // chunks a wave takes per ticket
+
+// item that owns position x of the concatenated chunk / slot space (pre[] ascending, pre[0] = 0, pre[n] = total)
+__device__ __forceinline__ uint32_t big_find(const uint64_t* __restrict__ pre, uint32_t n, uint64_t x)
+{
+    uint32_t lo = 0, hi = n;                         // pre[lo] <= x < pre[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
 
 template <int K, int NWAVES, bool USE_BC>
 __global__ void __launch_bounds__(NWAVES * 64)
-k_count_big(const uint4* __restrict__ records, const BigItem* __restrict__ items, const uint64_t* __restrict__ rec_base, CountParams cp,
-            CountGlobals* __restrict__ g, uint4* __restrict__ out, unsigned long long* __restrict__ hist_global,
-            uint32_t* __restrict__ tab_pool, uint32_t* __restrict__ failed)
+k_big_insert(const uint4* __restrict__ records, const BigItem* __restrict__ items, const uint64_t* __restrict__ rec_base,
+             const uint64_t* __restrict__ chunk_pre, uint32_t n_items, uint32_t* __restrict__ tab_pool,
+             unsigned long long* __restrict__ ticket, uint32_t* __restrict__ failed)
 {
     constexpr int KW = KTraits<K>::KW;
-    constexpr int NT = NWAVES * 64;
     __shared__ WaveStage<K> stages[NWAVES];
-    __shared__ uint32_t ctl[CTL_N];
-    __shared__ uint32_t tasks[ADJ_TASKS_BIG];
-    const BigItem it = items[blockIdx.x];
-    const uint32_t S = 1u << it.log2s;
-    uint32_t* keys = tab_pool + it.tab_off;
-    uint32_t* cnt = keys + (size_t)KW * S;
-    uint32_t* ctxs = cnt + S;
-    uint32_t* bcw = ctxs + S;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_NTASK] = 0; ctl[CTL_BOUNDARY] = 0; }
+    __shared__ uint32_t fill, ovf;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { fill = 0; ovf = 0; }
     __syncthreads();
-    const uint64_t rec_begin = rec_base[it.b0], rec_end = rec_base[it.b1];
-    for (uint64_t c = rec_begin + (uint64_t)COUNT_CHUNK * wave; c < rec_end; c += (uint64_t)COUNT_CHUNK * NWAVES)
-        wave_count_chunk<K, USE_BC, false>(records, c, rec_end, &stages[wave], lane, keys, cnt, ctxs, bcw, S, &ctl[CTL_FILL], &ctl[CTL_OVF]);
-    __threadfence();
+    const uint64_t n_chunks = chunk_pre[n_items];
+    for (uint32_t guard = 0; guard < 0x7FFFFFFFu; ++guard) {                 // every wave leaves when the tickets run out
+        unsigned long long t0 = 0;
+        if (lane == 0) t0 = atomicAdd(ticket, (unsigned long long)BIG_TICKET_CHUNKS);
+        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)t0);
+        if (first >= n_chunks) break;
+        for (int k = 0; k < BIG_TICKET_CHUNKS; ++k) {
+            const uint64_t t = first + k;
+            if (t >= n_chunks) break;
+            const uint32_t it = big_find(chunk_pre, n_items, t);
+            const BigItem I = items[it];
+            const uint32_t S = 1u << I.log2s;
+            uint32_t* keys = tab_pool + I.tab_off;
+            uint32_t* cnt = keys + (size_t)KW * S;
+            const uint64_t rb = rec_base[I.b0] + (t - chunk_pre[it]) * COUNT_CHUNK;
+            wave_count_chunk<K, USE_BC, false>(records, rb, rec_base[I.b1], &stages[wave], lane, keys, cnt, cnt + S, cnt + 2 * (size_t)S, S, &fill, &ovf);
+        }
+    }
     __syncthreads();
-    if (ctl[CTL_OVF]) { if (tid == 0) atomicOr(failed, 1u); return; }
-    uint4* seg_out = out;                                             // the fallback's own buffer, cp.seg_cap entries
-    uint32_t occ = table_finish<K, USE_BC, false, ADJ_TASKS_BIG>(keys, cnt, ctxs, bcw, S, cp, seg_out, &g->big_cursor, nullptr,
-                                                  &g->solid_overflow, nullptr, hist_global, tasks, &ctl[CTL_NTASK],
-                                                  &ctl[CTL_BOUNDARY], nullptr, nullptr, tid, NT);
+    if (threadIdx.x == 0 && ovf) atomicOr(failed, 1u);
+}
+
+template <int K> struct BigView { uint32_t* keys; uint32_t* cnt; uint32_t* ctxs; uint32_t* bcw; uint32_t S, slot; };
+template <int K>
+__device__ __forceinline__ BigView<K> big_view(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_pre, uint32_t n_items,
+                                               uint32_t* __restrict__ tab_pool, uint64_t x)
+{
+    const uint32_t it = big_find(slot_pre, n_items, x);
+    const BigItem I = items[it];
+    const uint32_t S = 1u << I.log2s;
+    uint32_t* keys = tab_pool + I.tab_off;
+    uint32_t* cnt = keys + (size_t)KTraits<K>::KW * S;
+    return BigView<K>{keys, cnt, cnt + S, cnt + 2 * (size_t)S, S, (uint32_t)(x - slot_pre[it])};
+}
+
+template <int K, bool USE_BC>
+__global__ void __launch_bounds__(256)
+k_big_flags(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_pre, uint32_t n_items, uint32_t* __restrict__ tab_pool,
+            CountParams cp, CountGlobals* __restrict__ g)
+{
+    const uint64_t total = slot_pre[n_items];
+    uint32_t occ = 0;
+    for (uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x; x < total; x += (uint64_t)gridDim.x * 256) {
+        const BigView<K> v = big_view<K>(items, slot_pre, n_items, tab_pool, x);
+        const uint32_t c = tld(&v.cnt[v.slot]);
+        if (!c) continue;
+        ++occ;
+        const bool solid = (c & CNT_MASK) >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&v.bcw[v.slot]) : 0u, cp.min_bc);
+        if (solid && cp.do_adj && cp.keep_pre) { const uint32_t ctx = tld(&v.ctxs[v.slot]) & 0xFFu; tst(&v.ctxs[v.slot], ctx | (ctx << 8)); }
+        tst(&v.bcw[v.slot], solid ? FLAG_SOLID : 0u);
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
-    if (lane == 0 && occ) atomicAdd(&g->n_distinct, (unsigned long long)occ);
-    __syncthreads();
-    if (tid == 0 && ctl[CTL_BOUNDARY]) atomicAdd(&g->n_boundary, (unsigned long long)ctl[CTL_BOUNDARY]);
+    if ((threadIdx.x & 63) == 0 && occ) atomicAdd(&g->n_distinct, (unsigned long long)occ);
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_big_resolve(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_pre, uint32_t n_items, uint32_t* __restrict__ tab_pool)
+{
+    constexpr int KW = KTraits<K>::KW;
+    const uint64_t total = slot_pre[n_items];
+    const u128 m = KTraits<K>::mask();
+    for (uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x; x < total; x += (uint64_t)gridDim.x * 256) {
+        const BigView<K> v = big_view<K>(items, slot_pre, n_items, tab_pool, x);
+        if (!tld(&v.cnt[v.slot]) || !(tld(&v.bcw[v.slot]) & FLAG_SOLID)) continue;
+        const uint32_t S = v.S, slot = v.slot;
+        const u128 F{(uint64_t)tld(&v.keys[slot]) | ((uint64_t)tld(&v.keys[S + slot]) << 32),
+                     (uint64_t)tld(&v.keys[2 * (size_t)S + slot]) | (KW == 4 ? ((uint64_t)tld(&v.keys[3 * (size_t)S + slot]) << 32) : 0ull)};
+        for (uint32_t ctx = tld(&v.ctxs[slot]) & 0xFFu; ctx; ctx &= ctx - 1) {
+            const uint32_t bit = (uint32_t)__ffs(ctx) - 1u;
+            u128 nb;
+            if (bit < 4) { nb = shl128(F, 2); nb.lo &= m.lo; nb.hi &= m.hi; nb.lo |= bit; }
+            else {
+                nb = shr128(F, 2);
+                constexpr int TOP = KTraits<K>::BITS - 2;
+                if (TOP >= 64) nb.hi |= (uint64_t)(bit - 4) << (TOP - 64); else nb.lo |= (uint64_t)(bit - 4) << TOP;
+            }
+            const uint32_t f = table_find<KW>(v.keys, v.cnt, S, canon_value<K>(nb));
+            if (f == ~0u) atomicOr(&v.bcw[slot], 1u << bit);                                      // lives in another item
+            else if (!(tld(&v.bcw[f]) & FLAG_SOLID)) atomicAnd(&v.ctxs[slot], ~(1u << bit));      // here, and not solid
+        }
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_big_emit(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_pre, uint32_t n_items, uint32_t* __restrict__ tab_pool,
+           CountParams cp, CountGlobals* __restrict__ g, uint4* __restrict__ out, unsigned long long* __restrict__ hist_global)
+{
+    constexpr int KW = KTraits<K>::KW;
+    const uint64_t total = slot_pre[n_items];
+    const int lane = threadIdx.x & 63;
+    uint32_t boundary = 0;
+    const uint64_t rounds = (total + (uint64_t)gridDim.x * 256 - 1) / ((uint64_t)gridDim.x * 256);
+    for (uint64_t r = 0; r < rounds; ++r) {                                    // whole waves stay together for the ballot
+        const uint64_t x = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        bool solid = false; BigView<K> v{}; uint32_t c = 0, flags = 0;
+        if (x < total) {
+            v = big_view<K>(items, slot_pre, n_items, tab_pool, x);
+            c = tld(&v.cnt[v.slot]);
+            flags = c ? tld(&v.bcw[v.slot]) : 0u;
+            solid = (flags & FLAG_SOLID) != 0;
+        }
+        const unsigned long long mk = __ballot(solid);
+        if (!mk) continue;
+        unsigned long long wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&g->big_cursor, (unsigned long long)__popcll(mk));
+        wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
+        if (!solid) continue;
+        const uint32_t S = v.S, slot = v.slot, count = c & CNT_MASK;
+        const uint32_t cw = tld(&v.ctxs[slot]);
+        const uint32_t pending = flags & 0xFFu & cw;
+        boundary += pending != 0;
+        const unsigned long long idx = wbase + __popcll(mk & ((1ull << lane) - 1ull));
+        if (idx < cp.seg_cap) {
+            const u128 kv{(uint64_t)tld(&v.keys[slot]) | ((uint64_t)tld(&v.keys[S + slot]) << 32),
+                          (uint64_t)tld(&v.keys[2 * (size_t)S + slot]) | (KW == 4 ? ((uint64_t)tld(&v.keys[3 * (size_t)S + slot]) << 32) : 0ull)};
+            const u128 kw = shl128(kv, 128 - KTraits<K>::BITS);
+            out[2 * idx] = uint4{(uint32_t)kw.hi, (uint32_t)(kw.hi >> 32), (uint32_t)kw.lo, (uint32_t)(kw.lo >> 32)};
+            out[2 * idx + 1] = uint4{0xFFFFFFFFu, count | ((cw & 0xFFu) << 24), 0xFFFFFFFFu, pending | (cw & 0xFF00u)};
+        } else atomicOr(&g->solid_overflow, 1u);
+        atomicAdd(&hist_global[count], 1ull);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) boundary += __shfl_down(boundary, d, 64);
+    if (lane == 0 && boundary) atomicAdd(&g->n_boundary, (unsigned long long)boundary);
 }
 
 // Gather the output segments into one dense array: block b copies a slice of segment blockIdx.y.

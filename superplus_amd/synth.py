@@ -39,8 +39,10 @@ class ReadSet:
         )
 
 
-def make_genome(size, seed, device="cpu", repeat_frac=0.0):
-    if torch.device(device).type != "cpu" and repeat_frac == 0:
+def make_genome(size, seed, device="cpu", repeat_frac=0.0, family_copies=0, family_len=300, family_div=0.10):
+    """family_copies > 0 plants that many diverged copies (substitution rate family_div) of ONE random
+    family_len-bp element, Alu-like: a few minimizers then own a large share of the k-mers (hot buckets)."""
+    if torch.device(device).type != "cpu" and repeat_frac == 0 and family_copies == 0:
         g = torch.Generator(device=device).manual_seed(seed)
         return torch.randint(0, 4, (size,), generator=g, dtype=torch.uint8, device=device)
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -53,6 +55,15 @@ def make_genome(size, seed, device="cpu", repeat_frac=0.0):
         ln = torch.randint(1000, 2000, (n_rep,), generator=g)
         for s, d, l in zip(src.tolist(), dst.tolist(), ln.tolist()):
             genome[d : d + l] = genome[s : s + l].clone()
+    if family_copies > 0 and size > 4 * family_len:
+        elem = torch.randint(0, 4, (family_len,), generator=g, dtype=torch.uint8)
+        pos = torch.randint(0, size - family_len, (family_copies,), generator=g)
+        copies = elem[None, :].repeat(family_copies, 1)
+        hit = torch.rand(copies.shape, generator=g) < family_div
+        sub = torch.randint(1, 4, copies.shape, generator=g, dtype=torch.uint8)
+        copies = torch.where(hit, (copies + sub) & 3, copies)
+        idx = pos[:, None] + torch.arange(family_len)[None, :]
+        genome[idx.reshape(-1)] = copies.reshape(-1)
     return genome.to(device)
 
 

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+from superplus_amd import synth
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -150,7 +151,7 @@ def test_result_independent_of_partition_geometry(oracle):
 
 def test_single_bucket_overflow_uses_hbm_table(oracle):
     """Tens of thousands of distinct k-mers that all contain one A14 (the smallest possible minimizer hash)
-    land in ONE fine bucket; it cannot be split, so it is counted in the HBM table (k_count_big)."""
+    land in ONE fine bucket; it cannot be split, so it is counted in an HBM table (k_big_insert and friends)."""
     rng = np.random.default_rng(9)
     reads, quals, bc = [], [], []
     for i in range(3000):
@@ -173,3 +174,14 @@ def test_hash_slice_passes(oracle, passes):
     ref, d = util.run_both(oracle, rs, K=48, passes=passes)
     st = util.check_parity(ref, d)
     assert st["n_passes"] == passes
+
+
+def test_repeat_family_hot_minimizers(oracle):
+    """An Alu-like family (many diverged copies of one element): a few minimizers own tens of thousands of
+    distinct k-mers each, far beyond an LDS table.  Those buckets are counted in HBM tables by the whole
+    grid (k_big_insert / k_big_flags / k_big_resolve / k_big_emit)."""
+    genome = synth.make_genome(1_500_000, 77, family_copies=1500)
+    rs = synth.make_reads(genome, 225_000, 78).numpy()
+    ref, d = util.run_both(oracle, rs, K=48)
+    st = util.check_parity(ref, d)
+    assert st["n_overflow_items"] > 100
