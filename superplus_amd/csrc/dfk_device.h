@@ -67,6 +67,12 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
     return x;
 }
 
+// Rank of a canonical m-mer among the candidates for minimizer (smaller wins).  The salt keeps poly-A --
+// value 0, the most frequent 16-mer of real genomes -- from being the global minimum: mix32(0) = 0.
+// The one m-mer that does hash to 0 is the salt itself, AGTACGGTATGCTCAC.
+constexpr uint32_t MMER_SALT = 0x2C6B39D1u;
+__device__ __forceinline__ uint32_t mmer_hash(uint32_t canon) { return mix32(canon ^ MMER_SALT); }
+
 // slot hash of a canonical k-mer (2K-bit value) for the LDS / HBM tables
 __device__ __forceinline__ uint32_t key_hash(u128 c)
 {

@@ -251,7 +251,7 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
         f = ((f << 2) | b) & mmask;
         rc = (rc >> 2) | ((3u - b) << rsh);
         if (j + 1 < M) continue;
-        uint32_t h = mix32(f < rc ? f : rc);
+        uint32_t h = mmer_hash(f < rc ? f : rc);
         const bool newmin = bi == 0 || h < P;
         P = newmin ? h : P;
         if (!WRITE) Pi = newmin ? bi : Pi;
@@ -392,7 +392,7 @@ __device__ __forceinline__ void for_each_run_in_pass(uint64_t r, const uint8_t* 
             uint32_t y = __brev(x);
             y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
             const uint32_t fw = y >> (32 - 2 * M), rcv = ~x & mmask;             // the scan's forward / reverse-complement values
-            const uint32_t bucket = bucket_of(mix32(fw < rcv ? fw : rcv), pp);
+            const uint32_t bucket = bucket_of(mmer_hash(fw < rcv ? fw : rcv), pp);
             const uint32_t lb = pass_local(bucket, pp);
             if (lb != 0xFFFFFFFFu) f(s0, nk, lb, bucket >> (pp.log2_nb - pp.log2_world), bit0);
             s0 += nk;
@@ -1334,7 +1334,7 @@ __device__ __forceinline__ uint32_t kmer_bucket(u128 F, const PartParams& pp)
         const uint32_t b = (uint32_t)(sh >= 64 ? (F.hi >> (sh - 64)) : (F.lo >> sh)) & 3u;
         f = ((f << 2) | b) & mmask;
         rc = (rc >> 2) | ((3u - b) << rsh);
-        if (i + 1 >= (int)M) { uint32_t h = mix32(f < rc ? f : rc); mv = h < mv ? h : mv; }
+        if (i + 1 >= (int)M) { uint32_t h = mmer_hash(f < rc ? f : rc); mv = h < mv ? h : mv; }
     }
     uint32_t bucket = (mv * 0x9E3779B1u) >> (32 - pp.log2_nb);
     return bucket;                       // owner rank = bucket & (world-1)

@@ -150,13 +150,15 @@ def test_result_independent_of_partition_geometry(oracle):
 
 
 def test_single_bucket_overflow_uses_hbm_table(oracle):
-    """Tens of thousands of distinct k-mers that all contain one A14 (the smallest possible minimizer hash)
-    land in ONE fine bucket; it cannot be split, so it is counted in an HBM table (k_big_insert and friends)."""
+    """Tens of thousands of distinct k-mers that all contain AGTACGGTATGCTCAC -- the one 16-mer whose minimizer
+    hash is 0 (dfk_device.h: MMER_SALT) -- land in ONE fine bucket; it cannot be split, so it is counted in an
+    HBM table (k_big_insert and friends)."""
     rng = np.random.default_rng(9)
+    hot = np.array(["ACGT".index(ch) for ch in "AGTACGGTATGCTCAC"], np.uint8)
     reads, quals, bc = [], [], []
     for i in range(3000):
         r = rng.integers(0, 4, 100, dtype=np.uint8)
-        r[43:57] = 0
+        r[42:58] = hot
         if i % 3 == 0:                          # some exact duplicates so that solid k-mers exist
             r = reads[-1].copy() if reads else r
         reads.append(r); quals.append(np.full(100, 30, np.uint8)); bc.append(1 + i % 5)
