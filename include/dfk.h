@@ -134,6 +134,9 @@ int dfk_spectrum_json(dfk_ctx* ctx, char* out, uint64_t cap, uint64_t* need);
  * kmers.kvec view (contexts before; needs DFK_F_KEEP_PRE_ADJ). */
 int dfk_solid_count(dfk_ctx* ctx, uint64_t* n);
 int dfk_solid_fetch(dfk_ctx* ctx, dfk_entry32* out, uint64_t cap, int pre_adjacency);
+/* The same entries in the order the device holds them (one copy per pass, no sort): what a caller that
+ * inserts them into its own dictionary needs -- the reference's kmers.kvec is in thread-arrival order too. */
+int dfk_solid_fetch_unsorted(dfk_ctx* ctx, dfk_entry32* out, uint64_t cap, int pre_adjacency);
 
 /* kmers.kvec image ("BINWRITE" | u64 n | n x 32-B entries; BuildReadQGraph48.cc:287-288,
  * feudal/BinaryStream.h:33-46) written straight to a file. */

@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace dfk;
@@ -910,6 +912,33 @@ int run(dfk_ctx* c, const Inputs& in)
     return rc == E_SEGMENT_FULL ? DFK_E_NOMEM : rc;
 }
 
+// Ascending (w0, w1) on the host cores: one most-significant-digit pass (12 bits of w0) over per-thread slices,
+// then the 4096 key ranges are sorted independently by a pool of threads.  A human-scale dictionary is
+// 3x10^9 entries; a single std::sort of that takes many minutes.
+void host_sort_entries(std::vector<dfk_entry32>& v)
+{
+    const auto less = [](const dfk_entry32& a, const dfk_entry32& b) { return a.w0 != b.w0 ? a.w0 < b.w0 : a.w1 < b.w1; };
+    const uint64_t n = v.size();
+    const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<uint64_t>(1, n >> 14));
+    if (T <= 1) { std::sort(v.begin(), v.end(), less); return; }
+    constexpr unsigned B = 4096, SH = 52;
+    std::vector<dfk_entry32> tmp(n);
+    std::vector<uint64_t> cnt((size_t)T * B, 0);
+    auto slice = [&](unsigned t) { return std::pair<uint64_t, uint64_t>(n * t / T, n * (t + 1) / T); };
+    auto run = [&](auto&& body) { std::vector<std::thread> th; for (unsigned t = 0; t < T; ++t) th.emplace_back(body, t); for (auto& x : th) x.join(); };
+    run([&](unsigned t) { auto [a, b] = slice(t); uint64_t* c = &cnt[(size_t)t * B]; for (uint64_t i = a; i < b; ++i) ++c[v[i].w0 >> SH]; });
+    std::vector<uint64_t> start(B + 1, 0);
+    {   // bucket-major, thread-minor offsets
+        uint64_t at = 0;
+        for (unsigned b = 0; b < B; ++b) { start[b] = at; for (unsigned t = 0; t < T; ++t) { const uint64_t c = cnt[(size_t)t * B + b]; cnt[(size_t)t * B + b] = at; at += c; } }
+        start[B] = at;
+    }
+    run([&](unsigned t) { auto [a, b] = slice(t); uint64_t* c = &cnt[(size_t)t * B]; for (uint64_t i = a; i < b; ++i) tmp[c[v[i].w0 >> SH]++] = v[i]; });
+    std::atomic<unsigned> next{0};
+    run([&](unsigned) { for (unsigned b; (b = next.fetch_add(1)) < B;) std::sort(tmp.begin() + start[b], tmp.begin() + start[b + 1], less); });
+    v.swap(tmp);
+}
+
 int fetch_sorted(dfk_ctx* c, bool pre, std::vector<dfk_entry32>** out)
 {
     std::vector<dfk_entry32>& v = pre ? c->sorted_pre : c->sorted;
@@ -923,8 +952,7 @@ int fetch_sorted(dfk_ctx* c, bool pre, std::vector<dfk_entry32>** out)
             if (pt.n) HIP_TRY(hipMemcpy(v.data() + at, src.p, pt.n * 32, hipMemcpyDeviceToHost));
             at += pt.n;
         }
-        std::sort(v.begin(), v.end(), [](const dfk_entry32& a, const dfk_entry32& b) {
-            return a.w0 != b.w0 ? a.w0 < b.w0 : a.w1 < b.w1; });
+        host_sort_entries(v);
         ok = true;
     }
     *out = &v;
@@ -1079,6 +1107,21 @@ int dfk_solid_fetch(dfk_ctx* c, dfk_entry32* out, uint64_t cap, int pre)
     std::vector<dfk_entry32>* v = nullptr;
     int rc = fetch_sorted(c, pre != 0, &v); if (rc) return rc;
     if (!v->empty()) memcpy(out, v->data(), v->size() * 32);
+    return 0;
+}
+
+int dfk_solid_fetch_unsorted(dfk_ctx* c, dfk_entry32* out, uint64_t cap, int pre)
+{
+    if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    if (cap < c->n_solid) return fail(DFK_E_ARG, "buffer too small: %llu < %llu", (unsigned long long)cap, (unsigned long long)c->n_solid);
+    if (pre && !(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
+    HIP_TRY(hipSetDevice(c->device));
+    uint64_t at = 0;
+    for (const dfk_ctx::Part& pt : c->parts) {
+        const DevBuf& src = pre ? pt.pre : pt.buf;
+        if (pt.n) HIP_TRY(hipMemcpy(out + at, src.p, pt.n * 32, hipMemcpyDeviceToHost));
+        at += pt.n;
+    }
     return 0;
 }
 

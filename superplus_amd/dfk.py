@@ -21,7 +21,7 @@ ENTRY_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("edge_id", "<u4"), ("coun
 
 EXPORTS = [
     "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_device",
-    "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch",
+    "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted",
     "dfk_write_kvec", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply",
 ]
@@ -155,6 +155,12 @@ class Dfk:
         n = self.solid_count()
         out = np.zeros(n, dtype=ENTRY_DTYPE)
         _check(lib().dfk_solid_fetch(self._ctx, _p(out), C.c_uint64(n), C.c_int(1 if pre_adjacency else 0)))
+        return out
+
+    def solid_unsorted(self, pre_adjacency=False):
+        n = self.solid_count()
+        out = np.zeros(n, dtype=ENTRY_DTYPE)
+        _check(lib().dfk_solid_fetch_unsorted(self._ctx, _p(out), C.c_uint64(n), C.c_int(1 if pre_adjacency else 0)))
         return out
 
     def write_kvec(self, path, pre_adjacency=False):

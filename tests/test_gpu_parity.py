@@ -18,6 +18,16 @@ def test_parity_synthetic(oracle, K, seed, G, pairs):
     assert d.spectrum_json() == oracle.spectrum_json(ref["hist"])
 
 
+def test_unsorted_fetch_is_a_permutation_of_the_sorted_one(oracle):
+    rs = util.make_set(5, 400000, 60000)
+    ref, d = util.run_both(oracle, rs, K=48, passes=2)
+    a, b = d.solid(), d.solid_unsorted()
+    assert len(a) == len(b) == ref["n_solid"] > 1 << 16                  # large enough for the threaded host sort
+    order = np.lexsort((b["w1"], b["w0"]))
+    util.assert_same_solid(b[order], a, "unsorted fetch, sorted here")
+    util.assert_same_solid(a, ref["solid"], "sorted fetch")
+
+
 def test_golden_fixtures_through_abi(oracle, golden_dir):
     """The committed golden vectors (reference classes, tests/golden/make_golden.py) through libdfk."""
     import os
@@ -186,4 +196,4 @@ def test_repeat_family_hot_minimizers(oracle):
     rs = synth.make_reads(genome, 225_000, 78).numpy()
     ref, d = util.run_both(oracle, rs, K=48)
     st = util.check_parity(ref, d)
-    assert st["n_overflow_items"] > 100
+    assert st["n_overflow_items"] > 20
