@@ -503,7 +503,6 @@ constexpr int COUNT_HIST_BINS = 256;             // spectrum bins kept in LDS; h
 constexpr uint32_t COUNT_MAX_PROBE = 96;
 constexpr uint32_t HIST_GLOBAL_BINS = 1u << 24;   // KDef count saturates at 2^24-1 (ReadPather.h:128-129)
 constexpr int COUNT_CHUNK = 32;                   // records a wave stages at a time
-constexpr uint32_t ADJ_TASKS_BIG = 4096;          // neighbour look-up queue of the HBM-table fallback
 constexpr uint32_t FLAG_SOLID = 0x80000000u;      // barcode word reused after counting: solid flag | unresolved context bits
 
 template <int K> struct WaveStage {               // per-wave private LDS
@@ -770,7 +769,8 @@ __device__ __forceinline__ u128 canon_value(u128 F)
     return lt128(R, F) ? R : F;
 }
 
-// Finish a counted table: decide solidity, clean up adjacencies, emit.
+// Finish a counted LDS table: decide solidity, clean up adjacencies, emit.  (The HBM-table fallback does
+// the same three steps as separate grid-wide launches: k_big_flags / k_big_resolve / k_big_emit.)
 //
 // recomputeAdjacencies (ReadPather.h:329-364) keeps a context bit only if the neighbouring k-mer is
 // solid.  A neighbour observed next to this k-mer in a read almost always shares its minimizer bucket
@@ -782,10 +782,10 @@ __device__ __forceinline__ u128 canon_value(u128 F)
 //           unresolved for the small HBM pass afterwards (k_adjacency) -- about one bit in ten
 //   pass 3  emit solid slots into the workgroup's output segment (LDS cursor) and the spectrum
 // `sync` is __syncthreads for the whole workgroup.
-template <int K, bool USE_BC, bool LDS_HIST, uint32_t ADJ_TASKS>
+template <int K, bool USE_BC, uint32_t ADJ_TASKS>
 __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
                                                  uint32_t S, const CountParams& cp, uint4* __restrict__ seg_out,
-                                                 unsigned long long* cursor64, uint32_t* cursor32, unsigned int* seg_overflow,
+                                                 uint32_t* cursor32, unsigned int* seg_overflow,
                                                  uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
                                                  uint32_t* tasks, uint32_t* n_tasks, uint32_t* n_boundary,
                                                  uint16_t* solid_list, uint32_t* n_solid, int tid, int nthreads)
@@ -810,7 +810,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         if (f == ~0u) atomicOr(&bcw[slot], 1u << bit);                                         // lives in another item
         else if (!(tld(&bcw[f]) & FLAG_SOLID)) atomicAnd(&ctxs[slot], ~(1u << bit));           // here, and not solid
     };
-    auto sync = [&]() { if (!LDS_HIST) __threadfence(); __syncthreads(); };                   // HBM table: publish first
+    auto sync = [&]() { __syncthreads(); };
     // ---- pass 1
     for (uint32_t base = 0; base < S; base += nthreads) {
         const uint32_t slot = base + tid;
@@ -820,7 +820,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         ++n_occ;
         const uint32_t count = c & CNT_MASK;                           // saturated at 2^24-1 by the insert (ReadPather.h:128-129)
         const bool solid = count >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&bcw[slot]) : 0u, cp.min_bc);
-        if (LDS_HIST && solid) solid_list[atomicAdd(n_solid, 1u)] = (uint16_t)slot;
+        if (solid) solid_list[atomicAdd(n_solid, 1u)] = (uint16_t)slot;
         if (solid && cp.do_adj) {
             const uint32_t ctx = tld(&ctxs[slot]) & 0xFFu;
             if (cp.keep_pre) tst(&ctxs[slot], ctx | (ctx << 8));
@@ -877,13 +877,13 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
             // pad (word 3) carries the unresolved bits (and the original context for tests) until k_adjacency
             seg_out[2 * idx + 1] = uint4{0xFFFFFFFFu, count | ((cw & 0xFFu) << 24), 0xFFFFFFFFu, pending | (cw & 0xFF00u)};
         } else atomicOr(seg_overflow, 1u);
-        if (LDS_HIST && count < (uint32_t)COUNT_HIST_BINS) atomicAdd(&hist_lds[count], 1u);
+        if (count < (uint32_t)COUNT_HIST_BINS) atomicAdd(&hist_lds[count], 1u);
         else atomicAdd(&hist_global[count], 1ull);
     };
-    if constexpr (LDS_HIST) {
-        // LDS table: the solid slots were listed by pass 1, so the emit runs on dense lanes; the workgroup's
-        // segment cursor moves once; then the state words of the whole table are cleared with wide stores
-        // (key words are rewritten on claim).  cnt, ctxs and bcw are contiguous.
+    {
+        // the solid slots were listed by pass 1, so the emit runs on dense lanes; the workgroup's segment
+        // cursor moves once; then the state words of the whole table are cleared with wide stores (key words
+        // are rewritten on claim).  cnt, ctxs and bcw are contiguous.
         const uint32_t ns = __builtin_amdgcn_readfirstlane(tld(n_solid));
         const uint32_t base = __builtin_amdgcn_readfirstlane(tld(cursor32));
 #ifdef DFK_ABLATE_EMIT
@@ -898,20 +898,6 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         if (tid == 0) { tst(cursor32, base + ns); tst(n_solid, 0u); }
         uint4* z = reinterpret_cast<uint4*>(cnt);
         for (uint32_t i = tid; i < 3 * S / 4; i += nthreads) z[i] = uint4{0, 0, 0, 0};
-    } else {
-        for (uint32_t base = 0; base < S; base += nthreads) {
-            const uint32_t slot = base + tid;
-            const uint32_t c = slot < S ? tld(&cnt[slot]) : 0;
-            const uint32_t flags = c ? tld(&bcw[slot]) : 0u;
-            const bool solid = (flags & FLAG_SOLID) != 0;
-            unsigned long long m = __ballot(solid);
-            if (!m) continue;
-            uint32_t n = __popcll(m);
-            unsigned long long wbase = 0;
-            if (lane == 0) wbase = atomicAdd(cursor64, (unsigned long long)n);
-            wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
-            if (solid) emit(slot, c, flags, wbase + __popcll(m & ((1ull << lane) - 1ull)));
-        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) boundary += __shfl_down(boundary, d, 64);
@@ -997,7 +983,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
 #else
             uint32_t occ =
 #endif
-            table_finish<K, USE_BC, true, S / 2>(keys, cnt, ctxs, bcw, S, cp, seg_out, nullptr, &ctl[CTL_CURSOR],
+            table_finish<K, USE_BC, S / 2>(keys, cnt, ctxs, bcw, S, cp, seg_out, &ctl[CTL_CURSOR],
                                                          &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
                                                          &ctl[CTL_BOUNDARY], solid_list, &ctl[CTL_NSOLID], tid, NT);
 #pragma unroll
