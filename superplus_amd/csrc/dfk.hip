@@ -60,7 +60,8 @@ struct Inputs {           // device pointers
 struct dfk_ctx {
     dfk_config cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;             // everything except ...
+    hipStream_t stream2 = nullptr;            // ... the scatter of the next pass, which runs (low priority) under the count of the current one
     hipDeviceProp_t prop{};
     uint64_t budget = 0, held = 0, peak = 0;
     struct Owned { void* p; uint64_t bytes, seq; };
@@ -419,28 +420,34 @@ template <int K> uint64_t item_budget(const dfk_ctx* c)
     return (uint64_t)std::min(std::max(b, 0.5 * (double)S), 3.0 * (double)S);
 }
 
+// One pass's records: begin() builds the pass's bucket tables and enqueues the scatter on c->stream without
+// waiting for it; end() waits, checks that every bucket received what the counting scan saw, and frees the
+// cursors.  (run_typed enqueues the next pass's scatter on a second stream before counting the current one.)
+struct ScatterJob { Partition P; DevBuf cur, d_bad; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; uint32_t lo = 0, n = 0; };
+
 template <int K>
-int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0,
-                      uint32_t sub_lo, uint32_t sub_n, Partition* P)
+int scatter_begin(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0,
+                  uint32_t sub_lo, uint32_t sub_n, ScatterJob* J)
 {
+    Partition* P = &J->P;
+    J->st = c->stream; J->lo = sub_lo; J->n = sub_n;
     const PartParams pp = part_params<K>(c, T.log2_nb, log2_world, read_id0, sub_lo, sub_n);
     const uint64_t budget = item_budget<K>(c);
     int rc = pass_tables(c, T.acc, T.log2_nb - log2_world, 1u << log2_world, sub_lo, sub_n, budget, P); if (rc) return rc;
     const uint64_t nb = P->nb;
-    DevBuf cur, d_bad;
-    rc = c->alloc(cur, nb * 8, "bucket cursors"); if (rc) return rc;
+    rc = c->alloc(J->cur, nb * 8, "bucket cursors"); if (rc) return rc;
     rc = c->alloc(P->records, P->n_records * 32, "super-k-mer records"); if (rc) return rc;
-    rc = c->alloc(d_bad, 16, "scatter check"); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(cur.p, P->base.p, nb * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(d_bad.p, 0, 16, c->stream));
+    rc = c->alloc(J->d_bad, 16, "scatter check"); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(J->cur.p, P->base.p, nb * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(J->d_bad.p, 0, 16, c->stream));
     const size_t lds_b = sizeof(uint32_t) * pp.W * PART_THREADS + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
-    Timer t(c->stream);
-    t.start();
+    if (!J->e0) { HIP_TRY(hipEventCreate(&J->e0)); HIP_TRY(hipEventCreate(&J->e1)); }
+    HIP_TRY(hipEventRecord(J->e0, c->stream));
     if (in.n_reads)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 255) / 256)), dim3(256), 0, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p,
-                           (unsigned long long*)cur.p, P->n_records, (uint4*)P->records.p);
+                           (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p);
     HIP_TRY(hipGetLastError());
     // the few reads with more runs than a summary holds are scanned again
     if (T.n_ovf)
@@ -448,20 +455,27 @@ int partition_scatter(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32
                            dim3(PART_THREADS), lds_b, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                           (unsigned long long*)cur.p, P->n_records, (uint4*)P->records.p, (uint4*)nullptr,
+                           (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p, (uint4*)nullptr,
                            (const uint32_t*)T.ovf_list.p, T.n_ovf, (const uint64_t*)nullptr);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, (const unsigned long long*)cur.p,
-                       (const uint64_t*)P->base.p, nb, (unsigned int*)d_bad.p);
+    hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, (const unsigned long long*)J->cur.p,
+                       (const uint64_t*)P->base.p, nb, (unsigned int*)J->d_bad.p);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(J->e1, c->stream));
+    return 0;
+}
+
+int scatter_end(dfk_ctx* c, ScatterJob* J)
+{
+    HIP_TRY(hipEventSynchronize(J->e1));
+    float ms = 0; (void)hipEventElapsedTime(&ms, J->e0, J->e1);
+    c->st.ms_part_scatter += ms;
     unsigned int bad = 0;
-    HIP_TRY(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, c->stream));
-    c->st.ms_part_scatter += t.stop();
-    c->release(d_bad);
+    HIP_TRY(hipMemcpy(&bad, J->d_bad.p, 4, hipMemcpyDeviceToHost));
+    c->release(J->d_bad); c->release(J->cur);
     if (bad) return fail(DFK_E_HIP, "scatter: %u buckets did not receive the records counted for them (run summaries and bucket counters disagree)", bad);
-    TRACE("scatter of buckets [%u, %u) done (%llu records, %llu items)", sub_lo, sub_lo + sub_n,
-          (unsigned long long)P->n_records, (unsigned long long)P->n_items);
-    c->release(cur);
+    TRACE("scatter of buckets [%u, %u) done (%llu records, %llu items)", J->lo, J->lo + J->n,
+          (unsigned long long)J->P.n_records, (unsigned long long)J->P.n_items);
     return 0;
 }
 
@@ -474,6 +488,7 @@ struct CountRun {                     // device state shared by the count launch
     DevBuf big; uint64_t big_cap = 0;  // output of the HBM-table fallback (its own buffer)
     DevBuf d_hist, d_g;                // spectrum bins and counters: live across the passes of one run
     DevBuf d_snap;                     // their state before the current pass (a pass that runs out of room is undone and redone)
+    DevBuf d_seg, d_segcnt;            // output segments of the pass being counted (count_prepare .. count_run)
     uint64_t solid_seen = 0, inst_seen = 0;   // totals of the passes done so far (sizes the next pass's output)
 };
 
@@ -658,8 +673,17 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
 
 // Count one pass: run k_count over its items (+ split / HBM-table fallbacks), gather the pass's solid
 // k-mers into a dense part.
-template <int K, bool USE_BC>
-int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
+// solid k-mers a pass of n_inst instances is expected to emit at most (what its output segments are sized for)
+uint64_t solid_cap(const dfk_ctx* c, const CountRun& R, uint64_t n_inst)
+{
+    uint64_t cap = n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
+    if (R.inst_seen) cap = std::min<uint64_t>(cap, (uint64_t)(1.3 * (double)R.solid_seen / (double)R.inst_seen * (double)n_inst) + 65536);
+    else cap = std::min<uint64_t>(cap, n_inst / 16 + (1u << 20));   // first pass: a prior (30x data: n_inst/15); too small -> redone
+    return cap;
+}
+
+template <int K>
+int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R)
 {
     const unsigned attempt = c->seg_attempt;
     // Output: one segment per persistent workgroup, filled through an LDS cursor.  Every solid k-mer has
@@ -667,16 +691,14 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
     // ratio gives a much tighter estimate.
     R.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(P.n_items, count_grid<K>(c)));
     const uint32_t nseg = R.grid;
-    uint64_t cap = P.n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
-    if (R.inst_seen) cap = std::min<uint64_t>(cap, (uint64_t)(1.3 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
-    else cap = std::min<uint64_t>(cap, P.n_inst / 16 + (1u << 20));   // first pass: a prior (30x data: n_inst/15); too small -> redone
+    uint64_t cap = solid_cap(c, R, P.n_inst);
     const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
     // the dense part made afterwards needs room too: leave a third of what is left for it
     if (cap * 32 > room / 3 * 2) cap = room / 3 * 2 / 32;
     // dynamic item scheduling balances the workgroups to within a few items (<= 3/4 S entries each);
     // if a segment still fills up the whole run is redone with twice the room
     const uint64_t seg_cap = std::min<uint64_t>(((cap / nseg) * 5 / 4 + 8192) << attempt, 0xFFFFFFF0ull);
-    DevBuf d_seg, d_segcnt;
+    DevBuf& d_seg = R.d_seg; DevBuf& d_segcnt = R.d_segcnt;
     int rc = c->alloc(d_seg, seg_cap * nseg * 32, "solid k-mer segments"); if (rc) return rc;
     rc = c->alloc(d_segcnt, 4ull * nseg, "segment counts"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_segcnt.p, 0, 4ull * nseg, c->stream));
@@ -684,7 +706,16 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
     R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, nseg, seg_cap, c->cfg.min_freq > 1 ? 1u : 0u,
                        (c->cfg.flags & DFK_F_KEEP_PRE_ADJ) ? 1u : 0u};
     R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p; R.big_cap = 0;
+    return 0;
+}
 
+template <int K, bool USE_BC>
+int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
+{
+    DevBuf& d_seg = R.d_seg; DevBuf& d_segcnt = R.d_segcnt;
+    const uint32_t nseg = R.cp.n_segments;
+    const uint64_t seg_cap = R.cp.seg_cap;
+    int rc = 0;
     Timer t(c->stream);
     std::vector<ItemRange> overflowed;
     c->st.n_items += P.n_items;
@@ -745,6 +776,13 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
     R.solid_seen += part.n; R.inst_seen += P.n_inst;
     if (R.inst_seen) c->distinct_per_inst = (double)hg.n_distinct / (double)R.inst_seen;
     return 0;
+}
+
+template <int K, bool USE_BC>
+int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
+{
+    int rc = count_prepare<K>(c, P, R); if (rc) return rc;
+    return count_run<K, USE_BC>(c, P, R);
 }
 
 // ------------------------------------------------------------------ stage: adjacency (a6)
@@ -821,22 +859,41 @@ uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
 // records (32 B each), its output segments and, at the end, its dense part of the dictionary; the parts of
 // earlier passes stay resident, so later passes are smaller.  Buckets are hash-distributed, so a range holds
 // its share of the records and instances to within a fraction of a percent.
-uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, uint32_t sub_nb, uint32_t lo)
+// `running` != null: the range is scattered while that pass is being counted, so (1) its tables and records
+// must fit beside everything the running pass holds plus the part it is about to add, and (2) its segments
+// and part must fit once the running pass has been released.
+struct RunningPass { uint64_t bytes_held; uint64_t n_inst; };
+uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, uint32_t sub_nb, uint32_t lo, const RunningPass* running)
 {
     const double room = c->budget > c->held ? (double)(c->budget - c->held) : 0.0;
     const double inst_per = (double)T.n_inst / sub_nb, rec_per = (double)T.n_records / sub_nb;
     // solid k-mers per instance: observed on the passes done so far, else the prior stage_count starts from
     double ratio = R.inst_seen ? 1.3 * (double)R.solid_seen / (double)R.inst_seen : 1.0 / 16.0;
     ratio = std::min(ratio, 1.0 / std::max<uint32_t>(1, c->cfg.min_freq));
-    const double per_bucket = 60.0 + 32.0 * rec_per + 32.0 * ratio * inst_per * (1.25 * (double)(1u << c->seg_attempt) + 1.0);
+    const double per_in = 60.0 + 32.0 * rec_per;                                         // tables and records
+    const double per_out = 32.0 * ratio * inst_per * (1.25 * (double)(1u << c->seg_attempt) + 1.0);   // segments and part
     const double fixed = 300e6;                                       // segment slack (8192 entries each), small tables
-    const double fit = room > fixed ? (room - fixed) / per_bucket : 0.0, left = (double)(sub_nb - lo);
+    double fit;
+    if (!running) fit = room > fixed ? (room - fixed) / (per_in + per_out) : 0.0;
+    else {
+        const double part_running = 32.0 * ratio * (double)running->n_inst;
+        const double now = room - part_running - fixed;
+        const double later = room + (double)running->bytes_held - part_running - fixed;
+        fit = std::max(0.0, std::min(now / per_in, later / (per_in + per_out)));
+    }
+    const double left = (double)(sub_nb - lo);
     double n = c->plan_derate * fit;
     if (left <= 0.99 * fit && left < 1.06 * n) n = left;              // no sliver of a last pass if the rest (almost certainly) fits
     else if (left > n && left < 1.3 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big and a small one
-    n = std::max(16.0, std::min(n, left));
-    return (uint32_t)n;
+    n = std::min(n, left);
+    return n < 16.0 ? (running ? 0u : 16u) : (uint32_t)n;
 }
+
+struct StreamSwap {                                    // run a stretch of host code against the second stream
+    dfk_ctx* c; hipStream_t keep;
+    StreamSwap(dfk_ctx* ctx, hipStream_t s) : c(ctx), keep(ctx->stream) { c->stream = s; }
+    ~StreamSwap() { c->stream = keep; }
+};
 
 template <int K>
 int run_typed(dfk_ctx* c, const Inputs& in)
@@ -855,26 +912,62 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
     CountRun R;
     rc = count_run_begin(c, &R); if (rc) return rc;
-    // Passes over contiguous ranges of the fine buckets, each as large as the free HBM allows.  A pass that
-    // runs out of room (its estimate of the solid k-mers was too low) is undone and redone smaller.
+    // Passes over contiguous ranges of the fine buckets, each as large as the free HBM allows.  While a pass is
+    // counted (LDS- and issue-bound) the next range is scattered on a second, low-priority stream (bound by
+    // scattered atomics and stores): the two kernels share the CUs.  A pass that runs out of room (its estimate
+    // of the solid k-mers was too low) is undone together with whatever was started after it, and redone smaller.
     const uint32_t sub_nb = 1u << T.log2_nb;
     const uint32_t forced = (uint32_t)c->cfg.reserved[0];            // dfk_config.reserved[0] = forced number of passes (tests)
     const uint32_t per_forced = forced ? std::max<uint32_t>(1, (sub_nb + forced - 1) / forced) : 0;
-    uint32_t lo = 0, n_passes = 0, retries = 0;
+    const bool overlap = getenv("DFK_NO_OVERLAP") == nullptr;
+    uint32_t n_passes = 0, retries = 0;
     c->seg_attempt = 0; c->distinct_per_inst = 0.0;
-    while (lo < sub_nb) {
-        const uint32_t n = forced ? std::min(per_forced, sub_nb - lo) : plan_range(c, T, R, sub_nb, lo);
-        TRACE("pass %u: buckets [%u, %u) of %u (%.1f %%), %.2f GB held of %.2f", n_passes + 1, lo, lo + n, sub_nb, 100.0 * n / sub_nb,
-              c->held / 1e9, c->budget / 1e9);
-        const uint64_t mark = c->alloc_seq;
+    struct Job { ScatterJob sj; uint64_t mark = 0; bool valid = false; };
+    Job cur, nxt;
+    auto drop_events = [&](Job& j) { if (j.sj.e0) { (void)hipEventDestroy(j.sj.e0); (void)hipEventDestroy(j.sj.e1); j.sj.e0 = j.sj.e1 = nullptr; } };
+    // start the scatter of [lo, lo + n) on the second stream; NOMEM leaves nothing behind
+    auto start = [&](Job& j, uint32_t lo, uint32_t n) -> int {
+        j.sj = ScatterJob{}; j.mark = c->alloc_seq; j.valid = false;
+        TRACE("pass range [%u, %u) of %u (%.1f %%), %.2f GB held of %.2f", lo, lo + n, sub_nb, 100.0 * n / sub_nb, c->held / 1e9, c->budget / 1e9);
+        int r;
+        { StreamSwap sw(c, c->stream2); r = scatter_begin<K>(c, in, T, 0, 0, lo, n, &j.sj); }
+        if (r) { (void)hipStreamSynchronize(c->stream2); c->release_since(j.mark); drop_events(j); return r; }
+        j.valid = true;
+        return 0;
+    };
+    // the first range of a (re)started sequence: alone, shrinking until it fits
+    auto start_alone = [&](Job& j, uint32_t lo) -> int {
+        for (;;) {
+            const uint32_t n = forced ? std::min(per_forced, sub_nb - lo) : plan_range(c, T, R, sub_nb, lo, nullptr);
+            const int r = start(j, lo, n);
+            if (r != DFK_E_NOMEM || forced || n <= 16 || ++retries > 12) return r;
+            c->plan_derate *= 0.7;
+            TRACE("out of HBM (%s): planning smaller passes", g_err.c_str());
+        }
+    };
+    rc = start_alone(cur, 0); if (rc) return rc;
+    while (cur.valid) {
+        const uint32_t lo = cur.sj.lo, n = cur.sj.n, nlo = lo + n;
+        rc = scatter_end(c, &cur.sj); if (rc) return rc;
         const dfk_stats st0 = c->st;
         rc = count_snapshot(c, &R, false); if (rc) return rc;
-        Partition P;
-        rc = partition_scatter<K>(c, in, T, 0, 0, lo, n, &P);
-        if (!rc) rc = in.bc ? stage_count<K, true>(c, P, R) : stage_count<K, false>(c, P, R);
+        rc = count_prepare<K>(c, cur.sj.P, R);
+        nxt.valid = false;
+        if (!rc && overlap && nlo < sub_nb) {
+            const Partition& P = cur.sj.P;
+            const RunningPass rp{P.records.bytes + P.base.bytes + P.ipre.bytes + P.items.bytes + R.d_seg.bytes + R.d_segcnt.bytes, P.n_inst};
+            const uint32_t n2 = forced ? std::min(per_forced, sub_nb - nlo) : plan_range(c, T, R, sub_nb, nlo, &rp);
+            if (n2) {
+                const int r2 = start(nxt, nlo, n2);
+                if (r2 && r2 != DFK_E_NOMEM) return r2;                // NOMEM: this range is scattered after the count instead
+            }
+        }
+        if (!rc) rc = in.bc ? count_run<K, true>(c, cur.sj.P, R) : count_run<K, false>(c, cur.sj.P, R);
         if (rc == DFK_E_NOMEM || rc == E_SEGMENT_FULL) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->release_since(mark);
+            HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipStreamSynchronize(c->stream2));
+            c->release_since(cur.mark);                               // this pass and the one started under it
+            R.d_seg = R.d_segcnt = R.big = DevBuf{};
+            drop_events(cur); drop_events(nxt); nxt.valid = false;
             int rc2 = count_snapshot(c, &R, true); if (rc2) return rc2;
             const float ms_scatter = c->st.ms_part_scatter, ms_count = c->st.ms_count, ms_fb = c->st.ms_fallback;
             c->st = st0;                                              // the time spent stays on the books
@@ -883,12 +976,16 @@ int run_typed(dfk_ctx* c, const Inputs& in)
             if (rc == E_SEGMENT_FULL) { ++c->seg_attempt; TRACE("output segments too small: redoing the pass with twice the room"); }
             else if (forced || n <= 16) return rc;
             else { c->plan_derate *= 0.7; TRACE("out of HBM (%s): redoing the pass smaller", g_err.c_str()); }
+            rc = start_alone(cur, lo); if (rc) return rc;
             continue;
         }
         if (rc) return rc;
-        release_pass(c, &P);
-        lo += n; ++n_passes;
+        release_pass(c, &cur.sj.P);
+        drop_events(cur);
+        ++n_passes;
         c->seg_attempt = 0;                                           // later passes size their output from the observed ratio
+        if (nxt.valid) { cur = nxt; nxt = Job{}; }
+        else { cur = Job{}; if (nlo < sub_nb) { rc = start_alone(cur, nlo); if (rc) return rc; } }
     }
     c->release(T.acc); c->release(T.summ); c->release(T.ovf_list); c->release(T.class_hist);
     c->st.reserved[0] = n_passes;
@@ -989,7 +1086,12 @@ int dfk_create(const dfk_config* cfg, dfk_ctx** out)
         std::string a = c->prop.gcnArchName; delete c;
         return fail(DFK_E_NODEVICE, "device is %s; libdfk is built for gfx950 (MI355X) only", a.c_str());
     }
-    HIP_TRY(hipStreamCreate(&c->stream));
+    {
+        int lo_pri = 0, hi_pri = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);      // numerically lowest = highest priority
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi_pri));
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamDefault, lo_pri));
+    }
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
     c->budget = cfg->hbm_budget_bytes ? cfg->hbm_budget_bytes : (uint64_t)(0.9 * (double)fr);
@@ -1004,6 +1106,7 @@ void dfk_destroy(dfk_ctx* c)
     c->release_all();
     c->drop_pool();
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
