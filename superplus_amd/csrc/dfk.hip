@@ -33,6 +33,7 @@ int fail(int code, const char* fmt, ...)
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
+    bool sub = false;            // carved from a pass block (dfk_ctx::PassBlock): given back with the block, not on its own
 };
 
 bool g_trace = getenv("DFK_TRACE") != nullptr;
@@ -133,9 +134,19 @@ struct dfk_ctx {
             { (void)hipFree(chunks[i].p); reserved -= chunks[i].bytes; chunks.erase(chunks.begin() + i); }
             else ++i;
     }
+    // Everything one pass holds while it is in flight (bucket tables, records, output segments) comes out of ONE
+    // arena block, so that two passes in flight plus the growing dictionary never interleave: the blocks of
+    // successive passes do not grow, so each fits the hole left by the pass before the running one.
+    struct PassBlock { DevBuf block; size_t used = 0; };
+    PassBlock* sub = nullptr;                        // while set, bottom allocations are bumped out of it when they fit
     int alloc(DevBuf& b, size_t bytes, const char* what, bool top = false)
     {
         bytes = bytes ? (bytes + 255) & ~(size_t)255 : 256;
+        if (sub && !top && sub->used + bytes <= sub->block.bytes) {
+            b.p = (char*)sub->block.p + sub->used; b.bytes = bytes; b.sub = true;
+            sub->used += bytes;
+            return 0;
+        }
         if (held + bytes > budget)
             return fail(DFK_E_NOMEM, "HBM budget exceeded allocating %zu bytes for %s (held %llu, budget %llu)",
                         bytes, what, (unsigned long long)held, (unsigned long long)budget);
@@ -148,7 +159,13 @@ struct dfk_ctx {
             if (chunks.empty()) want = std::max<uint64_t>(want, std::min<uint64_t>(first_chunk_hint, budget));
             if (reserved + want > budget) { drop_empty_chunks(); want = std::min<uint64_t>(want, budget > reserved ? budget - reserved : 0); }
             want &= ~(uint64_t)0xFFF;                  // blocks carved from the top of a chunk must stay aligned
-            if (want < bytes) return fail(DFK_E_NOMEM, "HBM budget exhausted by fragmentation allocating %zu bytes for %s", bytes, what);
+            if (want < bytes) {
+                if (g_trace) {
+                    for (const Chunk& k : chunks) for (const Free& f : k.free_list) fprintf(stderr, "[dfk]   free %.2f GB at %.2f GB\n", f.bytes / 1e9, f.off / 1e9);
+                    for (const Owned& o : owned) if (o.bytes >= (1ull << 28)) fprintf(stderr, "[dfk]   held %.2f GB at %.2f GB (#%llu)\n", o.bytes / 1e9, ((char*)o.p - chunks[0].p) / 1e9, (unsigned long long)o.seq);
+                }
+                return fail(DFK_E_NOMEM, "HBM budget exhausted by fragmentation allocating %zu bytes for %s", bytes, what);
+            }
             void* p = nullptr;
             hipError_t e = hipMalloc(&p, want);
             if (e != hipSuccess && want > bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&p, want); }
@@ -166,6 +183,7 @@ struct dfk_ctx {
     void release(DevBuf& b)
     {
         if (!b.p) return;
+        if (b.sub) { b = DevBuf{}; return; }
         auto it = std::find_if(owned.begin(), owned.end(), [&](const Owned& o) { return o.p == b.p; });
         if (it != owned.end()) owned.erase(it);
         for (Chunk& k : chunks)
@@ -180,6 +198,20 @@ struct dfk_ctx {
                 break;
             }
         held -= b.bytes; b.p = nullptr; b.bytes = 0;
+    }
+    // keep only the upper `keep` bytes of a block (blocks carved from the top grow downwards: a reservation made
+    // for an upper bound is cut to what was needed, and the block stays adjacent to its long-lived neighbours)
+    void shrink_top(DevBuf& b, size_t keep)
+    {
+        keep = keep ? (keep + 255) & ~(size_t)255 : 256;
+        if (!b.p || keep >= b.bytes) return;
+        const size_t cut = b.bytes - keep;
+        auto it = std::find_if(owned.begin(), owned.end(), [&](const Owned& o) { return o.p == b.p; });
+        DevBuf low; low.p = b.p; low.bytes = cut;
+        b.p = (char*)b.p + cut; b.bytes = keep;
+        if (it != owned.end()) { it->p = b.p; it->bytes = keep; owned.push_back(Owned{low.p, (uint64_t)cut, it->seq}); }
+        else owned.push_back(Owned{low.p, (uint64_t)cut, alloc_seq});
+        release(low);
     }
     // give back everything allocated after `mark` (= alloc_seq at some earlier moment): what an abandoned
     // pass left behind.  The DevBufs that pointed at those blocks are dead; the caller resets them.
@@ -489,6 +521,7 @@ struct CountRun {                     // device state shared by the count launch
     DevBuf d_hist, d_g;                // spectrum bins and counters: live across the passes of one run
     DevBuf d_snap;                     // their state before the current pass (a pass that runs out of room is undone and redone)
     DevBuf d_seg, d_segcnt;            // output segments of the pass being counted (count_prepare .. count_run)
+    DevBuf d_part;                     // room reserved for its dense part, at the top, before anything else is placed beside it
     uint64_t solid_seen = 0, inst_seen = 0;   // totals of the passes done so far (sizes the next pass's output)
 };
 
@@ -693,8 +726,8 @@ int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R)
     const uint32_t nseg = R.grid;
     uint64_t cap = solid_cap(c, R, P.n_inst);
     const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
-    // the dense part made afterwards needs room too: leave a third of what is left for it
-    if (cap * 32 > room / 3 * 2) cap = room / 3 * 2 / 32;
+    // the segments (5/4 of the estimate) and the dense part made from them both have to fit
+    if ((double)cap * 32.0 * 2.3 > (double)room) cap = (uint64_t)((double)room / (32.0 * 2.3));
     // dynamic item scheduling balances the workgroups to within a few items (<= 3/4 S entries each);
     // if a segment still fills up the whole run is redone with twice the room
     const uint64_t seg_cap = std::min<uint64_t>(((cap / nseg) * 5 / 4 + 8192) << attempt, 0xFFFFFFF0ull);
@@ -706,7 +739,13 @@ int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R)
     R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, nseg, seg_cap, c->cfg.min_freq > 1 ? 1u : 0u,
                        (c->cfg.flags & DFK_F_KEEP_PRE_ADJ) ? 1u : 0u};
     R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p; R.big_cap = 0;
-    return 0;
+    // the part is reserved now, from the top, so that what is placed next (the records of the following pass)
+    // cannot fragment the room it needs; count_run cuts the reservation to size
+    // (once a pass has shown the solid/instance ratio the estimate is good to a fraction of a percent: the
+    // reservation is then 1.08x the expectation rather than the segments' 1.3x)
+    uint64_t res = cap;
+    if (R.inst_seen) res = std::min<uint64_t>(cap, (uint64_t)(1.08 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
+    return c->alloc(R.d_part, std::max<uint64_t>(1, res) * 32, "solid k-mer entries", true);
 }
 
 template <int K, bool USE_BC>
@@ -751,8 +790,8 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     HIP_TRY(hipMemcpy(&hg, R.d_g.p, sizeof hg, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(segcnt.data(), d_segcnt.p, 4ull * nseg, hipMemcpyDeviceToHost));
     if (hg.solid_overflow || hg.big_cursor > R.big_cap) {
-        // the spectrum and counters cannot be unwound: the caller restarts the run with more room
-        c->release(d_seg); c->release(d_segcnt); c->release(R.big);
+        // the caller undoes the pass and redoes it with more room
+        c->release(d_seg); c->release(d_segcnt); c->release(R.big); c->release(R.d_part);
         fail(DFK_E_NOMEM, "a solid k-mer output segment (%llu entries) is full", (unsigned long long)seg_cap);
         return E_SEGMENT_FULL;
     }
@@ -761,7 +800,8 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     dfk_ctx::Part part;
     part.n = prefix[nseg] + hg.big_cursor;
     DevBuf d_prefix;
-    rc = c->alloc(part.buf, part.n * 32, "solid k-mer entries", true); if (rc) return rc;
+    if (part.n * 32 <= R.d_part.bytes) { part.buf = R.d_part; R.d_part = DevBuf{}; c->shrink_top(part.buf, part.n * 32); }
+    else { c->release(R.d_part); rc = c->alloc(part.buf, part.n * 32, "solid k-mer entries", true); if (rc) return rc; }
     rc = c->alloc(d_prefix, 8ull * (nseg + 1), "segment prefix"); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_prefix.p, prefix.data(), 8ull * (nseg + 1), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_compact, dim3(8, nseg), dim3(256), 0, c->stream, (const uint4*)d_seg.p, seg_cap,
@@ -862,26 +902,76 @@ uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
 // `running` != null: the range is scattered while that pass is being counted, so (1) its tables and records
 // must fit beside everything the running pass holds plus the part it is about to add, and (2) its segments
 // and part must fit once the running pass has been released.
-struct RunningPass { uint64_t bytes_held; uint64_t n_inst; };
-uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, uint32_t sub_nb, uint32_t lo, const RunningPass* running)
+struct RunningPass { uint64_t bytes_held; uint64_t n_inst; uint32_t n_buckets; uint64_t block_off; };
+
+// The same question asked of the arena's actual free blocks (one chunk).  A pass block goes to the lowest free
+// block that holds it -- now, beside the running pass.  The reservation for its part is made later, when the
+// running pass's block is gone, and goes to the highest free block: it has to fit there, or it lands in a low
+// hole and cuts the room of later blocks.  Largest n for which both hold, by bisection.
+double fit_free_blocks(const dfk_ctx* c, double per_block, double per_res, const RunningPass& run)
+{
+    if (c->chunks.size() != 1 || c->chunks[0].free_list.empty()) return 1e300;
+    const std::vector<dfk_ctx::Free>& fl = c->chunks[0].free_list;
+    auto feasible = [&](double n) {
+        const uint64_t B = (uint64_t)(per_block * n / 0.98) + 1;
+        size_t at = fl.size();
+        for (size_t i = 0; i < fl.size(); ++i) if (fl[i].bytes >= B) { at = i; break; }
+        if (at == fl.size()) return false;
+        // free list once the running block is gone and the new block is in place
+        std::vector<dfk_ctx::Free> h(fl.begin(), fl.end());
+        h[at].off += B; h[at].bytes -= B;
+        h.push_back(dfk_ctx::Free{run.block_off, run.bytes_held});
+        std::sort(h.begin(), h.end(), [](const dfk_ctx::Free& a, const dfk_ctx::Free& b) { return a.off < b.off; });
+        uint64_t top_off = 0, top_bytes = 0;
+        for (const dfk_ctx::Free& f : h) {
+            if (!f.bytes) continue;
+            if (top_bytes && top_off + top_bytes == f.off) top_bytes += f.bytes; else { top_off = f.off; top_bytes = f.bytes; }
+        }
+        return per_res * n <= 0.98 * (double)top_bytes;
+    };
+    double lo = 0.0, hi = 0.0;
+    for (const dfk_ctx::Free& f : fl) hi = std::max(hi, 0.98 * (double)f.bytes / per_block);
+    if (feasible(hi)) return hi;
+    for (int it = 0; it < 30; ++it) { const double mid = 0.5 * (lo + hi); if (feasible(mid)) lo = mid; else hi = mid; }
+    return lo;
+}
+
+uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, uint32_t sub_nb, uint32_t lo, const RunningPass* running, bool overlap)
 {
     const double room = c->budget > c->held ? (double)(c->budget - c->held) : 0.0;
     const double inst_per = (double)T.n_inst / sub_nb, rec_per = (double)T.n_records / sub_nb;
     // solid k-mers per instance: observed on the passes done so far, else the prior stage_count starts from
     double ratio = R.inst_seen ? 1.3 * (double)R.solid_seen / (double)R.inst_seen : 1.0 / 16.0;
     ratio = std::min(ratio, 1.0 / std::max<uint32_t>(1, c->cfg.min_freq));
-    const double per_in = 60.0 + 32.0 * rec_per;                                         // tables and records
-    const double per_out = 32.0 * ratio * inst_per * (1.25 * (double)(1u << c->seg_attempt) + 1.0);   // segments and part
+    const double per_in = 81.0 + 32.5 * rec_per;                                         // tables and records (as the pass block is sized)
+    const double per_seg = 32.0 * ratio * inst_per * 1.25 * (double)(1u << c->seg_attempt);            // output segments (inside the pass block)
+    const double per_out = per_seg + 32.0 * ratio * inst_per;                                         // ... and the part's reservation
     const double fixed = 300e6;                                       // segment slack (8192 entries each), small tables
-    double fit;
-    if (!running) fit = room > fixed ? (room - fixed) / (per_in + per_out) : 0.0;
-    else {
-        const double part_running = 32.0 * ratio * (double)running->n_inst;
-        const double now = room - part_running - fixed;
-        const double later = room + (double)running->bytes_held - part_running - fixed;
-        fit = std::max(0.0, std::min(now / per_in, later / (per_in + per_out)));
-    }
     const double left = (double)(sub_nb - lo);
+    double fit;
+    if (!running) {
+        fit = room > fixed ? (room - fixed) / (per_in + per_out) : 0.0;
+        // more than one pass to go: leave room for the records of the next one, which is scattered while this
+        // one is counted (passes of equal or decreasing size also keep the arena from fragmenting: each new
+        // range fits the hole left by the pass before the running one)
+        if (c->plan_derate * fit < left && overlap) fit = room > fixed ? (room - fixed) / (2.0 * per_in + per_seg + per_out) : 0.0;
+    } else {
+        const double now = room - fixed;                              // (the running pass's part is reserved already)
+        const double later = room + (double)running->bytes_held - fixed;
+        TRACE("plan: now %.1f%% later %.1f%% geometry %.1f%% balance %.1f%% (room %.1f GB, running block %.1f GB)",
+              100 * 0.9 * now / (per_in + per_seg) / sub_nb, 100 * later / (per_in + per_out) / sub_nb,
+              100 * fit_free_blocks(c, per_in + per_seg, per_out - per_seg, *running) / sub_nb,
+              100 * std::max(0.0, room + (double)running->bytes_held - fixed) / (2.0 * (per_in + per_seg) + (per_out - per_seg)) / sub_nb,
+              room / 1e9, running->bytes_held / 1e9);
+        if (g_trace) for (const dfk_ctx::Free& f : c->chunks[0].free_list) fprintf(stderr, "[dfk]   free %.2f GB at %.2f GB\n", f.bytes / 1e9, f.off / 1e9);
+        // (a range that does not fit beside the running pass loses the overlap: plan it with more slack --
+        // the free room is in several pieces by now)
+        fit = std::max(0.0, std::min(0.9 * now / (per_in + per_seg), later / (per_in + per_out)));
+        fit = std::min(fit, fit_free_blocks(c, per_in + per_seg, per_out - per_seg, *running) / c->plan_derate);
+        // and leave the pass after this one (planned while this one is counted, the running one gone by then)
+        // a block of the same size: greedy ranges alternate between huge and tiny
+        fit = std::min(fit, std::max(0.0, room + (double)running->bytes_held - fixed) / (2.0 * (per_in + per_seg) + (per_out - per_seg)));
+    }
     double n = c->plan_derate * fit;
     if (left <= 0.99 * fit && left < 1.06 * n) n = left;              // no sliver of a last pass if the rest (almost certainly) fits
     else if (left > n && left < 1.3 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big and a small one
@@ -922,15 +1012,26 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     const bool overlap = getenv("DFK_NO_OVERLAP") == nullptr;
     uint32_t n_passes = 0, retries = 0;
     c->seg_attempt = 0; c->distinct_per_inst = 0.0;
-    struct Job { ScatterJob sj; uint64_t mark = 0; bool valid = false; };
+    struct Job { ScatterJob sj; dfk_ctx::PassBlock blk; uint64_t mark = 0; bool valid = false; };
     Job cur, nxt;
     auto drop_events = [&](Job& j) { if (j.sj.e0) { (void)hipEventDestroy(j.sj.e0); (void)hipEventDestroy(j.sj.e1); j.sj.e0 = j.sj.e1 = nullptr; } };
     // start the scatter of [lo, lo + n) on the second stream; NOMEM leaves nothing behind
     auto start = [&](Job& j, uint32_t lo, uint32_t n) -> int {
         j.sj = ScatterJob{}; j.mark = c->alloc_seq; j.valid = false;
         TRACE("pass range [%u, %u) of %u (%.1f %%), %.2f GB held of %.2f", lo, lo + n, sub_nb, 100.0 * n / sub_nb, c->held / 1e9, c->budget / 1e9);
-        int r;
-        { StreamSwap sw(c, c->stream2); r = scatter_begin<K>(c, in, T, 0, 0, lo, n, &j.sj); }
+        // the pass's block: tables (80 B per bucket with their scratch), records, and the output segments that
+        // count_prepare will size (an estimate: what does not fit the block falls back to the open arena)
+        const double share = (double)n / sub_nb;
+        const uint64_t seg_est = (uint64_t)(solid_cap(c, R, (uint64_t)(share * (double)T.n_inst)) * 32.0 * 1.25 * (double)(1u << c->seg_attempt))
+                               + 8192ull * 32 * count_grid<K>(c) * (1ull << c->seg_attempt) + (1ull << 20);
+        const uint64_t blk_bytes = (uint64_t)(1.01 * (80.0 * n + 32.0 * share * (double)T.n_records)) + seg_est + (16ull << 20);
+        j.blk = dfk_ctx::PassBlock{};
+        int r = c->alloc(j.blk.block, blk_bytes, "pass block");
+        if (!r) {
+            c->sub = &j.blk;
+            { StreamSwap sw(c, c->stream2); r = scatter_begin<K>(c, in, T, 0, 0, lo, n, &j.sj); }
+            c->sub = nullptr;
+        }
         if (r) { (void)hipStreamSynchronize(c->stream2); c->release_since(j.mark); drop_events(j); return r; }
         j.valid = true;
         return 0;
@@ -938,7 +1039,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     // the first range of a (re)started sequence: alone, shrinking until it fits
     auto start_alone = [&](Job& j, uint32_t lo) -> int {
         for (;;) {
-            const uint32_t n = forced ? std::min(per_forced, sub_nb - lo) : plan_range(c, T, R, sub_nb, lo, nullptr);
+            const uint32_t n = forced ? std::min(per_forced, sub_nb - lo) : plan_range(c, T, R, sub_nb, lo, nullptr, overlap);
             const int r = start(j, lo, n);
             if (r != DFK_E_NOMEM || forced || n <= 16 || ++retries > 12) return r;
             c->plan_derate *= 0.7;
@@ -951,12 +1052,15 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         rc = scatter_end(c, &cur.sj); if (rc) return rc;
         const dfk_stats st0 = c->st;
         rc = count_snapshot(c, &R, false); if (rc) return rc;
+        c->sub = &cur.blk;
         rc = count_prepare<K>(c, cur.sj.P, R);
+        c->sub = nullptr;
         nxt.valid = false;
         if (!rc && overlap && nlo < sub_nb) {
             const Partition& P = cur.sj.P;
-            const RunningPass rp{P.records.bytes + P.base.bytes + P.ipre.bytes + P.items.bytes + R.d_seg.bytes + R.d_segcnt.bytes, P.n_inst};
-            const uint32_t n2 = forced ? std::min(per_forced, sub_nb - nlo) : plan_range(c, T, R, sub_nb, nlo, &rp);
+            (void)P;
+            const RunningPass rp{cur.blk.block.bytes, cur.sj.P.n_inst, n, (uint64_t)((char*)cur.blk.block.p - c->chunks[0].p)};
+            const uint32_t n2 = forced ? std::min(per_forced, sub_nb - nlo) : plan_range(c, T, R, sub_nb, nlo, &rp, overlap);
             if (n2) {
                 const int r2 = start(nxt, nlo, n2);
                 if (r2 && r2 != DFK_E_NOMEM) return r2;                // NOMEM: this range is scattered after the count instead
@@ -966,7 +1070,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         if (rc == DFK_E_NOMEM || rc == E_SEGMENT_FULL) {
             HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipStreamSynchronize(c->stream2));
             c->release_since(cur.mark);                               // this pass and the one started under it
-            R.d_seg = R.d_segcnt = R.big = DevBuf{};
+            R.d_seg = R.d_segcnt = R.big = R.d_part = DevBuf{};
             drop_events(cur); drop_events(nxt); nxt.valid = false;
             int rc2 = count_snapshot(c, &R, true); if (rc2) return rc2;
             const float ms_scatter = c->st.ms_part_scatter, ms_count = c->st.ms_count, ms_fb = c->st.ms_fallback;
@@ -981,6 +1085,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         }
         if (rc) return rc;
         release_pass(c, &cur.sj.P);
+        c->release(cur.blk.block);
         drop_events(cur);
         ++n_passes;
         c->seg_attempt = 0;                                           // later passes size their output from the observed ratio

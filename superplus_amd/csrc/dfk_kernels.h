@@ -131,7 +131,7 @@ __device__ __forceinline__ void emit_record(const uint32_t* __restrict__ words, 
                                             uint64_t dst_index, uint4* __restrict__ records)
 {
     const bool hp = s0 > 0;
-    const bool hs = s0 + nk + (uint32_t)K <= gl;
+    const bool hs = s0 + nk + (uint32_t)K <= gl;                 // (callers that do not know gl pass 0xFFFFFFFF or 0: succ / no succ)
     // bases [s0-1, s0+nk+K) of the read (slot 0 is a dummy when the run starts the read)
     uint64_t bo = bit0 + 2ull * (hp ? s0 - 1 : 0);
     uint64_t wi = bo >> 5; uint32_t sh = (uint32_t)bo & 31u;
@@ -394,7 +394,7 @@ __device__ __forceinline__ void for_each_run_in_pass(uint64_t r, const uint8_t* 
             const uint32_t fw = y >> (32 - 2 * M), rcv = ~x & mmask;             // the scan's forward / reverse-complement values
             const uint32_t bucket = bucket_of(mmer_hash(fw < rcv ? fw : rcv), pp);
             const uint32_t lb = pass_local(bucket, pp);
-            if (lb != 0xFFFFFFFFu) f(s0, nk, lb, bucket >> (pp.log2_nb - pp.log2_world), bit0);
+            if (lb != 0xFFFFFFFFu) f(s0, nk, lb, bucket >> (pp.log2_nb - pp.log2_world), bit0, (uint32_t)i + 1 == n);
             s0 += nk;
         }
     }
@@ -419,7 +419,7 @@ k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, cons
         const uint64_t r = r_first + 256ull * j;
         if (r < n_reads)
             for_each_run_in_pass<K, false>(r, packed, packed_bytes, base_off, pp, summaries,
-                                           [&](uint32_t, uint32_t, uint32_t, uint32_t owner, uint64_t) { atomicAdd(&cnt[owner], 1u); });
+                                           [&](uint32_t, uint32_t, uint32_t, uint32_t owner, uint64_t, bool) { atomicAdd(&cnt[owner], 1u); });
     }
     __syncthreads();
     if (threadIdx.x < world) {
@@ -433,13 +433,13 @@ k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, cons
     for (int j = 0; j < SLICE_READS; ++j) {
         const uint64_t r = r_first + 256ull * j;
         if (r >= n_reads) continue;
-        const uint32_t gl = good_len[r];
         int32_t tag = -1;
         if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
         for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
-            [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t owner, uint64_t bit0) {
+            [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t owner, uint64_t bit0, bool last) {
                 const uint64_t dst = at[owner] + atomicAdd(&cnt[owner], 1u);
-                if (dst < slice_base[owner + 1]) emit_record<K>(words, n_words, bit0, s0, nk, lb, gl, tag, dst, records);
+                // only the read's last run has no successor base (its last k-mer ends the trimmed read)
+                if (dst < slice_base[owner + 1]) emit_record<K>(words, n_words, bit0, s0, nk, lb, last ? 0u : 0xFFFFFFFFu, tag, dst, records);
             });
     }
 }
@@ -457,15 +457,16 @@ k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const 
 {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_reads) return;
-    const uint32_t gl = good_len[r];
+    (void)good_len;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
     const uint64_t n_words = (packed_bytes + 3) >> 2;
     int32_t tag = -1;
     if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
     for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
-        [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t, uint64_t bit0) {
+        [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t, uint64_t bit0, bool last) {
             const uint64_t dst = atomicAdd(&bucket_cur[lb], 1ull);             // one random access for base and rank
-            if (dst < n_out) emit_record<K>(words, n_words, bit0, s0, nk, lb, gl, tag, dst, records);
+            // only the read's last run has no successor base (its last k-mer ends the trimmed read)
+            if (dst < n_out) emit_record<K>(words, n_words, bit0, s0, nk, lb, last ? 0u : 0xFFFFFFFFu, tag, dst, records);
         });
 }
 
