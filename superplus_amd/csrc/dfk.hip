@@ -472,7 +472,6 @@ int scatter_begin(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t l
     rc = c->alloc(J->d_bad, 16, "scatter check"); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(J->cur.p, P->base.p, nb * 8, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(J->d_bad.p, 0, 16, c->stream));
-    const size_t lds_b = sizeof(uint32_t) * pp.W * PART_THREADS + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
     if (!J->e0) { HIP_TRY(hipEventCreate(&J->e0)); HIP_TRY(hipEventCreate(&J->e1)); }
     HIP_TRY(hipEventRecord(J->e0, c->stream));
     if (in.n_reads)
@@ -481,27 +480,38 @@ int scatter_begin(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t l
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p,
                            (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p);
     HIP_TRY(hipGetLastError());
-    // the few reads with more runs than a summary holds are scanned again
-    if (T.n_ovf)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3((unsigned)((T.n_ovf + PART_THREADS - 1) / PART_THREADS)),
-                           dim3(PART_THREADS), lds_b, c->stream,
-                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
-                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                           (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p, (uint4*)nullptr,
-                           (const uint32_t*)T.ovf_list.p, T.n_ovf, (const uint64_t*)nullptr);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, (const unsigned long long*)J->cur.p,
-                       (const uint64_t*)P->base.p, nb, (unsigned int*)J->d_bad.p);
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(J->e1, c->stream));
     return 0;
 }
 
-int scatter_end(dfk_ctx* c, ScatterJob* J)
+template <int K>
+int scatter_end(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0, ScatterJob* J)
 {
     HIP_TRY(hipEventSynchronize(J->e1));
     float ms = 0; (void)hipEventElapsedTime(&ms, J->e0, J->e1);
     c->st.ms_part_scatter += ms;
+    // The few reads with more runs than a summary holds are scanned again -- here, on the main stream, between
+    // two counts: a handful of blocks on the low-priority stream wait milliseconds for a wave slot while
+    // k_count runs.  Then every bucket must have received exactly the records counted for it.
+    {
+        Partition* P = &J->P;
+        const PartParams pp = part_params<K>(c, T.log2_nb, log2_world, read_id0, J->lo, J->n);
+        const size_t lds_b = sizeof(uint32_t) * pp.W * PART_THREADS + sizeof(uint32_t) * 2 * PART_QCAP * PART_THREADS;
+        Timer t(c->stream);
+        t.start();
+        if (T.n_ovf)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, true>), dim3((unsigned)((T.n_ovf + PART_THREADS - 1) / PART_THREADS)),
+                               dim3(PART_THREADS), lds_b, c->stream,
+                               in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
+                               (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                               (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p, (uint4*)nullptr,
+                               (const uint32_t*)T.ovf_list.p, T.n_ovf, (const uint64_t*)nullptr);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)((P->nb + 255) / 256)), dim3(256), 0, c->stream, (const unsigned long long*)J->cur.p,
+                           (const uint64_t*)P->base.p, P->nb, (unsigned int*)J->d_bad.p);
+        HIP_TRY(hipGetLastError());
+        c->st.ms_part_scatter += t.stop();
+    }
     unsigned int bad = 0;
     HIP_TRY(hipMemcpy(&bad, J->d_bad.p, 4, hipMemcpyDeviceToHost));
     c->release(J->d_bad); c->release(J->cur);
@@ -1049,7 +1059,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     rc = start_alone(cur, 0); if (rc) return rc;
     while (cur.valid) {
         const uint32_t lo = cur.sj.lo, n = cur.sj.n, nlo = lo + n;
-        rc = scatter_end(c, &cur.sj); if (rc) return rc;
+        rc = scatter_end<K>(c, in, T, 0, 0, &cur.sj); if (rc) return rc;
         const dfk_stats st0 = c->st;
         rc = count_snapshot(c, &R, false); if (rc) return rc;
         c->sub = &cur.blk;

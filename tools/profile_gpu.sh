@@ -11,4 +11,7 @@ CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/bench_write.log 2>&1
+# the per-launch kernel traces are large and not needed once the stats exist (gpurun returns at most 64 MiB)
+find $OUT/fetch $OUT/write -name '*_kernel_trace.csv' -delete
+find $OUT/trace -name '*_kernel_trace.csv' -size +20M -delete
 find $OUT -name '*.csv' | head -50
