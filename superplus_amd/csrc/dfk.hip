@@ -1205,7 +1205,7 @@ int dfk_create(const dfk_config* cfg, dfk_ctx** out)
         int lo_pri = 0, hi_pri = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri);      // numerically lowest = highest priority
         HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi_pri));
-        HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamDefault, lo_pri));
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamDefault, getenv("DFK_S2_SAME_PRIO") ? hi_pri : lo_pri));
     }
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
