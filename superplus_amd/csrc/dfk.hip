@@ -986,7 +986,8 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
     if (left <= 0.99 * fit && left < 1.06 * n) n = left;              // no sliver of a last pass if the rest (almost certainly) fits
     else if (left > n && left < 1.3 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big and a small one
     n = std::min(n, left);
-    return n < 16.0 ? (running ? 0u : 16u) : (uint32_t)n;
+    if (n < 16.0) return running ? 0u : (uint32_t)std::min(16.0, left);
+    return (uint32_t)n;
 }
 
 struct StreamSwap {                                    // run a stretch of host code against the second stream
@@ -1050,6 +1051,10 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     auto start_alone = [&](Job& j, uint32_t lo) -> int {
         for (;;) {
             const uint32_t n = forced ? std::min(per_forced, sub_nb - lo) : plan_range(c, T, R, sub_nb, lo, nullptr, overlap);
+            // a budget that leaves room for slivers only would take thousands of passes: say so instead
+            if (!forced && n < sub_nb - lo && (uint64_t)n * 1024 < sub_nb)
+                return fail(DFK_E_NOMEM, "HBM budget too small: %.2f GB free of %.2f GB allows passes of %u of %u buckets",
+                            (c->budget - c->held) / 1e9, c->budget / 1e9, n, sub_nb);
             const int r = start(j, lo, n);
             if (r != DFK_E_NOMEM || forced || n <= 16 || ++retries > 12) return r;
             c->plan_derate *= 0.7;

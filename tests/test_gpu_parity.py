@@ -197,3 +197,27 @@ def test_repeat_family_hot_minimizers(oracle):
     ref, d = util.run_both(oracle, rs, K=48)
     st = util.check_parity(ref, d)
     assert st["n_overflow_items"] > 20
+
+
+def test_small_hbm_budget_plans_its_own_passes(oracle):
+    """With little HBM the library cuts the bucket space into ranges by itself (two passes in flight, each in its
+    own block, dictionary parts reserved at the top): same answer, more than one pass."""
+    rs = util.make_set(71, 5_000_000, 800_000)
+    ref, d = util.run_both(oracle, rs, K=48, hbm_budget_bytes=1200 << 20)
+    st = util.check_parity(ref, d)
+    assert st["n_passes"] >= 3, st["n_passes"]
+    # and a budget that cannot hold even small passes beside the dictionary is an error, not a crawl
+    from superplus_amd.dfk import Dfk, DfkError
+    tiny = Dfk(K=48, hbm_budget_bytes=700 << 20)
+    with pytest.raises(DfkError) as e:
+        tiny.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    assert e.value.code == -4
+
+
+def test_output_segments_too_small_are_redone(oracle):
+    """MIN_FREQ=1 at low coverage: nearly every instance is a solid k-mer, far more than the first pass's prior
+    (instances/16) sizes the output segments for; the pass is undone and redone with more room."""
+    rs = util.make_set(73, 12_000_000, 150_000, err=0.0)
+    ref, d = util.run_both(oracle, rs, K=48, min_freq=1, min_bc=0)
+    st = util.check_parity(ref, d)
+    assert st["n_solid"] > 8_000_000
