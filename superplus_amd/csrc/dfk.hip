@@ -104,11 +104,11 @@ struct dfk_ctx {
     uint64_t reserved = 0;                           // sum of chunk sizes
 
     uint64_t first_chunk_hint = 0;                   // set from the input size before a run: one big chunk, no growth
-    // long-lived blocks (dictionary parts, goodLens, bucket counters) are carved from the top of a chunk,
-    // per-pass temporaries from the bottom, so that the two kinds do not fragment each other
-    bool carve(Chunk& k, size_t bytes, DevBuf& b, bool top)
+    // long-lived blocks (dictionary parts, goodLens, bucket counters, summaries) grow from the bottom of the chunk,
+    // per-pass blocks and temporaries come from the top, so that the two kinds do not fragment each other
+    bool carve(Chunk& k, size_t bytes, DevBuf& b, bool long_lived)
     {
-        if (top) {
+        if (!long_lived) {                              // temporaries: the highest free block that fits, its upper end
             for (size_t i = k.free_list.size(); i-- > 0;)
                 if (k.free_list[i].bytes >= bytes) {
                     k.free_list[i].bytes -= bytes;
@@ -118,7 +118,7 @@ struct dfk_ctx {
                 }
             return false;
         }
-        for (size_t i = 0; i < k.free_list.size(); ++i)
+        for (size_t i = 0; i < k.free_list.size(); ++i)  // long-lived: the lowest free block that fits, its lower end
             if (k.free_list[i].bytes >= bytes) {
                 b.p = k.p + k.free_list[i].off; b.bytes = bytes;
                 k.free_list[i].off += bytes; k.free_list[i].bytes -= bytes;
@@ -199,19 +199,18 @@ struct dfk_ctx {
             }
         held -= b.bytes; b.p = nullptr; b.bytes = 0;
     }
-    // keep only the upper `keep` bytes of a block (blocks carved from the top grow downwards: a reservation made
-    // for an upper bound is cut to what was needed, and the block stays adjacent to its long-lived neighbours)
-    void shrink_top(DevBuf& b, size_t keep)
+    // keep only the first `keep` bytes of a block: a reservation made for an upper bound is cut to what was
+    // needed; the tail goes back to the free room above it (long-lived blocks grow upwards)
+    void shrink(DevBuf& b, size_t keep)
     {
         keep = keep ? (keep + 255) & ~(size_t)255 : 256;
         if (!b.p || keep >= b.bytes) return;
-        const size_t cut = b.bytes - keep;
         auto it = std::find_if(owned.begin(), owned.end(), [&](const Owned& o) { return o.p == b.p; });
-        DevBuf low; low.p = b.p; low.bytes = cut;
-        b.p = (char*)b.p + cut; b.bytes = keep;
-        if (it != owned.end()) { it->p = b.p; it->bytes = keep; owned.push_back(Owned{low.p, (uint64_t)cut, it->seq}); }
-        else owned.push_back(Owned{low.p, (uint64_t)cut, alloc_seq});
-        release(low);
+        DevBuf tail; tail.p = (char*)b.p + keep; tail.bytes = b.bytes - keep;
+        b.bytes = keep;
+        if (it != owned.end()) { it->bytes = keep; owned.push_back(Owned{tail.p, (uint64_t)tail.bytes, it->seq}); }
+        else owned.push_back(Owned{tail.p, (uint64_t)tail.bytes, alloc_seq});
+        release(tail);
     }
     // give back everything allocated after `mark` (= alloc_seq at some earlier moment): what an abandoned
     // pass left behind.  The DevBufs that pointed at those blocks are dead; the caller resets them.
@@ -811,7 +810,7 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     dfk_ctx::Part part;
     part.n = prefix[nseg] + hg.big_cursor;
     DevBuf d_prefix;
-    if (part.n * 32 <= R.d_part.bytes) { part.buf = R.d_part; R.d_part = DevBuf{}; c->shrink_top(part.buf, part.n * 32); }
+    if (part.n * 32 <= R.d_part.bytes) { part.buf = R.d_part; R.d_part = DevBuf{}; c->shrink(part.buf, part.n * 32); }
     else { c->release(R.d_part); rc = c->alloc(part.buf, part.n * 32, "solid k-mer entries", true); if (rc) return rc; }
     rc = c->alloc(d_prefix, 8ull * (nseg + 1), "segment prefix"); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_prefix.p, prefix.data(), 8ull * (nseg + 1), hipMemcpyHostToDevice, c->stream));
@@ -915,10 +914,10 @@ uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
 // and part must fit once the running pass has been released.
 struct RunningPass { uint64_t bytes_held; uint64_t n_inst; uint32_t n_buckets; uint64_t block_off; };
 
-// The same question asked of the arena's actual free blocks (one chunk).  A pass block goes to the lowest free
+// The same question asked of the arena's actual free blocks (one chunk).  A pass block goes to the highest free
 // block that holds it -- now, beside the running pass.  The reservation for its part is made later, when the
-// running pass's block is gone, and goes to the highest free block: it has to fit there, or it lands in a low
-// hole and cuts the room of later blocks.  Largest n for which both hold, by bisection.
+// running pass's block is gone, and goes to the lowest free block (the dictionary grows upwards): it has to fit
+// there, or it lands higher up and cuts the room of later blocks.  Largest n for which both hold, by bisection.
 double fit_free_blocks(const dfk_ctx* c, double per_block, double per_res, const RunningPass& run)
 {
     if (c->chunks.size() != 1 || c->chunks[0].free_list.empty()) return 1e300;
@@ -926,19 +925,21 @@ double fit_free_blocks(const dfk_ctx* c, double per_block, double per_res, const
     auto feasible = [&](double n) {
         const uint64_t B = (uint64_t)(per_block * n / 0.98) + 1;
         size_t at = fl.size();
-        for (size_t i = 0; i < fl.size(); ++i) if (fl[i].bytes >= B) { at = i; break; }
+        for (size_t i = fl.size(); i-- > 0;) if (fl[i].bytes >= B) { at = i; break; }
         if (at == fl.size()) return false;
-        // free list once the running block is gone and the new block is in place
+        // free list once the running block is gone and the new block is in place (at the upper end of fl[at])
         std::vector<dfk_ctx::Free> h(fl.begin(), fl.end());
-        h[at].off += B; h[at].bytes -= B;
+        h[at].bytes -= B;
         h.push_back(dfk_ctx::Free{run.block_off, run.bytes_held});
         std::sort(h.begin(), h.end(), [](const dfk_ctx::Free& a, const dfk_ctx::Free& b) { return a.off < b.off; });
-        uint64_t top_off = 0, top_bytes = 0;
-        for (const dfk_ctx::Free& f : h) {
+        uint64_t low_off = 0, low_bytes = 0; bool have = false;
+        for (const dfk_ctx::Free& f : h) {                             // the lowest run of adjacent free blocks
             if (!f.bytes) continue;
-            if (top_bytes && top_off + top_bytes == f.off) top_bytes += f.bytes; else { top_off = f.off; top_bytes = f.bytes; }
+            if (!have) { low_off = f.off; low_bytes = f.bytes; have = true; }
+            else if (low_off + low_bytes == f.off) low_bytes += f.bytes;
+            else break;
         }
-        return per_res * n <= 0.98 * (double)top_bytes;
+        return per_res * n <= 0.98 * (double)low_bytes;
     };
     double lo = 0.0, hi = 0.0;
     for (const dfk_ctx::Free& f : fl) hi = std::max(hi, 0.98 * (double)f.bytes / per_block);
