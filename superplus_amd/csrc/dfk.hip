@@ -524,13 +524,13 @@ int scatter_end(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log
 constexpr int E_SEGMENT_FULL = -100;   // internal: redo the run with larger output segments
 
 struct CountRun {                     // device state shared by the count launches of one run
-    CountGlobals* g = nullptr; uint4* seg = nullptr; uint32_t* seg_count = nullptr; unsigned long long* hist = nullptr;
+    CountGlobals* g = nullptr; uint4* seg = nullptr; unsigned long long* hist = nullptr;
     CountParams cp{}; unsigned grid = 0;
     DevBuf big; uint64_t big_cap = 0;  // output of the HBM-table fallback (its own buffer)
     DevBuf d_hist, d_g;                // spectrum bins and counters: live across the passes of one run
     DevBuf d_snap;                     // their state before the current pass (a pass that runs out of room is undone and redone)
-    DevBuf d_seg, d_segcnt;            // output segments of the pass being counted (count_prepare .. count_run)
-    DevBuf d_part;                     // room reserved for its dense part, at the top, before anything else is placed beside it
+    DevBuf d_part;                     // room reserved for the dense part of the pass being counted (count_prepare .. count_run)
+    DevBuf d_wg;                       // WgOut of every persistent workgroup
     uint64_t solid_seen = 0, inst_seen = 0;   // totals of the passes done so far (sizes the next pass's output)
 };
 
@@ -616,7 +616,7 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
     Timer tk(c->stream);
     tk.start();
     hipLaunchKernelGGL(kern, dim3(R.grid), dim3(NW * 64), lds, c->stream,
-                       (const uint4*)P.records.p, d_items, (const uint64_t*)P.base.p, cp, R.g, R.seg, R.seg_count, R.hist,
+                       (const uint4*)P.records.p, d_items, (const uint64_t*)P.base.p, cp, R.g, R.seg, (WgOut*)R.d_wg.p, R.hist,
                        (ItemRange*)d_ovf.p);
     HIP_TRY(hipGetLastError());
     *kernel_ms += tk.stop();
@@ -725,45 +725,39 @@ uint64_t solid_cap(const dfk_ctx* c, const CountRun& R, uint64_t n_inst)
     return cap;
 }
 
+template <int K> constexpr uint64_t out_chunk() { return 2ull << CountCfg<K>::LOG2S; }   // = table_finish's OUT_CHUNK
+
 template <int K>
 int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R)
 {
     const unsigned attempt = c->seg_attempt;
-    // Output: one segment per persistent workgroup, filled through an LDS cursor.  Every solid k-mer has
-    // >= min_freq instances, which bounds the total; after the first pass the observed solid/instance
-    // ratio gives a much tighter estimate.
+    // Output: the pass's part of the dictionary, reserved now (from the bottom of the arena's free room, where the
+    // dictionary grows) so that what is placed next -- the block of the following range -- cannot fragment the
+    // room it needs.  The persistent workgroups fill it chunk by chunk (WgOut); count_run cuts it to size.
+    // Every solid k-mer has >= min_freq instances, which bounds the total; after the first pass the observed
+    // solid/instance ratio holds to a fraction of a percent (buckets are hash-distributed).
     R.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(P.n_items, count_grid<K>(c)));
-    const uint32_t nseg = R.grid;
-    uint64_t cap = solid_cap(c, R, P.n_inst);
+    uint64_t res = solid_cap(c, R, P.n_inst);
+    if (R.inst_seen) res = std::min<uint64_t>(res, (uint64_t)(1.08 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
+    res = (res << attempt) + (uint64_t)R.grid * out_chunk<K>();       // + the chunk ends the workgroups leave empty
     const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
-    // the segments (5/4 of the estimate) and the dense part made from them both have to fit
-    if ((double)cap * 32.0 * 2.3 > (double)room) cap = (uint64_t)((double)room / (32.0 * 2.3));
-    // dynamic item scheduling balances the workgroups to within a few items (<= 3/4 S entries each);
-    // if a segment still fills up the whole run is redone with twice the room
-    const uint64_t seg_cap = std::min<uint64_t>(((cap / nseg) * 5 / 4 + 8192) << attempt, 0xFFFFFFF0ull);
-    DevBuf& d_seg = R.d_seg; DevBuf& d_segcnt = R.d_segcnt;
-    int rc = c->alloc(d_seg, seg_cap * nseg * 32, "solid k-mer segments"); if (rc) return rc;
-    rc = c->alloc(d_segcnt, 4ull * nseg, "segment counts"); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(d_segcnt.p, 0, 4ull * nseg, c->stream));
+    if (res * 32 > room) res = room / 32;
+    int rc = c->alloc(R.d_wg, sizeof(WgOut) * R.grid, "workgroup output state"); if (rc) return rc;
+    std::vector<WgOut> init(R.grid, WgOut{~0ull, (unsigned int)out_chunk<K>(), 0u});   // no chunk yet: the first item takes one
+    HIP_TRY(hipMemcpy(R.d_wg.p, init.data(), sizeof(WgOut) * R.grid, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(&R.g->big_cursor, 0, 8, c->stream));
-    R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, nseg, seg_cap, c->cfg.min_freq > 1 ? 1u : 0u,
+    HIP_TRY(hipMemsetAsync(&R.g->part_cursor, 0, 8, c->stream));
+    R.cp = CountParams{c->cfg.min_freq, c->cfg.min_bc, 0, 0, res, c->cfg.min_freq > 1 ? 1u : 0u,
                        (c->cfg.flags & DFK_F_KEEP_PRE_ADJ) ? 1u : 0u};
-    R.seg = (uint4*)d_seg.p; R.seg_count = (uint32_t*)d_segcnt.p; R.big_cap = 0;
-    // the part is reserved now, from the top, so that what is placed next (the records of the following pass)
-    // cannot fragment the room it needs; count_run cuts the reservation to size
-    // (once a pass has shown the solid/instance ratio the estimate is good to a fraction of a percent: the
-    // reservation is then 1.08x the expectation rather than the segments' 1.3x)
-    uint64_t res = cap;
-    if (R.inst_seen) res = std::min<uint64_t>(cap, (uint64_t)(1.08 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
-    return c->alloc(R.d_part, std::max<uint64_t>(1, res) * 32, "solid k-mer entries", true);
+    R.big_cap = 0;
+    rc = c->alloc(R.d_part, std::max<uint64_t>(1, res) * 32, "solid k-mer entries", true); if (rc) return rc;
+    R.seg = (uint4*)R.d_part.p;
+    return 0;
 }
 
 template <int K, bool USE_BC>
 int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
 {
-    DevBuf& d_seg = R.d_seg; DevBuf& d_segcnt = R.d_segcnt;
-    const uint32_t nseg = R.cp.n_segments;
-    const uint64_t seg_cap = R.cp.seg_cap;
     int rc = 0;
     Timer t(c->stream);
     std::vector<ItemRange> overflowed;
@@ -796,31 +790,54 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     c->st.ms_fallback += t.stop();
 
     CountGlobals hg{};
-    std::vector<uint32_t> segcnt(nseg);
+    std::vector<WgOut> wg(R.grid);
     HIP_TRY(hipMemcpy(&hg, R.d_g.p, sizeof hg, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(segcnt.data(), d_segcnt.p, 4ull * nseg, hipMemcpyDeviceToHost));
-    if (hg.solid_overflow || hg.big_cursor > R.big_cap) {
+    HIP_TRY(hipMemcpy(wg.data(), R.d_wg.p, sizeof(WgOut) * R.grid, hipMemcpyDeviceToHost));
+    c->release(R.d_wg);
+    const uint64_t CH = out_chunk<K>(), claimed = hg.part_cursor;
+    // the holes: the unused end of every workgroup's last chunk
+    std::vector<std::pair<uint64_t, uint64_t>> holes;
+    uint64_t n_holes = 0;
+    for (const WgOut& w : wg) if (w.chunk != ~0ull && w.used < CH) { holes.push_back({w.chunk + w.used, w.chunk + CH}); n_holes += CH - w.used; }
+    const uint64_t n_lds = claimed - n_holes;                          // solid k-mers the LDS path emitted
+    if (hg.solid_overflow || claimed > R.cp.seg_cap || hg.big_cursor > R.big_cap || n_lds + hg.big_cursor > R.cp.seg_cap) {
         // the caller undoes the pass and redoes it with more room
-        c->release(d_seg); c->release(d_segcnt); c->release(R.big); c->release(R.d_part);
-        fail(DFK_E_NOMEM, "a solid k-mer output segment (%llu entries) is full", (unsigned long long)seg_cap);
+        c->release(R.big); c->release(R.d_part);
+        fail(DFK_E_NOMEM, "the room reserved for a pass's solid k-mers (%llu entries) is full", (unsigned long long)R.cp.seg_cap);
         return E_SEGMENT_FULL;
     }
-    std::vector<uint64_t> prefix(nseg + 1, 0);
-    for (uint32_t sg = 0; sg < nseg; ++sg) prefix[sg + 1] = prefix[sg] + segcnt[sg];
+    // entries beyond n_lds move into the holes below n_lds: afterwards [0, n_lds) is dense
+    std::sort(holes.begin(), holes.end());
+    std::vector<uint64_t> dst, src;
+    for (const auto& h : holes) for (uint64_t i = h.first; i < std::min(h.second, n_lds); ++i) dst.push_back(i);
+    {
+        size_t hi = 0;
+        for (uint64_t i = n_lds; i < claimed && src.size() < dst.size(); ++i) {
+            while (hi < holes.size() && holes[hi].second <= i) ++hi;
+            if (hi < holes.size() && holes[hi].first <= i) { i = holes[hi].second - 1; continue; }   // skip a hole
+            src.push_back(i);
+        }
+    }
+    if (src.size() != dst.size())
+        return fail(DFK_E_HIP, "output compaction: %zu holes, %zu entries to move", dst.size(), src.size());
     dfk_ctx::Part part;
-    part.n = prefix[nseg] + hg.big_cursor;
-    DevBuf d_prefix;
-    if (part.n * 32 <= R.d_part.bytes) { part.buf = R.d_part; R.d_part = DevBuf{}; c->shrink(part.buf, part.n * 32); }
-    else { c->release(R.d_part); rc = c->alloc(part.buf, part.n * 32, "solid k-mer entries", true); if (rc) return rc; }
-    rc = c->alloc(d_prefix, 8ull * (nseg + 1), "segment prefix"); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d_prefix.p, prefix.data(), 8ull * (nseg + 1), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_compact, dim3(8, nseg), dim3(256), 0, c->stream, (const uint4*)d_seg.p, seg_cap,
-                       (const uint64_t*)d_prefix.p, (uint4*)part.buf.p);
-    HIP_TRY(hipGetLastError());
+    part.n = n_lds + hg.big_cursor;
+    part.buf = R.d_part; R.d_part = DevBuf{};
+    if (!src.empty()) {
+        DevBuf d_mv; rc = c->alloc(d_mv, 16ull * src.size(), "hole moves"); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(d_mv.p, src.data(), 8ull * src.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync((uint64_t*)d_mv.p + src.size(), dst.data(), 8ull * src.size(), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_fill_holes, dim3((unsigned)((src.size() + 255) / 256)), dim3(256), 0, c->stream, (uint4*)part.buf.p,
+                           (const uint64_t*)d_mv.p, (const uint64_t*)d_mv.p + src.size(), (uint64_t)src.size());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->release(d_mv);
+    }
     if (hg.big_cursor)
-        HIP_TRY(hipMemcpyAsync((char*)part.buf.p + 32 * prefix[nseg], R.big.p, 32 * hg.big_cursor, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync((char*)part.buf.p + 32 * n_lds, R.big.p, 32 * hg.big_cursor, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->release(d_seg); c->release(d_segcnt); c->release(d_prefix); c->release(R.big);
+    c->release(R.big);
+    c->shrink(part.buf, part.n * 32);
     c->parts.push_back(part);
     c->n_solid += part.n; c->st.n_solid = c->n_solid;
     R.solid_seen += part.n; R.inst_seen += P.n_inst;
@@ -956,9 +973,9 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
     double ratio = R.inst_seen ? 1.12 * (double)R.solid_seen / (double)R.inst_seen : 1.0 / 16.0;
     ratio = std::min(ratio, 1.0 / std::max<uint32_t>(1, c->cfg.min_freq));
     const double per_in = 81.0 + 32.5 * rec_per;                                         // tables and records (as the pass block is sized)
-    const double per_seg = 32.0 * ratio * inst_per * 1.25 * (double)(1u << c->seg_attempt);            // output segments (inside the pass block)
-    const double per_out = per_seg + 32.0 * ratio * inst_per;                                         // ... and the part's reservation
-    const double fixed = 300e6;                                       // segment slack (8192 entries each), small tables
+    const double per_seg = 0.0;                                                                       // (no output segments any more: workgroups write into the part's reservation)
+    const double per_out = 32.0 * ratio * inst_per * (double)(1u << c->seg_attempt);                  // the part's reservation
+    const double fixed = 120e6;                                       // chunk ends left empty by the workgroups (67 MB), small tables
     const double left = (double)(sub_nb - lo);
     double fit;
     if (!running) {
@@ -1032,12 +1049,10 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     auto start = [&](Job& j, uint32_t lo, uint32_t n) -> int {
         j.sj = ScatterJob{}; j.mark = c->alloc_seq; j.valid = false;
         TRACE("pass range [%u, %u) of %u (%.1f %%), %.2f GB held of %.2f", lo, lo + n, sub_nb, 100.0 * n / sub_nb, c->held / 1e9, c->budget / 1e9);
-        // the pass's block: tables (80 B per bucket with their scratch), records, and the output segments that
-        // count_prepare will size (an estimate: what does not fit the block falls back to the open arena)
+        // the pass's block: tables (80 B per bucket with their scratch) and records (an estimate: what does not
+        // fit the block falls back to the open arena)
         const double share = (double)n / sub_nb;
-        const uint64_t seg_est = (uint64_t)(solid_cap(c, R, (uint64_t)(share * (double)T.n_inst)) * 32.0 * 1.25 * (double)(1u << c->seg_attempt))
-                               + 8192ull * 32 * count_grid<K>(c) * (1ull << c->seg_attempt) + (1ull << 20);
-        const uint64_t blk_bytes = (uint64_t)(1.01 * (80.0 * n + 32.0 * share * (double)T.n_records)) + seg_est + (16ull << 20);
+        const uint64_t blk_bytes = (uint64_t)(1.01 * (80.0 * n + 32.0 * share * (double)T.n_records)) + (16ull << 20);
         j.blk = dfk_ctx::PassBlock{};
         int r = c->alloc(j.blk.block, blk_bytes, "pass block");
         if (!r) {
@@ -1087,7 +1102,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         if (rc == DFK_E_NOMEM || rc == E_SEGMENT_FULL) {
             HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipStreamSynchronize(c->stream2));
             c->release_since(cur.mark);                               // this pass and the one started under it
-            R.d_seg = R.d_segcnt = R.big = R.d_part = DevBuf{};
+            R.d_wg = R.big = R.d_part = DevBuf{};
             drop_events(cur); drop_events(nxt); nxt.valid = false;
             int rc2 = count_snapshot(c, &R, true); if (rc2) return rc2;
             const float ms_scatter = c->st.ms_part_scatter, ms_count = c->st.ms_count, ms_fb = c->st.ms_fallback;

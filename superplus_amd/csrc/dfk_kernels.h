@@ -484,8 +484,8 @@ struct ItemRange { uint32_t b0, b1; };     // a work item: fine buckets [b0,b1) 
 struct CountParams {
     uint32_t min_freq, min_bc;
     uint32_t n_items;
-    uint32_t n_segments;             // output segments (one per persistent workgroup)
-    uint64_t seg_cap;                // entries per segment
+    uint32_t n_segments;             // (unused)
+    uint64_t seg_cap;                // entries the output buffer holds (k_count: the part's reservation; k_big_emit: the fallback buffer)
     uint32_t do_adj;                 // resolve adjacencies inside the table where possible (min_freq > 1)
     uint32_t keep_pre;               // keep the pre-adjacency context byte in the entry's pad field (tests)
 };
@@ -495,10 +495,17 @@ struct CountGlobals {                // device-resident counters
     unsigned long long big_cursor;   // entries written to the fallback buffer by k_big_emit
     unsigned int next_item;
     unsigned int n_overflow;         // items that overflowed their table
-    unsigned int solid_overflow;     // an output segment ran out of room
+    unsigned int solid_overflow;     // the output buffer ran out of room
     unsigned int pad;
     unsigned long long n_boundary;   // solid entries left with unresolved (cross-item) context bits
+    unsigned long long part_cursor;  // entries of the part's reservation handed out to workgroups so far (whole chunks)
 };
+
+// Where a persistent workgroup is in the chunk of the output buffer it is filling (kept across the launches of
+// one pass).  Workgroups take chunks of OUT_CHUNK entries from CountGlobals::part_cursor and fill them item by
+// item, an item's entries running over into a fresh chunk when needed; only the last chunk of every workgroup
+// is left partly empty, and the host moves entries from the tail into those holes.
+struct WgOut { unsigned long long chunk; unsigned int used; unsigned int pad; };
 
 constexpr int COUNT_HIST_BINS = 256;             // spectrum bins kept in LDS; higher counts go straight to the global bins
 constexpr uint32_t COUNT_MAX_PROBE = 96;
@@ -770,6 +777,11 @@ __device__ __forceinline__ u128 canon_value(u128 F)
     return lt128(R, F) ? R : F;
 }
 
+// ctl words (LDS)
+enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_USED = 4, CTL_DISTINCT = 5, CTL_NTASK = 6, CTL_BOUNDARY = 7,
+       CTL_RB_LO = 8, CTL_RB_HI = 9, CTL_RE_LO = 10, CTL_RE_HI = 11, CTL_NSOLID = 12,
+       CTL_OUT_LO = 13, CTL_OUT_HI = 14, CTL_NEXT_LO = 15, CTL_NEXT_HI = 16, CTL_N = 24 };
+
 // Finish a counted LDS table: decide solidity, clean up adjacencies, emit.  (The HBM-table fallback does
 // the same three steps as separate grid-wide launches: k_big_flags / k_big_resolve / k_big_emit.)
 //
@@ -786,7 +798,7 @@ __device__ __forceinline__ u128 canon_value(u128 F)
 template <int K, bool USE_BC, uint32_t ADJ_TASKS>
 __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
                                                  uint32_t S, const CountParams& cp, uint4* __restrict__ seg_out,
-                                                 uint32_t* cursor32, unsigned int* seg_overflow,
+                                                 uint32_t* ctl, unsigned long long* part_cursor, unsigned int* seg_overflow,
                                                  uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
                                                  uint32_t* tasks, uint32_t* n_tasks, uint32_t* n_boundary,
                                                  uint16_t* solid_list, uint32_t* n_solid, int tid, int nthreads)
@@ -833,6 +845,15 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         tst(&bcw[slot], solid ? FLAG_SOLID : 0u);
     }
     sync();
+    // ---- room for this item's solid k-mers: the rest of the workgroup's chunk, and a fresh one if that is not enough
+    constexpr uint32_t OUT_CHUNK = 4 * ADJ_TASKS;                      // = 2 S entries: more than a table can emit
+    if (tid == 0) {
+        const uint32_t ns = tld(n_solid), used = tld(&ctl[CTL_USED]);
+        if (used + ns > OUT_CHUNK) {
+            const unsigned long long nx = atomicAdd(part_cursor, (unsigned long long)OUT_CHUNK);
+            tst(&ctl[CTL_NEXT_LO], (uint32_t)nx); tst(&ctl[CTL_NEXT_HI], (uint32_t)(nx >> 32));
+        }
+    }
     // ---- pass 2
 #ifdef DFK_ABLATE_PASS2
     if (false) {
@@ -863,6 +884,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
             sync();
         }
     }
+    else sync();                                                      // (the chunk claimed above must be visible)
     // ---- pass 3
     uint32_t boundary = 0;
     auto emit = [&](uint32_t slot, uint32_t c, uint32_t flags, unsigned long long idx) {
@@ -886,17 +908,26 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         // cursor moves once; then the state words of the whole table are cleared with wide stores (key words
         // are rewritten on claim).  cnt, ctxs and bcw are contiguous.
         const uint32_t ns = __builtin_amdgcn_readfirstlane(tld(n_solid));
-        const uint32_t base = __builtin_amdgcn_readfirstlane(tld(cursor32));
+        const uint32_t used = __builtin_amdgcn_readfirstlane(tld(&ctl[CTL_USED]));
+        const unsigned long long cur = (unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OUT_LO])) |
+                                       ((unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OUT_HI])) << 32);
+        const unsigned long long nxt = (unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_NEXT_LO])) |
+                                       ((unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_NEXT_HI])) << 32);
 #ifdef DFK_ABLATE_EMIT
         for (uint32_t i = tid; i < 0 * ns; i += nthreads) {
 #else
         for (uint32_t i = tid; i < ns; i += nthreads) {
 #endif
             const uint32_t slot = solid_list[i];
-            emit(slot, tld(&cnt[slot]), tld(&bcw[slot]), (unsigned long long)base + i);
+            const uint32_t pos = used + i;
+            emit(slot, tld(&cnt[slot]), tld(&bcw[slot]), pos < OUT_CHUNK ? cur + pos : nxt + (pos - OUT_CHUNK));
         }
         __syncthreads();
-        if (tid == 0) { tst(cursor32, base + ns); tst(n_solid, 0u); }
+        if (tid == 0) {
+            if (used + ns > OUT_CHUNK) { tst(&ctl[CTL_OUT_LO], (uint32_t)nxt); tst(&ctl[CTL_OUT_HI], (uint32_t)(nxt >> 32)); tst(&ctl[CTL_USED], used + ns - OUT_CHUNK); }
+            else tst(&ctl[CTL_USED], used + ns);
+            tst(n_solid, 0u);
+        }
         uint4* z = reinterpret_cast<uint4*>(cnt);
         for (uint32_t i = tid; i < 3 * S / 4; i += nthreads) z[i] = uint4{0, 0, 0, 0};
     }
@@ -906,14 +937,11 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
     return n_occ;
 }
 
-// ctl words (LDS)
-enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_CURSOR = 4, CTL_DISTINCT = 5, CTL_NTASK = 6, CTL_BOUNDARY = 7,
-       CTL_RB_LO = 8, CTL_RB_HI = 9, CTL_RE_LO = 10, CTL_RE_HI = 11, CTL_NSOLID = 12, CTL_N = 16 };
 
 template <int K, int LOG2S, int NWAVES, bool USE_BC>
 __global__ void __launch_bounds__(NWAVES * 64)
 k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, const uint64_t* __restrict__ rec_base,
-        CountParams cp, CountGlobals* __restrict__ g, uint4* __restrict__ out, uint32_t* __restrict__ seg_count,
+        CountParams cp, CountGlobals* __restrict__ g, uint4* __restrict__ out, WgOut* __restrict__ wg_out,
         unsigned long long* __restrict__ hist_global, ItemRange* __restrict__ overflow_items)
 {
     constexpr uint32_t S = 1u << LOG2S;
@@ -931,7 +959,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     WaveStage<K>* stages = reinterpret_cast<WaveStage<K>*>(tasks + S / 2 + S / 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WaveStage<K>* st = stages + wave;
-    uint4* seg_out = out + 2ull * cp.seg_cap * blockIdx.x;
+    uint4* seg_out = out;                                              // the part's reservation, shared by all workgroups
 
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) hist[i] = 0;
     for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;             // count, context and barcode words; key words are written on claim
@@ -939,7 +967,9 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     // ticket and the record range of item i+1 in registers (a returning global atomic plus a dependent
     // load are ~4 us of latency that every wave would otherwise wait for behind a barrier).
     if (tid == 0) {
-        ctl[CTL_CURSOR] = seg_count[blockIdx.x]; ctl[CTL_DISTINCT] = 0; ctl[CTL_BOUNDARY] = 0;
+        const WgOut w = wg_out[blockIdx.x];
+        ctl[CTL_OUT_LO] = (uint32_t)w.chunk; ctl[CTL_OUT_HI] = (uint32_t)(w.chunk >> 32); ctl[CTL_USED] = w.used;
+        ctl[CTL_NEXT_LO] = 0; ctl[CTL_NEXT_HI] = 0; ctl[CTL_DISTINCT] = 0; ctl[CTL_BOUNDARY] = 0;
         ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0; ctl[CTL_NSOLID] = 0;
         const uint32_t it0 = atomicAdd(&g->next_item, 1u);
         uint64_t b0 = 0, e0 = 0;
@@ -984,7 +1014,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
 #else
             uint32_t occ =
 #endif
-            table_finish<K, USE_BC, S / 2>(keys, cnt, ctxs, bcw, S, cp, seg_out, &ctl[CTL_CURSOR],
+            table_finish<K, USE_BC, S / 2>(keys, cnt, ctxs, bcw, S, cp, seg_out, ctl, &g->part_cursor,
                                                          &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
                                                          &ctl[CTL_BOUNDARY], solid_list, &ctl[CTL_NSOLID], tid, NT);
 #pragma unroll
@@ -1000,8 +1030,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     __syncthreads();
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) if (hist[i]) atomicAdd(&hist_global[i], (unsigned long long)hist[i]);
     if (tid == 0) {
-        uint32_t cur = ctl[CTL_CURSOR];
-        seg_count[blockIdx.x] = cur > cp.seg_cap ? (uint32_t)cp.seg_cap : cur;
+        wg_out[blockIdx.x] = WgOut{(unsigned long long)ctl[CTL_OUT_LO] | ((unsigned long long)ctl[CTL_OUT_HI] << 32), ctl[CTL_USED], 0u};
         if (ctl[CTL_DISTINCT]) atomicAdd(&g->n_distinct, (unsigned long long)ctl[CTL_DISTINCT]);
         if (ctl[CTL_BOUNDARY]) atomicAdd(&g->n_boundary, (unsigned long long)ctl[CTL_BOUNDARY]);
     }
@@ -1174,16 +1203,15 @@ k_big_emit(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_
     if (lane == 0 && boundary) atomicAdd(&g->n_boundary, (unsigned long long)boundary);
 }
 
-// Gather the output segments into one dense array: block b copies a slice of segment blockIdx.y.
+// After a pass: entries at the tail of the handed-out region move into the holes the workgroups left at the end
+// of their last chunks (src and dst are entry indices, built by the host from the WgOut records).
 __global__ void __launch_bounds__(256)
-k_compact(const uint4* __restrict__ seg, uint64_t seg_cap, const uint64_t* __restrict__ seg_prefix, uint4* __restrict__ dense)
+k_fill_holes(uint4* __restrict__ out, const uint64_t* __restrict__ src, const uint64_t* __restrict__ dst, uint64_t n)
 {
-    const uint32_t s = blockIdx.y;
-    const uint64_t n = seg_prefix[s + 1] - seg_prefix[s];
-    const uint4* src = seg + 2ull * seg_cap * s;
-    uint4* dst = dense + 2ull * seg_prefix[s];
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += (uint64_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[2 * dst[i]] = out[2 * src[i]];
+    out[2 * dst[i] + 1] = out[2 * src[i] + 1];
 }
 
 // ============================================================================ a6: adjacency clean-up

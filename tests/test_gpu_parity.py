@@ -201,14 +201,20 @@ def test_repeat_family_hot_minimizers(oracle):
 
 def test_small_hbm_budget_plans_its_own_passes(oracle):
     """With little HBM the library cuts the bucket space into ranges by itself (two passes in flight, each in its
-    own block, dictionary parts reserved at the top): same answer, more than one pass."""
-    rs = util.make_set(71, 5_000_000, 800_000)
-    ref, d = util.run_both(oracle, rs, K=48, hbm_budget_bytes=1200 << 20)
-    st = util.check_parity(ref, d)
-    assert st["n_passes"] >= 3, st["n_passes"]
-    # and a budget that cannot hold even small passes beside the dictionary is an error, not a crawl
+    own block, dictionary parts reserved where the dictionary grows): same answer, more than one pass."""
     from superplus_amd.dfk import Dfk, DfkError
-    tiny = Dfk(K=48, hbm_budget_bytes=700 << 20)
+    rs = util.make_set(71, 5_000_000, 800_000)
+    ref, d = util.run_both(oracle, rs, K=48)
+    st = util.check_parity(ref, d)
+    assert st["n_passes"] == 1
+    budget = st["hbm_bytes_peak"] - int(0.35 * 32 * st["n_records"])    # the dictionary fits, the records do not all at once
+    del d
+    ref, d = util.run_both(oracle, rs, K=48, hbm_budget_bytes=budget)
+    st = util.check_parity(ref, d)
+    assert st["n_passes"] >= 2, st["n_passes"]
+    del d
+    # and a budget that cannot even hold the spectrum bins beside the reads' summaries is an error
+    tiny = Dfk(K=48, hbm_budget_bytes=300 << 20)
     with pytest.raises(DfkError) as e:
         tiny.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
     assert e.value.code == -4
