@@ -983,7 +983,12 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
         // more than one pass to go: leave room for the records of the next one, which is scattered while this
         // one is counted (passes of equal or decreasing size also keep the arena from fragmenting: each new
         // range fits the hole left by the pass before the running one)
-        if (c->plan_derate * fit < left && overlap) fit = room > fixed ? (room - fixed) / (2.0 * per_in + per_seg + per_out) : 0.0;
+        if (c->plan_derate * fit < left && overlap) {
+            fit = room > fixed ? (room - fixed) / (2.0 * per_in + per_seg + per_out) : 0.0;
+            // the very first scatter has nothing to hide under: keep it short (its fixed cost, reading every
+            // summary, is paid anyway; a sixteenth of the buckets adds about as much again)
+            if (lo == 0) fit = std::min(fit, (double)sub_nb / 16.0 / c->plan_derate);
+        }
     } else {
         const double now = room - fixed;                              // (the running pass's part is reserved already)
         const double later = room + (double)running->bytes_held - fixed;
