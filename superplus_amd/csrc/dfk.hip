@@ -721,7 +721,7 @@ uint64_t solid_cap(const dfk_ctx* c, const CountRun& R, uint64_t n_inst)
     uint64_t cap = n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
     // (buckets are hash-distributed: once a pass has been counted the solid/instance ratio holds to a fraction of a percent)
     if (R.inst_seen) cap = std::min<uint64_t>(cap, (uint64_t)(1.12 * (double)R.solid_seen / (double)R.inst_seen * (double)n_inst) + 65536);
-    else cap = std::min<uint64_t>(cap, n_inst / 16 + (1u << 20));   // first pass: a prior (30x data: n_inst/15); too small -> redone
+    else cap = std::min<uint64_t>(cap, n_inst / 10 + (1u << 20));   // first pass: a prior (30x data: n_inst/15, 58x: n_inst/28); too small -> redone
     return cap;
 }
 
@@ -970,7 +970,7 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
     const double room = c->budget > c->held ? (double)(c->budget - c->held) : 0.0;
     const double inst_per = (double)T.n_inst / sub_nb, rec_per = (double)T.n_records / sub_nb;
     // solid k-mers per instance: observed on the passes done so far, else the prior stage_count starts from
-    double ratio = R.inst_seen ? 1.12 * (double)R.solid_seen / (double)R.inst_seen : 1.0 / 16.0;
+    double ratio = R.inst_seen ? 1.12 * (double)R.solid_seen / (double)R.inst_seen : 1.0 / 10.0;
     ratio = std::min(ratio, 1.0 / std::max<uint32_t>(1, c->cfg.min_freq));
     const double per_in = 81.0 + 32.5 * rec_per;                                         // tables and records (as the pass block is sized)
     const double per_seg = 0.0;                                                                       // (no output segments any more: workgroups write into the part's reservation)
