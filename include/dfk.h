@@ -47,7 +47,7 @@ typedef struct dfk_config {
     uint32_t K;                 /* 40, 48 or 60 */
     uint32_t min_qual;          /* MIN_QUAL, default 7   (10X/DF.cc:129-132) */
     uint32_t min_freq;          /* MIN_FREQ, default 3 */
-    uint32_t min_bc;            /* MIN_BC,   default 2; 0..2 supported on the GPU path */
+    uint32_t min_bc;            /* MIN_BC,   default 2; 0..4 */
     int32_t  device;            /* HIP device ordinal */
     int64_t  ign_bc_below;      /* createDict ignBcBelow (= bc_start, DF.cc:344-349) */
     uint64_t hbm_budget_bytes;  /* 0 = 90 % of free HBM (mem_frac analogue, GRAPHMEM=0.9) */

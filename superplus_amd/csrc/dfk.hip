@@ -589,16 +589,16 @@ int count_run_end(dfk_ctx* c, CountRun* R)
     return 0;
 }
 
-template <int K> unsigned count_grid(const dfk_ctx* c)
+template <int K> unsigned count_grid(const dfk_ctx* c, int nbc = 1)      // persistent workgroups of k_count: as many as fit the LDS
 {
     constexpr int LOG2S = CountCfg<K>::LOG2S, NW = CountCfg<K>::NWAVES;
-    const size_t lds = count_lds_bytes<K, LOG2S, NW>();
+    const size_t lds = nbc <= 1 ? count_lds_bytes<K, LOG2S, NW, 1>() : nbc == 2 ? count_lds_bytes<K, LOG2S, NW, 2>() : count_lds_bytes<K, LOG2S, NW, 3>();
     const unsigned per_cu = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / lds);
     return (unsigned)c->prop.multiProcessorCount * per_cu;
 }
 
 // one k_count launch over `n_items` device-resident items; overflowed items come back as bucket ranges
-template <int K, bool USE_BC>
+template <int K, int NBC>
 int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint64_t n_items, const CountRun& R,
                  std::vector<ItemRange>* overflowed, float* kernel_ms)
 {
@@ -609,8 +609,8 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
     int rc = c->alloc(d_ovf, n_items * sizeof(ItemRange), "overflow list"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(&R.g->next_item, 0, 8, c->stream));      // next_item, n_overflow
     CountParams cp = R.cp; cp.n_items = (uint32_t)n_items;
-    const size_t lds = count_lds_bytes<K, LOG2S, NW>();
-    auto kern = k_count<K, LOG2S, NW, USE_BC>;
+    const size_t lds = count_lds_bytes<K, LOG2S, NW, NBC>();
+    auto kern = k_count<K, LOG2S, NW, NBC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     TRACE("k_count: %llu items, grid %u, lds %zu, seg_cap %llu", (unsigned long long)n_items, R.grid, lds, (unsigned long long)R.cp.seg_cap);
     Timer tk(c->stream);
@@ -632,7 +632,7 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
     return 0;
 }
 
-template <int K, bool USE_BC>
+template <int K, int NBC>
 int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& singles, CountRun& R)
 {
     constexpr int KW = KTraits<K>::KW, NW = 8;
@@ -672,7 +672,7 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
         tot_inst += inst;
         uint32_t l2 = std::max<uint32_t>(13, ceil_log2(2 * inst + 64));
         items.push_back(BigItem{singles[i].b0, singles[i].b1, words, l2, 0});
-        words += (uint64_t)(KW + 3) << l2;
+        words += (uint64_t)(KW + 3 + (NBC > 1 ? NBC - 1 : 0)) << l2;
         chunk_pre[i + 1] = chunk_pre[i] + (rec[2 * i + 1] - rec[2 * i] + COUNT_CHUNK - 1) / COUNT_CHUNK;
         slot_pre[i + 1] = slot_pre[i] + (1ull << l2);
     }
@@ -694,10 +694,10 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     const unsigned cus = (unsigned)c->prop.multiProcessorCount;
     const unsigned g_ins = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + NW * BIG_TICKET_CHUNKS - 1) / (NW * BIG_TICKET_CHUNKS), 4ull * cus));
     const unsigned g_slot = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((slot_pre[n] + 255) / 256, 16ull * cus));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_insert<K, NW, USE_BC>), dim3(g_ins), dim3(NW * 64), 0, c->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_insert<K, NW, NBC>), dim3(g_ins), dim3(NW * 64), 0, c->stream,
                        (const uint4*)P.records.p, (const BigItem*)d_items.p, (const uint64_t*)P.base.p, (const uint64_t*)d_chunk_pre, n,
                        (uint32_t*)pool.p, (unsigned long long*)d_fail.p + 1, (uint32_t*)d_fail.p);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_flags<K, USE_BC>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_flags<K, NBC>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
                        (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p, cpb, R.g);
     if (cpb.do_adj)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_resolve<K>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
@@ -715,6 +715,10 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
 
 // Count one pass: run k_count over its items (+ split / HBM-table fallbacks), gather the pass's solid
 // k-mers into a dense part.
+// barcodes a table slot remembers: max(1, MIN_BC - 1); 0 without barcodes
+int barcode_words(const dfk_ctx* c, bool have_bc)
+{ return !have_bc ? 0 : (int)std::max<uint32_t>(1, std::min<uint32_t>(c->cfg.min_bc, 4) - (c->cfg.min_bc > 1 ? 1 : 0)); }
+
 // solid k-mers a pass of n_inst instances is expected to emit at most (what its output segments are sized for)
 uint64_t solid_cap(const dfk_ctx* c, const CountRun& R, uint64_t n_inst)
 {
@@ -728,7 +732,7 @@ uint64_t solid_cap(const dfk_ctx* c, const CountRun& R, uint64_t n_inst)
 template <int K> constexpr uint64_t out_chunk() { return 2ull << CountCfg<K>::LOG2S; }   // = table_finish's OUT_CHUNK
 
 template <int K>
-int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R)
+int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R, int nbc)
 {
     const unsigned attempt = c->seg_attempt;
     // Output: the pass's part of the dictionary, reserved now (from the bottom of the arena's free room, where the
@@ -736,7 +740,7 @@ int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R)
     // room it needs.  The persistent workgroups fill it chunk by chunk (WgOut); count_run cuts it to size.
     // Every solid k-mer has >= min_freq instances, which bounds the total; after the first pass the observed
     // solid/instance ratio holds to a fraction of a percent (buckets are hash-distributed).
-    R.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(P.n_items, count_grid<K>(c)));
+    R.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(P.n_items, count_grid<K>(c, nbc)));
     uint64_t res = solid_cap(c, R, P.n_inst);
     if (R.inst_seen) res = std::min<uint64_t>(res, (uint64_t)(1.08 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
     res = (res << attempt) + (uint64_t)R.grid * out_chunk<K>();       // + the chunk ends the workgroups leave empty
@@ -755,14 +759,14 @@ int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R)
     return 0;
 }
 
-template <int K, bool USE_BC>
+template <int K, int NBC>
 int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
 {
     int rc = 0;
     Timer t(c->stream);
     std::vector<ItemRange> overflowed;
     c->st.n_items += P.n_items;
-    rc = launch_count<K, USE_BC>(c, P, (const ItemRange*)P.items.p, P.n_items, R, &overflowed, &c->st.ms_count); if (rc) return rc;
+    rc = launch_count<K, NBC>(c, P, (const ItemRange*)P.items.p, P.n_items, R, &overflowed, &c->st.ms_count); if (rc) return rc;
     t.start();
     // items that overflowed their LDS table are halved by bucket index and retried; a single fine bucket
     // that still overflows is counted in an HBM table
@@ -781,12 +785,12 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
         DevBuf d_next; rc = c->alloc(d_next, next.size() * sizeof(ItemRange), "split items"); if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(d_next.p, next.data(), next.size() * sizeof(ItemRange), hipMemcpyHostToDevice, c->stream));
         float ignored = 0;
-        rc = launch_count<K, USE_BC>(c, P, (const ItemRange*)d_next.p, next.size(), R, &overflowed, &ignored);
+        rc = launch_count<K, NBC>(c, P, (const ItemRange*)d_next.p, next.size(), R, &overflowed, &ignored);
         c->release(d_next);
         if (rc) return rc;
     }
     TRACE("fallback: %zu single-bucket items", singles.size());
-    if (!singles.empty()) { rc = launch_count_big<K, USE_BC>(c, P, singles, R); if (rc) return rc; }
+    if (!singles.empty()) { rc = launch_count_big<K, NBC>(c, P, singles, R); if (rc) return rc; }
     c->st.ms_fallback += t.stop();
 
     CountGlobals hg{};
@@ -845,11 +849,17 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     return 0;
 }
 
-template <int K, bool USE_BC>
-int stage_count(dfk_ctx* c, const Partition& P, CountRun& R)
+
+template <int K>
+int stage_count(dfk_ctx* c, const Partition& P, CountRun& R, bool have_bc)
 {
-    int rc = count_prepare<K>(c, P, R); if (rc) return rc;
-    return count_run<K, USE_BC>(c, P, R);
+    int rc = count_prepare<K>(c, P, R, barcode_words(c, have_bc)); if (rc) return rc;
+    switch (barcode_words(c, have_bc)) {
+    case 0: return count_run<K, 0>(c, P, R);
+    case 1: return count_run<K, 1>(c, P, R);
+    case 2: return count_run<K, 2>(c, P, R);
+    default: return count_run<K, 3>(c, P, R);
+    }
 }
 
 // ------------------------------------------------------------------ stage: adjacency (a6)
@@ -1090,7 +1100,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         const dfk_stats st0 = c->st;
         rc = count_snapshot(c, &R, false); if (rc) return rc;
         c->sub = &cur.blk;
-        rc = count_prepare<K>(c, cur.sj.P, R);
+        rc = count_prepare<K>(c, cur.sj.P, R, barcode_words(c, in.bc != nullptr));
         c->sub = nullptr;
         nxt.valid = false;
         if (!rc && overlap && nlo < sub_nb) {
@@ -1103,7 +1113,14 @@ int run_typed(dfk_ctx* c, const Inputs& in)
                 if (r2 && r2 != DFK_E_NOMEM) return r2;                // NOMEM: this range is scattered after the count instead
             }
         }
-        if (!rc) rc = in.bc ? count_run<K, true>(c, cur.sj.P, R) : count_run<K, false>(c, cur.sj.P, R);
+        if (!rc) {
+            switch (barcode_words(c, in.bc != nullptr)) {               // barcodes a table slot remembers: max(1, MIN_BC - 1)
+            case 0: rc = count_run<K, 0>(c, cur.sj.P, R); break;
+            case 1: rc = count_run<K, 1>(c, cur.sj.P, R); break;
+            case 2: rc = count_run<K, 2>(c, cur.sj.P, R); break;
+            default: rc = count_run<K, 3>(c, cur.sj.P, R); break;
+            }
+        }
         if (rc == DFK_E_NOMEM || rc == E_SEGMENT_FULL) {
             HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipStreamSynchronize(c->stream2));
             c->release_since(cur.mark);                               // this pass and the one started under it
@@ -1212,7 +1229,7 @@ int dfk_create(const dfk_config* cfg, dfk_ctx** out)
     *out = nullptr;
     if (cfg->abi_version != DFK_ABI_VERSION) return fail(DFK_E_ARG, "dfk_config.abi_version %u != %d", cfg->abi_version, DFK_ABI_VERSION);
     if (cfg->K != 40 && cfg->K != 48 && cfg->K != 60) return fail(DFK_E_ARG, "K=%u: the reference instantiates 40, 48 and 60 only", cfg->K);
-    if (cfg->min_bc > 2) return fail(DFK_E_ARG, "MIN_BC=%u: the GPU path tracks at most 2 distinct barcodes per k-mer", cfg->min_bc);
+    if (cfg->min_bc > 4) return fail(DFK_E_ARG, "MIN_BC=%u: a table slot remembers at most 3 distinct barcodes (MIN_BC <= 4)", cfg->min_bc);
     if (cfg->min_freq == 0 || cfg->min_freq > 0xFFFFFFu) return fail(DFK_E_ARG, "MIN_FREQ out of range");
     uint32_t M = cfg->minimizer_len ? cfg->minimizer_len : 16;
     if (M < 8 || M > 16 || M >= cfg->K) return fail(DFK_E_ARG, "minimizer_len must be in 8..16");

@@ -571,7 +571,7 @@ enum : uint32_t { PS_PROBING = 0, PS_FOUND = 1, PS_FAILED = 2, PS_IDLE = 3 };
 // one counter bounds both the probe sequence (COUNT_MAX_PROBE steps) and the waits on a locked slot
 constexpr uint32_t PROBE_COST = 1u << 12, PROBE_LIMIT = (COUNT_MAX_PROBE + 1) * PROBE_COST;
 
-template <int KW, bool USE_BC, bool LDS_TABLE>
+template <int KW, int NBC, bool LDS_TABLE>
 __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
                                              uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw,
                                              uint32_t S, const Probe& A, uint32_t& n_claimed)
@@ -638,12 +638,21 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
                                                          __HIP_MEMORY_SCOPE_AGENT)) {}
         }
         atomicOr(&ctxs[slot], A.ctx);
-        if (USE_BC) {
-            // first barcode > 0 | BCW_MULTI once a second distinct one (or an ignored read, tag -1) arrives
+        if (NBC > 0) {
+            // areEnoughBarcodes (BuildReadQGraph48.cc:112-132): the slot remembers up to NBC = max(1, MIN_BC-1)
+            // distinct positive barcodes (word j of the slot: bcw[j*S + slot], 0 = free); BCW_MULTI in word 0 says
+            // "passes": one barcode more than it can remember has arrived, or an ignored read (tag -1).  A barcode
+            // tries the words in order and stops at itself or at the first free word, so it is never held twice.
             if (A.tag == -1) atomicOr(&bcw[slot], BCW_MULTI);
             else if (A.tag > 0) {
-                const uint32_t old = atomicCAS(&bcw[slot], 0u, (uint32_t)A.tag);
-                if (old != 0u && old != (uint32_t)A.tag && !(old & BCW_MULTI)) atomicOr(&bcw[slot], BCW_MULTI);
+                bool settled = false;
+#pragma unroll
+                for (int j = 0; j < NBC; ++j)
+                    if (!settled) {
+                        const uint32_t old = atomicCAS(&bcw[(size_t)j * S + slot], 0u, (uint32_t)A.tag);
+                        settled = old == 0u || (old & ~BCW_MULTI) == (uint32_t)A.tag || (j == 0 && (old & BCW_MULTI));
+                    }
+                if (!settled) atomicOr(&bcw[slot], BCW_MULTI);
             }
         }
     }
@@ -694,7 +703,7 @@ __device__ __forceinline__ Probe make_probe(const InstRegs& in, uint32_t S, bool
 
 // Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
 // block barriers).  Lanes load half a record each (1 KiB per wave, coalesced).
-template <int K, bool USE_BC, bool LDS_TABLE>
+template <int K, int NBC, bool LDS_TABLE>
 __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
                                                  WaveStage<K>* __restrict__ st, int lane,
                                                  uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
@@ -726,7 +735,7 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
 #ifdef DFK_ABLATE_INSERT        // timing experiment only: keep the extraction alive, skip the table
         if ((A.k0 ^ A.k1 ^ A.ctx) == 0x12345u) ++n_claimed;
 #else
-        ok = table_insert<KTraits<K>::KW, USE_BC, LDS_TABLE>(keys, cnt, ctxs, bcw, S, A, n_claimed) && ok;
+        ok = table_insert<KTraits<K>::KW, NBC, LDS_TABLE>(keys, cnt, ctxs, bcw, S, A, n_claimed) && ok;
 #endif
     }
 #pragma unroll
@@ -741,7 +750,7 @@ __device__ __forceinline__ bool bc_pass(uint32_t v, uint32_t min_bc)
 {
     if (!USE_BC || min_bc == 0) return true;
     if (min_bc == 1) return v != 0;
-    return (v & BCW_MULTI) != 0;                                     // >= 2 distinct barcodes > 0, or an ignored (-1) one
+    return (v & BCW_MULTI) != 0;                                     // >= MIN_BC distinct barcodes > 0, or an ignored (-1) one
 }
 
 // Look a canonical k-mer up in a finished table (no concurrent inserts).  Returns its slot or ~0.
@@ -795,7 +804,7 @@ enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_USED = 4, CTL
 //           unresolved for the small HBM pass afterwards (k_adjacency) -- about one bit in ten
 //   pass 3  emit solid slots into the workgroup's output segment (LDS cursor) and the spectrum
 // `sync` is __syncthreads for the whole workgroup.
-template <int K, bool USE_BC, uint32_t ADJ_TASKS>
+template <int K, int NBC, uint32_t ADJ_TASKS>
 __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
                                                  uint32_t S, const CountParams& cp, uint4* __restrict__ seg_out,
                                                  uint32_t* ctl, unsigned long long* part_cursor, unsigned int* seg_overflow,
@@ -832,7 +841,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         if (!c) continue;
         ++n_occ;
         const uint32_t count = c & CNT_MASK;                           // saturated at 2^24-1 by the insert (ReadPather.h:128-129)
-        const bool solid = count >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&bcw[slot]) : 0u, cp.min_bc);
+        const bool solid = count >= cp.min_freq && bc_pass<(NBC > 0)>(NBC > 0 ? tld(&bcw[slot]) : 0u, cp.min_bc);
         if (solid) solid_list[atomicAdd(n_solid, 1u)] = (uint16_t)slot;
         if (solid && cp.do_adj) {
             const uint32_t ctx = tld(&ctxs[slot]) & 0xFFu;
@@ -929,7 +938,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
             tst(n_solid, 0u);
         }
         uint4* z = reinterpret_cast<uint4*>(cnt);
-        for (uint32_t i = tid; i < 3 * S / 4; i += nthreads) z[i] = uint4{0, 0, 0, 0};
+        for (uint32_t i = tid; i < (3 + (NBC > 1 ? NBC - 1 : 0)) * S / 4; i += nthreads) z[i] = uint4{0, 0, 0, 0};
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) boundary += __shfl_down(boundary, d, 64);
@@ -938,7 +947,7 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
 }
 
 
-template <int K, int LOG2S, int NWAVES, bool USE_BC>
+template <int K, int LOG2S, int NWAVES, int NBC>
 __global__ void __launch_bounds__(NWAVES * 64)
 k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, const uint64_t* __restrict__ rec_base,
         CountParams cp, CountGlobals* __restrict__ g, uint4* __restrict__ out, WgOut* __restrict__ wg_out,
@@ -951,8 +960,9 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     uint32_t* keys = smem;                          // [KW][S]
     uint32_t* cnt = keys + KW * S;                  // [S]
     uint32_t* ctxs = cnt + S;                       // [S]
-    uint32_t* bcw = ctxs + S;                       // [S]
-    uint32_t* hist = bcw + S;                       // [COUNT_HIST_BINS]
+    uint32_t* bcw = ctxs + S;                       // [max(1, NBC)][S]
+    constexpr uint32_t XW = NBC > 1 ? NBC - 1 : 0;  // barcode words beyond the first
+    uint32_t* hist = bcw + (1 + XW) * S;            // [COUNT_HIST_BINS]
     uint32_t* ctl = hist + COUNT_HIST_BINS;         // [CTL_N]
     uint32_t* tasks = ctl + CTL_N;                  // [S] neighbour look-up queue
     uint16_t* solid_list = reinterpret_cast<uint16_t*>(tasks + S / 2); // [S] solid slots of the item being finished  (tasks: [S/2])
@@ -962,7 +972,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     uint4* seg_out = out;                                              // the part's reservation, shared by all workgroups
 
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) hist[i] = 0;
-    for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;             // count, context and barcode words; key words are written on claim
+    for (uint32_t i = tid; i < (3 + XW) * S; i += NT) cnt[i] = 0;      // count, context and barcode words; key words are written on claim
     // The item loop is software-pipelined: while the workgroup counts item i, thread 0 already holds the
     // ticket and the record range of item i+1 in registers (a returning global atomic plus a dependent
     // load are ~4 us of latency that every wave would otherwise wait for behind a barrier).
@@ -997,24 +1007,24 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
             ci = __builtin_amdgcn_readfirstlane(ci);
             if (ci >= n_chunks) break;
             if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
-            wave_count_chunk<K, USE_BC, true>(records, rb + (uint64_t)ci * COUNT_CHUNK, re, st, lane, keys, cnt, ctxs, bcw, S,
+            wave_count_chunk<K, NBC, true>(records, rb + (uint64_t)ci * COUNT_CHUNK, re, st, lane, keys, cnt, ctxs, bcw, S,
                                         &ctl[CTL_FILL], &ctl[CTL_OVF]);
             if (lane == 0 && tld(&ctl[CTL_FILL]) > (S / 4) * 3) tst(&ctl[CTL_OVF], 1u);   // stop when 3/4 full
         }
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(ctl[CTL_OVF])) {
             if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = items[item];
-            for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;     // abandon the table
+            for (uint32_t i = tid; i < (3 + XW) * S; i += NT) cnt[i] = 0;   // abandon the table
             __syncthreads();                                           // everyone has read CTL_OVF before it is reset
         } else {
 #ifdef DFK_ABLATE_FINISH        // timing experiment only: no solidity/adjacency/emit passes
-            for (uint32_t i = tid; i < 3 * S; i += NT) cnt[i] = 0;
+            for (uint32_t i = tid; i < (3 + XW) * S; i += NT) cnt[i] = 0;
             uint32_t occ = 0;
             if (false)
 #else
             uint32_t occ =
 #endif
-            table_finish<K, USE_BC, S / 2>(keys, cnt, ctxs, bcw, S, cp, seg_out, ctl, &g->part_cursor,
+            table_finish<K, NBC, S / 2>(keys, cnt, ctxs, bcw, S, cp, seg_out, ctl, &g->part_cursor,
                                                          &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
                                                          &ctl[CTL_BOUNDARY], solid_list, &ctl[CTL_NSOLID], tid, NT);
 #pragma unroll
@@ -1036,10 +1046,10 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     }
 }
 
-template <int K, int LOG2S, int NWAVES>
+template <int K, int LOG2S, int NWAVES, int NBC>
 constexpr size_t count_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + (1u << LOG2S) / 2 + (1u << LOG2S) / 2) + sizeof(WaveStage<K>) * NWAVES;
+    return sizeof(uint32_t) * ((size_t)(KTraits<K>::KW + 3 + (NBC > 1 ? NBC - 1 : 0)) * (1u << LOG2S) + COUNT_HIST_BINS + CTL_N + (1u << LOG2S) / 2 + (1u << LOG2S) / 2) + sizeof(WaveStage<K>) * NWAVES;
 }
 
 // Fallback for a fine bucket that cannot fit an LDS table: its table lives in HBM (tab = [KW+3][S] words,
@@ -1062,7 +1072,7 @@ __device__ __forceinline__ uint32_t big_find(const uint64_t* __restrict__ pre, u
     return lo;
 }
 
-template <int K, int NWAVES, bool USE_BC>
+template <int K, int NWAVES, int NBC>
 __global__ void __launch_bounds__(NWAVES * 64)
 k_big_insert(const uint4* __restrict__ records, const BigItem* __restrict__ items, const uint64_t* __restrict__ rec_base,
              const uint64_t* __restrict__ chunk_pre, uint32_t n_items, uint32_t* __restrict__ tab_pool,
@@ -1089,7 +1099,7 @@ k_big_insert(const uint4* __restrict__ records, const BigItem* __restrict__ item
             uint32_t* keys = tab_pool + I.tab_off;
             uint32_t* cnt = keys + (size_t)KW * S;
             const uint64_t rb = rec_base[I.b0] + (t - chunk_pre[it]) * COUNT_CHUNK;
-            wave_count_chunk<K, USE_BC, false>(records, rb, rec_base[I.b1], &stages[wave], lane, keys, cnt, cnt + S, cnt + 2 * (size_t)S, S, &fill, &ovf);
+            wave_count_chunk<K, NBC, false>(records, rb, rec_base[I.b1], &stages[wave], lane, keys, cnt, cnt + S, cnt + 2 * (size_t)S, S, &fill, &ovf);
         }
     }
     __syncthreads();
@@ -1109,7 +1119,7 @@ __device__ __forceinline__ BigView<K> big_view(const BigItem* __restrict__ items
     return BigView<K>{keys, cnt, cnt + S, cnt + 2 * (size_t)S, S, (uint32_t)(x - slot_pre[it])};
 }
 
-template <int K, bool USE_BC>
+template <int K, int NBC>
 __global__ void __launch_bounds__(256)
 k_big_flags(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_pre, uint32_t n_items, uint32_t* __restrict__ tab_pool,
             CountParams cp, CountGlobals* __restrict__ g)
@@ -1121,7 +1131,7 @@ k_big_flags(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot
         const uint32_t c = tld(&v.cnt[v.slot]);
         if (!c) continue;
         ++occ;
-        const bool solid = (c & CNT_MASK) >= cp.min_freq && bc_pass<USE_BC>(USE_BC ? tld(&v.bcw[v.slot]) : 0u, cp.min_bc);
+        const bool solid = (c & CNT_MASK) >= cp.min_freq && bc_pass<(NBC > 0)>(NBC > 0 ? tld(&v.bcw[v.slot]) : 0u, cp.min_bc);
         if (solid && cp.do_adj && cp.keep_pre) { const uint32_t ctx = tld(&v.ctxs[v.slot]) & 0xFFu; tst(&v.ctxs[v.slot], ctx | (ctx << 8)); }
         tst(&v.bcw[v.slot], solid ? FLAG_SOLID : 0u);
     }

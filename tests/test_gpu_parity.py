@@ -46,13 +46,28 @@ def test_golden_fixtures_through_abi(oracle, golden_dir):
 
 
 @pytest.mark.parametrize("min_freq,min_bc,use_bc,ign", [(1, 2, True, 0), (2, 0, True, 0), (3, 1, True, 0), (3, 2, False, 0),
-                                                       (3, 2, True, 2000), (5, 2, True, 10**9)])
+                                                       (3, 2, True, 2000), (5, 2, True, 10**9),
+                                                       (3, 3, True, 0), (3, 4, True, 0), (2, 3, True, 2000)])
 def test_filter_variants(oracle, min_freq, min_bc, use_bc, ign):
     """MIN_FREQ / MIN_BC / no-barcode / ignBcBelow variants (areIgnoredBarcodes, areEnoughBarcodes;
     min_freq == 1 skips recomputeAdjacencies, BuildReadQGraph48.cc:313)."""
     rs = util.make_set(21, 50000, 5000)
     ref, d = util.run_both(oracle, rs, K=48, min_freq=min_freq, min_bc=min_bc, use_bc=use_bc, ign_bc_below=ign)
     util.check_parity(ref, d)
+
+
+@pytest.mark.parametrize("K,min_bc", [(40, 3), (60, 4)])
+def test_min_bc_above_two_other_k(oracle, K, min_bc):
+    """MIN_BC 3 and 4 (a table slot remembers MIN_BC-1 barcodes) with 3 and 4 key words per slot; also through the
+    HBM-table fallback (tiny items force overflow)."""
+    rs = util.make_set(23, 60000, 6000)
+    ref, d = util.run_both(oracle, rs, K=K, min_bc=min_bc)
+    util.check_parity(ref, d)
+    n_solid = ref["n_solid"]
+    assert 0 < n_solid < util.run_both(oracle, rs, K=K, min_bc=2)[0]["n_solid"]      # the filter bites
+    ref, d = util.run_both(oracle, rs, K=K, min_bc=min_bc, inst_per_item=100000)
+    st = util.check_parity(ref, d)
+    assert st["n_overflow_items"] > 0
 
 
 def _custom(reads, quals, bc=None):
