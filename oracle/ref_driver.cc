@@ -321,6 +321,27 @@ int side( std::string const& head, std::string const& outdir )
     BinaryWriter::writeFile((outdir+"/frag_reads_orig.dti").c_str(),ds);
     BinaryWriter::writeFile((outdir+"/subsam.names").c_str(),names);
     BinaryWriter::writeFile((outdir+"/subsam.starts").c_str(),starts);
+
+    // frag_reads_orig.1000.{fastb,qualp}: the reference's own random stream (random/RNGen.cc through randomx())
+    // and its own feudal writers; the glue restates 10X/DfTools.cc: LoadData draws one number per pair even at
+    // LR_SELECT_FRAC = 1 (:115-117,131,147), then WriteSubSample (:32-67) keeps a pair when its draw says so or
+    // when only as many pairs are left as are still wanted.
+    for ( size_t i = 0; i + 1 < reads.size(); i += 2 ) (void)randomx();
+    {
+        size_t pair_count = std::min<size_t>( reads.size()/2, 500 );
+        double frac = static_cast<double>(pair_count)/(reads.size()/2);
+        vecbvec sbases; VecPQVec squals;
+        sbases.reserve(pair_count*2); squals.reserve(pair_count*2);
+        for ( size_t i = 0; i+1 < reads.size() && pair_count; i += 2 )
+        {
+            bool take = (1. * randomx() / RNGen::RNGEN_RAND_MAX) <= frac;
+            if ( take || pair_count*2 >= reads.size()-i )
+            { sbases.push_back(reads[i]); sbases.push_back(reads[i+1]);
+              squals.push_back(quals[i]); squals.push_back(quals[i+1]); pair_count--; }
+        }
+        sbases.WriteAll((outdir+"/frag_reads_orig.1000.fastb").c_str());
+        squals.WriteAll((outdir+"/frag_reads_orig.1000.qualp").c_str());
+    }
     return 0;
 }
 

@@ -9,9 +9,10 @@
 //          work_dir/stats/histogram_kmer_count.json          WriteKmerSpectrum (BuildReadQGraph48.cc:283-285)
 //          work_dir/kmers.kvec                               the dictionary  (BuildReadQGraph48.cc:287-288)
 //
-// The hot path itself runs in libdfk (HIP); this file is host plumbing only.  Not reproduced: the
-// 500-pair random sample frag_reads_orig.1000.* (write-only in the reference, needs its RNG) and
-// everything after createDict (graph build, pathing, the other seven stages), which are out of scope.
+//          work_dir/data/frag_reads_orig.1000.{fastb,qualp}  WriteSubSample  (10X/DfTools.cc:32-67)
+//
+// The hot path itself runs in libdfk (HIP); this file is host plumbing only.  Not reproduced: everything
+// after createDict (graph build, pathing, the other seven stages), which are out of scope.
 #include "../../include/dfk.h"
 #include "feudal_io.h"
 
@@ -51,6 +52,22 @@ std::vector<std::string> parse_set(std::string s)
     while (std::getline(ss, tok, ',')) if (!tok.empty()) out.push_back(tok);
     return out;
 }
+
+// The reference's global random stream (random/RNGen.h:28-84, RNGen.cc:17-18): additive lagged Fibonacci over 31
+// words seeded from 1 by x -> x*1103515245 + 12345, front at word 3, rear at word 0, 310 draws discarded; a draw is
+// the new front word >> 1.  (The reference keeps the words in unsigned long; only their low 32 bits ever matter.)
+struct RefRandom {
+    uint32_t st[31]; int f = 3, r = 0;
+    RefRandom()
+    { uint32_t last = 1; st[0] = last; for (int i = 1; i < 31; ++i) st[i] = last = last * 1103515245u + 12345u; for (int n = 0; n < 310; ++n) next(); }
+    long next()
+    {
+        const uint32_t result = (st[f] += st[r]);
+        if (++f >= 31) { f = 0; ++r; }
+        else if (++r >= 31) r = 0;
+        return (long)(result >> 1);
+    }
+};
 
 struct DataSet { uint8_t dt; uint8_t pad[7]; int64_t start; };   // 10X/DfTools.h:23-45; dt 2 = UNBAR_10X, 3 = BAR_10X
 static_assert(sizeof(DataSet) == 16, "DataSet is 16 bytes");
@@ -134,6 +151,29 @@ int main(int argc, char** argv)
         feudal::write_fastb(rh + ".fastb", R.packed.data(), R.base_off, R.read_len);
         feudal::write_qualp(rh + ".qualp", R.pq.data(), R.pq_off);
         { feudal::BinWriter w(rh + ".bci"); w.vec(bci); }
+        {
+            // WriteSubSample(bases, quals, 500, ".../frag_reads_orig.1000") (DfTools.cc:32-67,169).  The stream has
+            // already given LoadData one number per pair: its decider draws even at LR_SELECT_FRAC = 1
+            // (:115-117,131,147).  A pair is kept when its draw says so, or when only as many are left as are wanted.
+            RefRandom rng;
+            const size_t n = R.size();
+            for (size_t i = 0; i + 1 < n; i += 2) (void)rng.next();
+            size_t want = std::min<size_t>(n / 2, 500);
+            const double frac = n / 2 ? (double)want / (double)(n / 2) : 0.0;
+            std::vector<uint8_t> sp, sq; std::vector<uint64_t> so{0}, sqo{0}; std::vector<uint32_t> sl;
+            for (size_t i = 0; i + 1 < n && want; i += 2) {
+                const bool take = (1. * rng.next() / 2147483647.0) <= frac;
+                if (!(take || want * 2 >= n - i)) continue;
+                for (size_t k = i; k < i + 2; ++k) {
+                    sp.insert(sp.end(), R.packed.begin() + R.base_off[k], R.packed.begin() + R.base_off[k + 1]); so.push_back(sp.size());
+                    sq.insert(sq.end(), R.pq.begin() + R.pq_off[k], R.pq.begin() + R.pq_off[k + 1]); sqo.push_back(sq.size());
+                    sl.push_back(R.read_len[k]);
+                }
+                --want;
+            }
+            feudal::write_fastb(rh + ".1000.fastb", sp.data(), so, sl);
+            feudal::write_qualp(rh + ".1000.qualp", sq.data(), sqo);
+        }
         printf("%s: loaded %zu reads\n", date().c_str(), R.size());
         for (const DataSet& d : datasets) printf("\t%s starts at %ld\n", d.dt == 2 ? "UNBAR_10X" : "BAR_10X", (long)d.start);
 

@@ -23,7 +23,8 @@ def test_ingest_matches_reference_side_files(tmp_path, golden_dir):
     rd = lambda p: open(p, "rb").read()
     for ext in ("fastb", "qualp", "bci"):          # one LR input already in LoadData order: copied verbatim
         assert rd(f"{tmp_path}/w/data/frag_reads_orig.{ext}") == rd(f"{golden_dir}/reads.{ext}"), ext
-    for name in ("frag_reads_orig.lens", "frag_reads_orig.qhist"):
+    # .1000.*: the 500-pair sample LoadData writes with the reference's own random stream (reproduced in df_main.cc)
+    for name in ("frag_reads_orig.lens", "frag_reads_orig.qhist", "frag_reads_orig.1000.fastb", "frag_reads_orig.1000.qualp"):
         assert rd(f"{tmp_path}/w/data/{name}") == rd(f"{golden_dir}/side/{name}"), name
     # .dti: 16-byte records {u8 dt, 7 pad bytes (undefined in the reference), i64 start} -- compare fields
     dt = np.dtype([("dt", "u1"), ("pad", "V7"), ("start", "<i8")])
