@@ -299,11 +299,26 @@ int rdreads( std::string const& head, char const* out )
 struct SideDataSet { uint8_t dt; int64_t start; };                 // same layout as DataSet (10X/DfTools.h:30-45)
 TRIVIALLY_SERIALIZABLE(SideDataSet);
 
-int side( std::string const& head, std::string const& outdir )
+int side( std::string const& head, std::string const& outdir, double frac0 = 1.0 )
 {
-    vecbvec reads; reads.ReadAll((head+".fastb").c_str());
-    VecPQVec quals; quals.ReadAll((head+".qualp").c_str());
-    vec<int64_t> bci; BinaryReader::readFile((head+".bci").c_str(),&bci);
+    vecbvec reads0; reads0.ReadAll((head+".fastb").c_str());
+    VecPQVec quals0; quals0.ReadAll((head+".qualp").c_str());
+    vec<int64_t> bci0; BinaryReader::readFile((head+".bci").c_str(),&bci0);
+    // LoadData (10X/DfTools.cc:99-162) for one LR input, with the reference's containers and random stream:
+    // every pair draws a number, unbarcoded pairs first, then barcode by barcode, and stays if the draw <= frac
+    vecbvec reads; VecPQVec quals; vec<int64_t> bci; bci.push_back(0);
+    reads.reserve(reads0.size()); quals.reserve(quals0.size());
+    auto decider = [frac0]() { return (1. * randomx() / RNGen::RNGEN_RAND_MAX) <= frac0; };
+    for ( size_t i = 0; i < (size_t) bci0[1]; i += 2 )
+        if ( decider() ) { reads.push_back(reads0[i]); reads.push_back(reads0[i+1]); quals.push_back(quals0[i]); quals.push_back(quals0[i+1]); }
+    for ( size_t bc = 1; bc < bci0.size()-1; ++bc )
+    {   bci.push_back( reads.size() );
+        for ( size_t i = (size_t) bci0[bc]; i < (size_t) bci0[bc+1]; i += 2 )
+            if ( decider() ) { reads.push_back(reads0[i]); reads.push_back(reads0[i+1]); quals.push_back(quals0[i]); quals.push_back(quals0[i+1]); } }
+    bci.push_back( reads.size() );
+    if ( frac0 != 1.0 )
+    {   reads.WriteAll((outdir+"/frag_reads_orig.fastb").c_str()); quals.WriteAll((outdir+"/frag_reads_orig.qualp").c_str());
+        BinaryWriter::writeFile((outdir+"/frag_reads_orig.bci").c_str(),bci); }
     vec<int16_t> lens(reads.size()); int maxLen = 0;
     for ( size_t i = 0; i != reads.size(); ++i ) { lens[i] = reads[i].size(); if ( lens[i] > maxLen ) maxLen = lens[i]; }
     vec<vec<vec<int64_t>>> hist( 2, vec<vec<int64_t>>( maxLen, vec<int64_t>(256,0) ) );
@@ -326,7 +341,6 @@ int side( std::string const& head, std::string const& outdir )
     // and its own feudal writers; the glue restates 10X/DfTools.cc: LoadData draws one number per pair even at
     // LR_SELECT_FRAC = 1 (:115-117,131,147), then WriteSubSample (:32-67) keeps a pair when its draw says so or
     // when only as many pairs are left as are still wanted.
-    for ( size_t i = 0; i + 1 < reads.size(); i += 2 ) (void)randomx();
     {
         size_t pair_count = std::min<size_t>( reads.size()/2, 500 );
         double frac = static_cast<double>(pair_count)/(reads.size()/2);
@@ -371,6 +385,7 @@ int main( int argc, char** argv )
     if ( cmd == "mkreads" && argc == 4 ) return mkreads(argv[2],argv[3]);
     if ( cmd == "rdreads" && argc == 4 ) return rdreads(argv[2],argv[3]);
     if ( cmd == "side" && argc == 4 ) return side(argv[2],argv[3]);
+    if ( cmd == "side" && argc == 5 ) return side(argv[2],argv[3],atof(argv[4]));
     if ( cmd == "dict" && argc == 10 )
     {
         unsigned K = atoi(argv[2]);

@@ -90,8 +90,8 @@ int main(int argc, char** argv)
     const unsigned K = (unsigned)atoi(a["K"].c_str());
     if (K != 40 && K != 48 && K != 60) give_up("K must be 40, 48 or 60");                        // DF.cc:209
     if (a["LR"].empty()) give_up("I'm not sure you really want to do this, since it may\ndelete your starting files.  So I'm going to quit.");
-    for (const std::string& f : parse_set(a["LR_SELECT_FRAC"]))
-        if (atof(f.c_str()) != 1.0) give_up("LR_SELECT_FRAC != 1.0 needs the reference's random number stream; not supported");
+    std::vector<double> select_frac;
+    for (const std::string& f : parse_set(a["LR_SELECT_FRAC"])) select_frac.push_back(atof(f.c_str()));
 
     std::string work_dir = a["ROOT"] + "/GapToy/" + a["INSTANCE"];                                  // DF.cc:221-222
     if (!a["OUT_DIR"].empty()) work_dir = a["OUT_DIR"];
@@ -127,23 +127,31 @@ int main(int argc, char** argv)
         std::vector<int64_t> bci{0};
         std::vector<DataSet> datasets;
         R.base_off.push_back(0); R.pq_off.push_back(0);
-        auto append = [&](const In& x, int64_t lo, int64_t hi) {
-            if (hi <= lo) return;
-            R.packed.insert(R.packed.end(), x.packed.begin() + x.boff[lo], x.packed.begin() + x.boff[hi]);
-            R.pq.insert(R.pq.end(), x.pq.begin() + x.qoff[lo], x.pq.begin() + x.qoff[hi]);
-            for (int64_t r = lo; r < hi; ++r) {
-                R.base_off.push_back(R.base_off.back() + (x.boff[r + 1] - x.boff[r]));
-                R.pq_off.push_back(R.pq_off.back() + (x.qoff[r + 1] - x.qoff[r]));
-                R.read_len.push_back(x.len[r]);
+        // every pair asks the reference's random stream whether it stays (DfTools.cc:115-117): always at
+        // LR_SELECT_FRAC = 1, but the number is drawn all the same, and WriteSubSample continues the stream
+        if (select_frac.size() == 1 && heads.size() > 1) select_frac.assign(heads.size(), select_frac[0]);
+        if (select_frac.size() != heads.size()) throw std::runtime_error("LR_SELECT_FRAC needs one value per LR input");   // DfTools.cc:96
+        RefRandom rng;
+        auto append = [&](const In& x, double frac, int64_t lo, int64_t hi) {
+            for (int64_t r = lo; r + 1 < hi + (hi - lo) % 2; r += 2) {
+                if (!((1. * rng.next() / 2147483647.0) <= frac)) continue;
+                for (int64_t k = r; k < std::min<int64_t>(r + 2, hi); ++k) {
+                    R.packed.insert(R.packed.end(), x.packed.begin() + x.boff[k], x.packed.begin() + x.boff[k + 1]);
+                    R.pq.insert(R.pq.end(), x.pq.begin() + x.qoff[k], x.pq.begin() + x.qoff[k + 1]);
+                    R.base_off.push_back(R.base_off.back() + (x.boff[k + 1] - x.boff[k]));
+                    R.pq_off.push_back(R.pq_off.back() + (x.qoff[k + 1] - x.qoff[k]));
+                    R.read_len.push_back(x.len[k]);
+                }
             }
         };
-        for (const In& x : ins) {                                                                   // PASS_UNBARCODED
+        for (size_t i = 0; i < ins.size(); ++i) {                                                   // PASS_UNBARCODED
             DataSet d{}; d.dt = 2; d.start = (int64_t)R.size(); datasets.push_back(d);
-            append(x, 0, x.bci[1]);
+            append(ins[i], select_frac[i], 0, ins[i].bci[1]);
         }
-        for (const In& x : ins) {                                                                   // PASS_BARCODED
+        for (size_t i = 0; i < ins.size(); ++i) {                                                   // PASS_BARCODED
+            const In& x = ins[i];
             DataSet d{}; d.dt = 3; d.start = (int64_t)R.size(); datasets.push_back(d);
-            for (size_t b = 1; b + 1 < x.bci.size(); ++b) { bci.push_back((int64_t)R.size()); append(x, x.bci[b], x.bci[b + 1]); }
+            for (size_t b = 1; b + 1 < x.bci.size(); ++b) { bci.push_back((int64_t)R.size()); append(x, select_frac[i], x.bci[b], x.bci[b + 1]); }
         }
         bci.push_back((int64_t)R.size());
         ins.clear();
@@ -152,12 +160,9 @@ int main(int argc, char** argv)
         feudal::write_qualp(rh + ".qualp", R.pq.data(), R.pq_off);
         { feudal::BinWriter w(rh + ".bci"); w.vec(bci); }
         {
-            // WriteSubSample(bases, quals, 500, ".../frag_reads_orig.1000") (DfTools.cc:32-67,169).  The stream has
-            // already given LoadData one number per pair: its decider draws even at LR_SELECT_FRAC = 1
-            // (:115-117,131,147).  A pair is kept when its draw says so, or when only as many are left as are wanted.
-            RefRandom rng;
+            // WriteSubSample(bases, quals, 500, ".../frag_reads_orig.1000") (DfTools.cc:32-67,169), on the same stream.
+            // A pair is kept when its draw says so, or when only as many are left as are wanted.
             const size_t n = R.size();
-            for (size_t i = 0; i + 1 < n; i += 2) (void)rng.next();
             size_t want = std::min<size_t>(n / 2, 500);
             const double frac = n / 2 ? (double)want / (double)(n / 2) : 0.0;
             std::vector<uint8_t> sp, sq; std::vector<uint64_t> so{0}, sqo{0}; std::vector<uint32_t> sl;

@@ -77,7 +77,10 @@ def main():
     feudal.write_bci(head + ".bci", bci)
     side = os.path.join(HERE, "side")
     os.makedirs(side, exist_ok=True)
-    subprocess.check_call([REFDRV, "side", head, side])      # .lens/.qhist/.dti/subsam.* via the reference's BinaryWriter
+    subprocess.check_call([REFDRV, "side", head, side])      # .lens/.qhist/.dti/subsam.*/.1000.* via the reference's BinaryWriter, feudal writers and randomx()
+    side07 = os.path.join(HERE, "side_frac07")
+    os.makedirs(side07, exist_ok=True)
+    subprocess.check_call([REFDRV, "side", head, side07, "0.7"])   # the same with LR_SELECT_FRAC = 0.7 (+ the selected reads themselves)
     for K, use_bc, min_bc, tag in ((48, 1, 2, "k48"), (48, 1, 1, "k48_minbc1"), (40, 0, 0, "k40_nobc"), (60, 0, 0, "k60_nobc")):
         out = os.path.join(HERE, "tmp_" + tag)
         os.makedirs(out, exist_ok=True)

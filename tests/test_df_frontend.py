@@ -73,6 +73,18 @@ def test_missing_input_gives_up_like_the_reference(tmp_path):
     assert run_df("K=47", "LR=x").returncode == 1
 
 
+def test_lr_select_frac_follows_the_reference_random_stream(tmp_path, golden_dir):
+    """LR_SELECT_FRAC=0.7: which pairs stay is decided by the reference's global random stream (one draw per pair,
+    DfTools.cc:115-117); tests/golden/side_frac07/* were written by refdrv with the reference's randomx() and
+    feudal writers."""
+    r = run_df(f"LR={golden_dir}/reads.fastb", f"OUT_DIR={tmp_path}/w", "EXIT_LOAD=True", "LR_SELECT_FRAC=0.7")
+    assert r.returncode == 0, r.stdout + r.stderr
+    rd = lambda p: open(p, "rb").read()
+    for name in ("frag_reads_orig.fastb", "frag_reads_orig.qualp", "frag_reads_orig.bci", "frag_reads_orig.lens",
+                 "frag_reads_orig.qhist", "frag_reads_orig.1000.fastb", "frag_reads_orig.1000.qualp"):
+        assert rd(f"{tmp_path}/w/data/{name}") == rd(f"{golden_dir}/side_frac07/{name}"), name
+
+
 @pytest.mark.gpu
 def test_df_end_to_end_on_gpu(tmp_path, golden_dir, oracle):
     r = run_df(f"LR={golden_dir}/reads.fastb", f"OUT_DIR={tmp_path}/w", "K=48")
