@@ -75,7 +75,7 @@ struct dfk_ctx {
     struct Part { DevBuf buf, pre; uint64_t n = 0; };   // dfk_entry32[n]: one per pass
     std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
-    unsigned seg_attempt = 0;                 // output segments are sized (estimate << seg_attempt)
+    unsigned seg_attempt = 0;                 // the room for a pass's solid k-mers is (estimate << seg_attempt)
     double distinct_per_inst = 0.0;           // observed on the passes of the current run (sizes the work items)
     double plan_derate = 0.95;                // share of the free HBM a pass is planned into; lowered when a pass ran out (kept across runs)
     std::vector<int64_t> hist;
@@ -134,7 +134,7 @@ struct dfk_ctx {
             { (void)hipFree(chunks[i].p); reserved -= chunks[i].bytes; chunks.erase(chunks.begin() + i); }
             else ++i;
     }
-    // Everything one pass holds while it is in flight (bucket tables, records, output segments) comes out of ONE
+    // Everything one pass holds while it is in flight (bucket tables, records) comes out of ONE
     // arena block, so that two passes in flight plus the growing dictionary never interleave: the blocks of
     // successive passes do not grow, so each fits the hole left by the pass before the running one.
     struct PassBlock { DevBuf block; size_t used = 0; };
@@ -521,7 +521,7 @@ int scatter_end(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log
 }
 
 // ------------------------------------------------------------------ stage: count (a2 second half, a3, a4, a5)
-constexpr int E_SEGMENT_FULL = -100;   // internal: redo the run with larger output segments
+constexpr int E_SEGMENT_FULL = -100;   // internal: the room reserved for a pass's solid k-mers was too small; redo the pass with more
 
 struct CountRun {                     // device state shared by the count launches of one run
     CountGlobals* g = nullptr; uint4* seg = nullptr; unsigned long long* hist = nullptr;
@@ -689,7 +689,7 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     uint64_t* d_chunk_pre = (uint64_t*)d_pre.p; uint64_t* d_slot_pre = d_chunk_pre + (n + 1);
     HIP_TRY(hipMemcpyAsync(d_chunk_pre, chunk_pre.data(), 8ull * (n + 1), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_slot_pre, slot_pre.data(), 8ull * (n + 1), hipMemcpyHostToDevice, c->stream));
-    CountParams cpb = R.cp; cpb.seg_cap = R.big_cap; cpb.n_segments = 1;   // one segment: the fallback's own buffer
+    CountParams cpb = R.cp; cpb.seg_cap = R.big_cap;                       // the fallback writes to its own buffer
     // the whole grid works on the fallback tables together (d_fail + 8: the chunk ticket)
     const unsigned cus = (unsigned)c->prop.multiProcessorCount;
     const unsigned g_ins = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + NW * BIG_TICKET_CHUNKS - 1) / (NW * BIG_TICKET_CHUNKS), 4ull * cus));
@@ -719,7 +719,7 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
 int barcode_words(const dfk_ctx* c, bool have_bc)
 { return !have_bc ? 0 : (int)std::max<uint32_t>(1, std::min<uint32_t>(c->cfg.min_bc, 4) - (c->cfg.min_bc > 1 ? 1 : 0)); }
 
-// solid k-mers a pass of n_inst instances is expected to emit at most (what its output segments are sized for)
+// solid k-mers a pass of n_inst instances is expected to emit at most (what its part's reservation is sized for)
 uint64_t solid_cap(const dfk_ctx* c, const CountRun& R, uint64_t n_inst)
 {
     uint64_t cap = n_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;
@@ -933,12 +933,12 @@ uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
 }
 
 // How many fine buckets the next pass may take, from what is free now.  A pass holds its bucket tables, its
-// records (32 B each), its output segments and, at the end, its dense part of the dictionary; the parts of
+// records (32 B each) and its dense part of the dictionary (reserved when the pass is counted); the parts of
 // earlier passes stay resident, so later passes are smaller.  Buckets are hash-distributed, so a range holds
 // its share of the records and instances to within a fraction of a percent.
 // `running` != null: the range is scattered while that pass is being counted, so (1) its tables and records
-// must fit beside everything the running pass holds plus the part it is about to add, and (2) its segments
-// and part must fit once the running pass has been released.
+// must fit beside everything the running pass holds, and (2) its part must fit once the running pass has been
+// released.
 struct RunningPass { uint64_t bytes_held; uint64_t n_inst; uint32_t n_buckets; uint64_t block_off; };
 
 // The same question asked of the arena's actual free blocks (one chunk).  A pass block goes to the highest free
@@ -983,7 +983,7 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
     double ratio = R.inst_seen ? 1.12 * (double)R.solid_seen / (double)R.inst_seen : 1.0 / 10.0;
     ratio = std::min(ratio, 1.0 / std::max<uint32_t>(1, c->cfg.min_freq));
     const double per_in = 81.0 + 32.5 * rec_per;                                         // tables and records (as the pass block is sized)
-    const double per_seg = 0.0;                                                                       // (no output segments any more: workgroups write into the part's reservation)
+    const double per_seg = 0.0;                                                                       // (workgroups write straight into the part's reservation: nothing else per pass)
     const double per_out = 32.0 * ratio * inst_per * (double)(1u << c->seg_attempt);                  // the part's reservation
     const double fixed = 120e6;                                       // chunk ends left empty by the workgroups (67 MB), small tables
     const double left = (double)(sub_nb - lo);
@@ -1131,7 +1131,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
             c->st = st0;                                              // the time spent stays on the books
             c->st.ms_part_scatter = ms_scatter; c->st.ms_count = ms_count; c->st.ms_fallback = ms_fb;
             if (++retries > 12) return DFK_E_NOMEM;
-            if (rc == E_SEGMENT_FULL) { ++c->seg_attempt; TRACE("output segments too small: redoing the pass with twice the room"); }
+            if (rc == E_SEGMENT_FULL) { ++c->seg_attempt; TRACE("the room reserved for the pass's solid k-mers was too small: redoing the pass with twice as much"); }
             else if (forced || n <= 16) return rc;
             else { c->plan_derate *= 0.7; TRACE("out of HBM (%s): redoing the pass smaller", g_err.c_str()); }
             rc = start_alone(cur, lo); if (rc) return rc;

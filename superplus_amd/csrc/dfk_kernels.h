@@ -484,7 +484,7 @@ struct ItemRange { uint32_t b0, b1; };     // a work item: fine buckets [b0,b1) 
 struct CountParams {
     uint32_t min_freq, min_bc;
     uint32_t n_items;
-    uint32_t n_segments;             // (unused)
+    uint32_t reserved0;              // (unused)
     uint64_t seg_cap;                // entries the output buffer holds (k_count: the part's reservation; k_big_emit: the fallback buffer)
     uint32_t do_adj;                 // resolve adjacencies inside the table where possible (min_freq > 1)
     uint32_t keep_pre;               // keep the pre-adjacency context byte in the entry's pad field (tests)
@@ -802,7 +802,7 @@ enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_USED = 4, CTL
 //   pass 2  tasks, densely over the threads: neighbour found in this table -> keep the bit iff that slot
 //           is solid (final answer); not found -> the neighbour lives in another item: bit stays, marked
 //           unresolved for the small HBM pass afterwards (k_adjacency) -- about one bit in ten
-//   pass 3  emit solid slots into the workgroup's output segment (LDS cursor) and the spectrum
+//   pass 3  emit solid slots into the workgroup's chunk of the dictionary part (WgOut) and the spectrum
 // `sync` is __syncthreads for the whole workgroup.
 template <int K, int NBC, uint32_t ADJ_TASKS>
 __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
@@ -913,9 +913,9 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         else atomicAdd(&hist_global[count], 1ull);
     };
     {
-        // the solid slots were listed by pass 1, so the emit runs on dense lanes; the workgroup's segment
-        // cursor moves once; then the state words of the whole table are cleared with wide stores (key words
-        // are rewritten on claim).  cnt, ctxs and bcw are contiguous.
+        // the solid slots were listed by pass 1, so the emit runs on dense lanes, into the room thread 0 took for
+        // them above; then the state words of the whole table are cleared with wide stores (key words are
+        // rewritten on claim).  cnt, ctxs and the barcode words are contiguous.
         const uint32_t ns = __builtin_amdgcn_readfirstlane(tld(n_solid));
         const uint32_t used = __builtin_amdgcn_readfirstlane(tld(&ctl[CTL_USED]));
         const unsigned long long cur = (unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OUT_LO])) |
