@@ -20,6 +20,35 @@ from . import dfk as _dfk
 from .dfk import Dfk, _check, lib
 
 
+def exchange_begin(send: torch.Tensor, send_counts, unit: int, comm, recv_alloc=None):
+    """First half of exchange(): the counts are exchanged (small, waited for), the receive buffer is made and the
+    all-to-all of the payload is started.  Returns a token for exchange_end().  With a transport that cannot run
+    the collective in the background the whole exchange happens here."""
+    sc = torch.tensor(list(send_counts), dtype=torch.int64, device=send.device)
+    rc = torch.empty_like(sc)
+    comm.all_to_all_single(rc, sc, None, None)
+    rcl = [int(x) for x in rc.tolist()]
+    recv = recv_alloc(sum(rcl)) if recv_alloc else torch.empty(sum(rcl) * unit, dtype=torch.uint8, device=send.device)
+    if send.is_cuda:
+        torch.cuda.synchronize(send.device)       # the library filled `send` on its own stream
+    start = getattr(comm, "all_to_all_single_async", None)
+    work = None
+    if start is not None:
+        work = start(recv, send, [x * unit for x in rcl], [int(x) * unit for x in send_counts])
+    else:
+        comm.all_to_all_single(recv, send, [x * unit for x in rcl], [int(x) * unit for x in send_counts])
+    return recv, rcl, work, send                   # `send` is kept alive until the collective has finished
+
+
+def exchange_end(token):
+    recv, rcl, work, send = token
+    if work is not None:
+        work.wait()
+    if recv.is_cuda:
+        torch.cuda.synchronize(recv.device)        # the library reads `recv` on its own stream
+    return recv, rcl
+
+
 def exchange(send: torch.Tensor, send_counts, unit: int, comm, recv_alloc=None):
     """All-to-all of variable-size slices.  `send` is a flat byte tensor holding, rank after rank,
     send_counts[r] units of `unit` bytes for rank r.  Returns (recv bytes, recv_counts).
@@ -66,6 +95,14 @@ class TorchComm:
                     reqs.append(self.dist.irecv(outs[peer], peer, group=self.group))
             for r in reqs:
                 r.wait()
+
+    def all_to_all_single_async(self, out, inp, out_split, in_split):
+        """The same collective, left running: returns a work handle (None if it had to be done on the spot)."""
+        try:
+            return self.dist.all_to_all_single(out, inp, out_split, in_split, group=self.group, async_op=True)
+        except RuntimeError:
+            self.all_to_all_single(out, inp, out_split, in_split)
+            return None
 
     def all_reduce_sum(self, value: int, device):
         t = torch.tensor([value], dtype=torch.int64, device=device)
@@ -184,12 +221,22 @@ class DistDfk(Dfk):
             raise _dfk.DfkError(-7, "Looks like your input data have almost no good bases.")
         self._n_inst_global = n_global
         log2_passes = comm.all_reduce_max(self.plan(world, n_global), packed.device)   # every rank runs the same passes
-        for p in range(1 << log2_passes):
-            send, counts = self.partition(world, n_global, log2_passes, p)
-            recv, _ = exchange(send, counts, 32, comm, self.recv_buffer)  # the k-mer shuffle, one bucket range at a time
-            del send
+        # The k-mer shuffle, one bucket range at a time -- and one range ahead: while pass p is counted, the records
+        # of pass p+1 have been cut and are on their way (the library keeps a second receive buffer for them).
+        n_pass = 1 << log2_passes
+        send, counts = self.partition(world, n_global, log2_passes, 0)
+        recv, _ = exchange_end(exchange_begin(send, counts, 32, comm, self.recv_buffer))
+        for p in range(n_pass):
+            token = None
+            if p + 1 < n_pass:
+                send, counts = self.partition(world, n_global, log2_passes, p + 1)
+                token = exchange_begin(send, counts, 32, comm, self.recv_buffer)
             self.count_records(recv, p)
             del recv
+            if token is not None:
+                recv, _ = exchange_end(token)
+                del token
+        del send
         keys, kcounts = self.adj_queries(world)
         rkeys, rcounts = exchange(keys, kcounts, 16, comm)                 # neighbour queries
         answers = self.adj_answer(rkeys)
@@ -223,18 +270,35 @@ def _a2a(bufs, counts, unit):
     return out, rcounts
 
 
-def run_inprocess(ranks, shards):
+def run_inprocess(ranks, shards, pipelined=False):
     """Drive `ranks` (DistDfk objects, possibly all on one GPU) through the sharded pipeline with the
-    exchanges done by tensor slicing.  shards[r] = (packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0)."""
+    exchanges done by tensor slicing.  shards[r] = (packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0).
+    pipelined: the order DistDfk.count_device uses (pass p+1 is cut and received before pass p is counted,
+    into buffers the library hands out)."""
     world = len(ranks)
     n_local = [ranks[r].begin(*shards[r]) for r in range(world)]
     n_global = sum(n_local)
     log2_passes = max(ranks[r].plan(world, n_global) for r in range(world))
-    for p in range(1 << log2_passes):
+
+    def shuffle(p):
         sends = [ranks[r].partition(world, n_global, log2_passes, p) for r in range(world)]
         recv, _ = _a2a([s[0] for s in sends], [s[1] for s in sends], 32)
-        recv = [x.clone() for x in recv]        # the send buffers are freed by count_records
-        del sends
+        if not pipelined:
+            return [x.clone() for x in recv]    # the send buffers are freed by count_records
+        out = []
+        for r in range(world):                  # receive into the library's own buffers, as the real driver does
+            buf = ranks[r].recv_buffer(recv[r].numel() // 32)
+            buf.copy_(recv[r])
+            out.append(buf)
+        return out
+
+    nxt = shuffle(0) if pipelined else None
+    for p in range(1 << log2_passes):
+        if pipelined:
+            recv = nxt
+            nxt = shuffle(p + 1) if p + 1 < (1 << log2_passes) else None
+        else:
+            recv = shuffle(p)
         for r in range(world):
             ranks[r].count_records(recv[r], p)
             ranks[r]._n_inst_global = n_global

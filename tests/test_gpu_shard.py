@@ -26,15 +26,19 @@ def _shards(rs, world, dev):
     return out
 
 
-@pytest.mark.parametrize("world,K,ign,passes", [(2, 48, 0, 0), (4, 48, 3000, 0), (8, 60, 0, 0), (2, 40, 0, 0), (2, 48, 0, 4), (4, 48, 0, 2)])
-def test_sharded_equals_single(oracle, world, K, ign, passes):
+@pytest.mark.parametrize("world,K,ign,passes,pipelined", [(2, 48, 0, 0, False), (4, 48, 3000, 0, False), (8, 60, 0, 0, False),
+                                                          (2, 40, 0, 0, False), (2, 48, 0, 4, False), (4, 48, 0, 2, False),
+                                                          (2, 48, 0, 4, True), (4, 48, 0, 8, True), (8, 48, 0, 2, True)])
+def test_sharded_equals_single(oracle, world, K, ign, passes, pipelined):
+    """pipelined: the order of the real driver -- pass p+1 is cut and received (into the library's second receive
+    buffer) before pass p is counted."""
     from superplus_amd.dist import DistDfk, run_inprocess
     rs = util.make_set(51 + world, 80000, 9000)
     ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=K,
                      ign_bc_below=ign)
     dev = torch.device("cuda", 0)
     ranks = [DistDfk(K=K, device=0, ign_bc_below=ign, keep_pre_adjacency=True, passes=passes) for _ in range(world)]
-    n_global = run_inprocess(ranks, _shards(rs, world, dev))
+    n_global = run_inprocess(ranks, _shards(rs, world, dev), pipelined=pipelined)
     assert n_global == ref["n_inst"]
     assert np.array_equal(np.concatenate([d.good_lens() for d in ranks]), ref["good_len"])
     for pre in (True, False):
@@ -63,7 +67,7 @@ def test_rccl_path_single_rank(oracle):
     try:
         rs = util.make_set(71, 60000, 6000)
         ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
-        d = DistDfk(K=48, device=0, passes=2)
+        d = DistDfk(K=48, device=0, passes=4)
         d.count_device(*_shards(rs, 1, dev)[0][:6])
         util.assert_same_solid(d.solid(), ref["solid"], "rccl world=1")
         assert np.array_equal(d.spectrum(), ref["hist"])
