@@ -47,6 +47,14 @@ def _worker(rank, world, port, q):
         owner = np.repeat(np.arange(world), counts)
         expect = (keys.reshape(-1, 16).sum(dim=1) % 251).to(torch.uint8).numpy() + owner.astype(np.uint8)
         assert np.array_equal(back.numpy(), expect)
+        # the pipelined form the driver uses: two exchanges begun back to back, ended in order, while "work" happens
+        from superplus_amd.dist import exchange_begin, exchange_end
+        t1 = exchange_begin(send, counts, 32, comm)
+        t2 = exchange_begin(keys, counts, 16, comm)
+        r1, c1 = exchange_end(t1)
+        r2, c2 = exchange_end(t2)
+        assert np.array_equal(r1.numpy(), recv.numpy()) and c1 == rcounts
+        assert np.array_equal(r2.numpy(), rkeys.numpy()) and c2 == rc
         total = comm.all_reduce_sum(sum(counts), "cpu")
         q.put((rank, "ok", total))
     except Exception as e:  # pragma: no cover
