@@ -354,8 +354,10 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     rc = c->alloc(T->summ, std::max<uint64_t>(1, in.n_reads) * 16, "run summaries", true); if (rc) return rc;
     if (!by_class) HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
     unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
+    static const unsigned scan_blocks = getenv("DFK_SCAN_BLOCKS") ? (unsigned)atoi(getenv("DFK_SCAN_BLOCKS")) : 0;
     if (by_class) grid = std::min<unsigned>(grid, 12u * (unsigned)c->prop.multiProcessorCount);   // grid-stride: class counts are flushed once per block
-    const size_t lds_a = (sizeof(uint32_t) + 1) * pp.W * PART_THREADS + sizeof(uint16_t) * SUMMARY_RUNS * PART_THREADS + (by_class ? n_bins * 4 : 0);
+    else if (scan_blocks) grid = std::min<unsigned>(grid, scan_blocks * (unsigned)c->prop.multiProcessorCount);
+    const size_t lds_a = (sizeof(uint32_t) + 1) * pp.W * PART_THREADS + sizeof(uint16_t) * SUMMARY_RUNS * PART_THREADS + sizeof(uint32_t) * PART_RING * PART_THREADS + (by_class ? n_bins * 4 : 0);
     Timer t(c->stream);
     t.start();
     if (grid)
@@ -929,7 +931,8 @@ uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
     // fine buckets of ~256-512 instances; an item packs several of them up to its instance budget.
     // (When sharded, the record header keeps 24 bits of the bucket id inside the pass for the receiver's
     // regroup: dfk_shard_plan asks for enough passes that a pass has <= 2^24 buckets per owner.)
-    uint32_t l = ceil_log2(n_inst / 512 + 1);
+    static const uint64_t per = getenv("DFK_INST_PER_BUCKET") ? (uint64_t)atoll(getenv("DFK_INST_PER_BUCKET")) : 512;
+    uint32_t l = ceil_log2(n_inst / per + 1);
     l = std::max<uint32_t>(l, 4 + log2_world);
     return std::min<uint32_t>(l, 28);
 }

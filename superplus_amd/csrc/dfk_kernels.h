@@ -101,7 +101,8 @@ struct PartParams {
     uint32_t sub_n;        // [sub_lo, sub_lo + sub_n); numbered owner * sub_n + (id - sub_lo) inside the pass
 };
 
-constexpr int PART_THREADS = 256;
+constexpr int PART_THREADS = 128;
+constexpr int PART_RING = 8;          // words of its read a lane of the counting scan keeps staged in LDS
 // Per-read run summary written by the counting scan (16 bytes): bits 0-3 = number of runs (super-k-mers) or
 // SUMMARY_OVERFLOW, then from bit 8 twelve bits per run: nk (6) | offset of its minimizer from the run's
 // first k-mer (6, < W).  The scatter passes rebuild each run's bucket from the 2M bits at that offset
@@ -192,6 +193,7 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
     uint32_t* queue = smem + pp.W * PART_THREADS;                // WRITE: [PART_QCAP][2][PART_THREADS]
     uint8_t* sidx = reinterpret_cast<uint8_t*>(smem + pp.W * PART_THREADS);              // !WRITE: [W][PART_THREADS] where each suffix minimum sits
     uint16_t* rq = reinterpret_cast<uint16_t*>(sidx + pp.W * PART_THREADS);              // !WRITE: [SUMMARY_RUNS][PART_THREADS] run fields
+    uint32_t* ring = reinterpret_cast<uint32_t*>(rq + SUMMARY_RUNS * PART_THREADS);       // !WRITE: [PART_RING][PART_THREADS] words of the read
     const int tid = threadIdx.x;
     if (WRITE && read_list) { if (r >= n_list) return; r = read_list[r]; }
     const uint32_t M = pp.M, W = pp.W;
@@ -216,9 +218,23 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
 
     // the word after the current one is always in flight (a load issued when it is needed costs a full
     // memory latency every 16 bases)
+    // The counting scan stages PART_RING words of the read in LDS at a time (one fill covers a 100-base read): a
+    // global load inside the loop has to be waited for with vmcnt(0), which also waits for every bucket atomic
+    // the lane has in flight -- that coupling cost the scan 200 ms of 560.  The scanning scatter (rare) keeps
+    // the word after the current one in a register instead.
     uint64_t wi = bit0 >> 5;
-    uint32_t wbits = wi < n_words ? words[wi] : 0u;
-    uint32_t wnext = wi + 1 < n_words ? words[wi + 1] : 0u;
+    uint64_t filled_to = wi;
+    auto fill = [&]() {
+        uint32_t w[PART_RING];
+#pragma unroll
+        for (int k = 0; k < PART_RING; ++k) w[k] = filled_to + k < n_words ? words[filled_to + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < PART_RING; ++k) ring[((filled_to + k) & (PART_RING - 1)) * PART_THREADS + tid] = w[k];
+        filled_to += PART_RING;
+    };
+    uint32_t wbits, wnext = 0;
+    if (!WRITE) { fill(); wbits = ring[(wi & (PART_RING - 1)) * PART_THREADS + tid]; }
+    else { wbits = wi < n_words ? words[wi] : 0u; wnext = wi + 1 < n_words ? words[wi + 1] : 0u; }
     uint32_t wpos = (uint32_t)bit0 & 31u;
     uint32_t sfx_next = 0xFFFFFFFFu;        // arr[bi + 1] of the previous block, read one position ahead
 
@@ -247,7 +263,11 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
     for (uint32_t j = 0; j < gl; ++j) {
         uint32_t b = (wbits >> wpos) & 3u;
         wpos += 2;
-        if (wpos == 32) { wpos = 0; ++wi; wbits = wnext; wnext = wi + 1 < n_words ? words[wi + 1] : 0u; }
+        if (wpos == 32) {
+            wpos = 0; ++wi;
+            if (!WRITE) { if (wi == filled_to) fill(); wbits = ring[(wi & (PART_RING - 1)) * PART_THREADS + tid]; }
+            else { wbits = wnext; wnext = wi + 1 < n_words ? words[wi + 1] : 0u; }
+        }
         f = ((f << 2) | b) & mmask;
         rc = (rc >> 2) | ((3u - b) << rsh);
         if (j + 1 < M) continue;
@@ -344,7 +364,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     uint32_t* lh = nullptr;
     const uint32_t n_bins = 2u * (PART_CLASSES << pp.log2_world);
     if (!WRITE && class_hist) {
-        lh = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + 5 * pp.W * PART_THREADS + 2 * SUMMARY_RUNS * PART_THREADS);
+        lh = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + 5 * pp.W * PART_THREADS + 2 * SUMMARY_RUNS * PART_THREADS + 4 * PART_RING * PART_THREADS);
         for (uint32_t i = threadIdx.x; i < n_bins; i += PART_THREADS) lh[i] = 0;
         __syncthreads();
     }

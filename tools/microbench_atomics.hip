@@ -8,7 +8,7 @@
 
 __device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
-template <int MODE>   // 0: u64 atomic no return, 1: u64 atomic returning, 2: u32 atomic returning, 3: u64 load, 4: 32-B store
+template <int MODE>   // 0: u64 atomic no return, 1: u64 atomic returning, 2: u32 atomic returning, 3: u64 load, 4: 32-B store, 5: u32 atomic no return
 __global__ void k(unsigned long long* tab, uint64_t mask, uint64_t n_ops, unsigned long long* sink)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,6 +20,7 @@ __global__ void k(unsigned long long* tab, uint64_t mask, uint64_t n_ops, unsign
         else if (MODE == 1) acc += atomicAdd(&tab[a], 1ull);
         else if (MODE == 2) acc += atomicAdd(reinterpret_cast<unsigned int*>(tab) + a, 1u);
         else if (MODE == 3) acc += tab[a];
+        else if (MODE == 5) atomicAdd(reinterpret_cast<unsigned int*>(tab) + a, 1u);
         else { uint4* p = reinterpret_cast<uint4*>(tab) + 2 * (a >> 2); p[0] = uint4{1, 2, 3, 4}; p[1] = uint4{5, 6, 7, 8}; }
     }
     if (acc == 0x123456789ull) *sink = acc;
@@ -39,7 +40,7 @@ template <int MODE> void run(const char* name, unsigned long long* tab, uint64_t
 int main()
 {
     unsigned long long* sink; CK(hipMalloc(&sink, 8));
-    for (uint64_t mb : {32, 128, 256, 512, 2048, 8192}) {
+    for (uint64_t mb : {32, 128, 256, 512, 1024, 2048, 8192}) {
         const uint64_t words = mb * 1024 * 1024 / 8;
         unsigned long long* tab; CK(hipMalloc(&tab, words * 8)); CK(hipMemset(tab, 0, words * 8));
         printf("table %llu MB\n", (unsigned long long)mb);
@@ -47,6 +48,7 @@ int main()
         run<0>("atomic u64", tab, words, n, sink);
         run<1>("atomic u64 returning", tab, words, n, sink);
         run<2>("atomic u32 returning", tab, words, n, sink);
+        run<5>("atomic u32", tab, words, n, sink);
         run<3>("load u64", tab, words, n, sink);
         run<4>("store 32 B", tab, words, n, sink);
         CK(hipFree(tab));
