@@ -75,7 +75,7 @@ def make_reads(genome, n_pairs, seed, read_len=100, err=0.005, unbar_frac=0.10,
     dev = genome.device
     G = genome.numel()
     L = read_len
-    assert G > 600 and L % 4 == 0
+    assert G > 600 and L % 4 == 0 and L <= 255       # (one PQVec block per quality run: nQs is a byte)
     g = torch.Generator(device=dev).manual_seed(seed)
     ri = lambda lo, hi, n: torch.randint(lo, hi, (n,), generator=g, device=dev)
     n_unbar = int(n_pairs * unbar_frac)

@@ -103,6 +103,15 @@ def test_ragged_and_degenerate_reads(oracle):
         util.check_parity(ref, d)
 
 
+def test_long_reads_take_the_scanning_scatter(oracle):
+    """240-base reads have more than the ten runs a summary holds: most of them go through the scanning
+    scatter (k_partition<K,true>) in every pass, and its words through several refills of the scan's LDS ring."""
+    rs = util.make_set(81, 300000, 6000, read_len=240)
+    for passes in (0, 4):
+        ref, d = util.run_both(oracle, rs, K=48, passes=passes)
+        util.check_parity(ref, d)
+
+
 def test_low_complexity_hot_buckets(oracle):
     """Poly-A / dinucleotide repeats: one k-mer seen thousands of times, runs longer than NK_MAX in one bucket,
     palindromes (not context-symmetrised)."""

@@ -54,6 +54,18 @@ def test_sharded_equals_single(oracle, world, K, ign, passes, pipelined):
     assert sum(d.stats()["n_distinct"] for d in ranks) == ref["n_distinct"]
 
 
+def test_sharded_long_reads(oracle):
+    """Reads whose summaries overflow reach their owners through the scanning scatter's slice mode."""
+    from superplus_amd.dist import DistDfk, run_inprocess
+    rs = util.make_set(91, 200000, 3000, read_len=240)
+    ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
+    dev = torch.device("cuda", 0)
+    ranks = [DistDfk(K=48, device=0, passes=2) for _ in range(2)]
+    run_inprocess(ranks, _shards(rs, 2, dev), pipelined=True)
+    allk = np.concatenate([d.solid() for d in ranks])
+    util.assert_same_solid(allk[np.lexsort((allk["w1"], allk["w0"]))], ref["solid"], "sharded long reads")
+
+
 def test_rccl_path_single_rank(oracle):
     """The real transport: torch.distributed with the nccl (= RCCL) backend, world size 1 on this GPU.
     Exercises TorchComm, the zero-copy views of library buffers and all_to_all_single with byte splits."""
