@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--family-copies", type=int, default=0,
                     help="plant this many diverged copies of one 300-bp element in the genome (hot minimizer buckets)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path (torch.distributed + DistDfk) even with one rank: a check of that path on one GPU")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="rehearsal on one GPU: run rank 0 of this many ranks against replicas of itself (not a benchmark result)")
     args = ap.parse_args()
@@ -130,9 +132,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: libdfk has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if "RANK" not in os.environ:                 # --force-dist without a launcher
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     G = int(args.genome_mb * 1e6)
     total_pairs = int(args.coverage * G / 200.0) if args.coverage > 0 else args.pairs
@@ -142,7 +149,7 @@ def main():
     genome = synth.make_genome(G, 20261004, device=dev, family_copies=args.family_copies)   # same genome on every rank
     rs = synth.make_reads(genome, hi - lo, 20261004 + 17 * (rank + 1))
     del genome
-    if world > 1:      # barcode ids must not collide between ranks
+    if multi:          # barcode ids must not collide between ranks
         stride = int(rs.bc.max().item()) + 1
         st = torch.tensor([stride], dtype=torch.int64, device=dev)
         dist.all_reduce(st, op=dist.ReduceOp.MAX)
@@ -157,7 +164,7 @@ def main():
         def step():
             d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc, read_id0=0)
             return d.stats()
-    elif world == 1:
+    elif not multi:
         d = Dfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes)
         def step():
             d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc)
@@ -170,7 +177,7 @@ def main():
             return d.stats()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -184,7 +191,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     n_inst = st["n_inst"]
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -226,7 +233,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, args.K, args.cpu_sample_reads)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

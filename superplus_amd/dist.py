@@ -13,6 +13,8 @@ exchange plumbing is tested on the CPU with gloo.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -69,40 +71,70 @@ def exchange(send: torch.Tensor, send_counts, unit: int, comm, recv_alloc=None):
 
 
 class TorchComm:
-    """torch.distributed transport (RCCL on GPUs, gloo in the CPU tests)."""
+    """torch.distributed transport (RCCL on GPUs, gloo in the CPU tests).
+
+    The payload never goes through the backend's all-to-all in one piece.  RCCL 2.26 (ROCm 7.0) delivers only the
+    first half of a send/recv of 2.5 GB or more and reports success (tools/check_rccl_large.py: rank to itself,
+    as bytes or as int64, waited for or not), and a pass of BASELINE configs[2] moves 3-7 GB per pair of ranks at
+    2 and 4 ranks.  So: the slice a rank keeps is a device copy, and every other slice travels as point-to-point
+    messages of at most PIECE bytes, one batch (= one RCCL group) per round."""
+
+    PIECE = int(os.environ.get("DFK_A2A_PIECE_BYTES", str(1 << 30)))
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
+    def _start(self, out, inp, out_split, in_split):
+        """Start the exchange; returns the requests still in flight."""
+        world, rank, dist = self.world, self.rank, self.dist
+        if out_split is None:
+            out_split = [out.numel() // world] * world
+        if in_split is None:
+            in_split = [inp.numel() // world] * world
+        if sum(out_split) != out.numel() or sum(in_split) != inp.numel():
+            raise ValueError("all_to_all: the splits do not cover the buffers")
+        out_off = np.concatenate([[0], np.cumsum(out_split)]).astype(np.int64)
+        in_off = np.concatenate([[0], np.cumsum(in_split)]).astype(np.int64)
+        if out_split[rank] != in_split[rank]:
+            raise ValueError("all_to_all: this rank sends itself %d elements and expects %d" % (in_split[rank], out_split[rank]))
+        if in_split[rank]:
+            out[int(out_off[rank]) : int(out_off[rank + 1])].copy_(inp[int(in_off[rank]) : int(in_off[rank + 1])])
+        piece = max(1, self.PIECE // max(1, inp.element_size()))
+        largest = max([n for r, n in enumerate(out_split) if r != rank] + [n for r, n in enumerate(in_split) if r != rank] + [0])
+        reqs = []
+        for j in range((largest + piece - 1) // piece):
+            ops = []
+            for d in range(1, world):           # rank r sends to r+d while it receives from r-d: every pair posts in the same order
+                to, frm = (rank + d) % world, (rank - d) % world
+                lo, hi = j * piece, (j + 1) * piece
+                if lo < in_split[to]:
+                    ops.append(dist.P2POp(dist.isend, inp[int(in_off[to]) + lo : int(in_off[to]) + min(hi, in_split[to])],
+                                          self._peer(to), self.group))
+                if lo < out_split[frm]:
+                    ops.append(dist.P2POp(dist.irecv, out[int(out_off[frm]) + lo : int(out_off[frm]) + min(hi, out_split[frm])],
+                                          self._peer(frm), self.group))
+            if ops:
+                reqs += dist.batch_isend_irecv(ops)
+        return reqs
+
+    def _peer(self, r):
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
     def all_to_all_single(self, out, inp, out_split, in_split):
-        try:
-            self.dist.all_to_all_single(out, inp, out_split, in_split, group=self.group)
-        except RuntimeError:
-            # a backend without all-to-all (some gloo builds): pairwise send/recv, same result
-            world, rank = self.world, self.rank
-            outs = list(out.split(out_split)) if out_split is not None else list(out.chunk(world))
-            ins = list(inp.split(in_split)) if in_split is not None else list(inp.chunk(world))
-            outs[rank].copy_(ins[rank])
-            reqs = []
-            for peer in range(world):
-                if peer == rank:
-                    continue
-                if ins[peer].numel():
-                    reqs.append(self.dist.isend(ins[peer].contiguous(), peer, group=self.group))
-                if outs[peer].numel():
-                    reqs.append(self.dist.irecv(outs[peer], peer, group=self.group))
-            for r in reqs:
-                r.wait()
+        for r in self._start(out, inp, out_split, in_split):
+            r.wait()
 
     def all_to_all_single_async(self, out, inp, out_split, in_split):
-        """The same collective, left running: returns a work handle (None if it had to be done on the spot)."""
-        try:
-            return self.dist.all_to_all_single(out, inp, out_split, in_split, group=self.group, async_op=True)
-        except RuntimeError:
-            self.all_to_all_single(out, inp, out_split, in_split)
-            return None
+        """The same exchange, left running: returns a handle whose wait() ends it."""
+        reqs = self._start(out, inp, out_split, in_split)
+
+        class _Pending:
+            def wait(self_inner):
+                for r in reqs:
+                    r.wait()
+        return _Pending()
 
     def all_reduce_sum(self, value: int, device):
         t = torch.tensor([value], dtype=torch.int64, device=device)
@@ -231,6 +263,8 @@ class DistDfk(Dfk):
             if p + 1 < n_pass:
                 send, counts = self.partition(world, n_global, log2_passes, p + 1)
                 token = exchange_begin(send, counts, 32, comm, self.recv_buffer)
+                if os.environ.get("DFK_SHARD_SERIAL"):                          # debugging aid: no transfer under the count
+                    token = (*exchange_end(token), None, None)
             self.count_records(recv, p)
             del recv
             if token is not None:

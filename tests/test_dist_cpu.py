@@ -13,13 +13,15 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, piece):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from superplus_amd.dist import TorchComm, exchange
         comm = TorchComm()
+        if piece:
+            comm.PIECE = piece                              # slices of up to 49 units of 32 bytes: several rounds each
         rng = np.random.default_rng(100 + rank)
         # records: 32-byte units; unit r->d carries (src, dst, serial) so the receiver can check routing
         counts = [int(rng.integers(0, 50)) for _ in range(world)]
@@ -64,12 +66,14 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_exchange_routing_gloo(world):
+@pytest.mark.parametrize("world,piece", [(2, 0), (4, 0), (2, 96), (3, 40)])
+def test_exchange_routing_gloo(world, piece):
+    """piece: the largest point-to-point message in bytes (0 = the default, 1 GiB); the small values split every
+    slice over several rounds, with a different number of rounds for every pair of ranks."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + int(np.random.default_rng().integers(0, 2000))
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, piece)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
