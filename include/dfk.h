@@ -138,6 +138,13 @@ int dfk_solid_fetch(dfk_ctx* ctx, dfk_entry32* out, uint64_t cap, int pre_adjace
  * inserts them into its own dictionary needs -- the reference's kmers.kvec is in thread-arrival order too. */
 int dfk_solid_fetch_unsorted(dfk_ctx* ctx, dfk_entry32* out, uint64_t cap, int pre_adjacency);
 
+/* Order-independent digest of the same entries, computed on the device: digest[0] = sum over entries of h(entry)
+ * mod 2^64, digest[1] = xor of h'(entry), h = a 64-bit mix of the entry's 32 bytes (k_digest in dfk_kernels.h;
+ * tests/util.py has the numpy form).  Replaces nothing in the reference: it is how two dictionaries of billions
+ * of entries are compared without fetching them (pass geometries, single GPU against sharded: digests of the
+ * ranks' disjoint shares add / xor). */
+int dfk_solid_digest(dfk_ctx* ctx, int pre_adjacency, uint64_t* digest /* [2] */);
+
 /* kmers.kvec image ("BINWRITE" | u64 n | n x 32-B entries; BuildReadQGraph48.cc:287-288,
  * feudal/BinaryStream.h:33-46) written straight to a file. */
 int dfk_write_kvec(dfk_ctx* ctx, const char* path, int pre_adjacency);

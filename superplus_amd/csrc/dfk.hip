@@ -1392,6 +1392,27 @@ int dfk_solid_fetch_unsorted(dfk_ctx* c, dfk_entry32* out, uint64_t cap, int pre
     return 0;
 }
 
+int dfk_solid_digest(dfk_ctx* c, int pre, uint64_t* digest)
+{
+    if (!c || !digest) return fail(DFK_E_ARG, "null argument");
+    if (!c->have) return fail(DFK_E_STATE, "no completed count");
+    if (pre && !(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf d; int rc = c->alloc(d, 16, "digest"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d.p, 0, 16, c->stream));
+    for (const dfk_ctx::Part& pt : c->parts) {
+        const DevBuf& src = pre ? pt.pre : pt.buf;
+        if (!pt.n) continue;
+        const unsigned grid = (unsigned)std::min<uint64_t>((pt.n + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_digest, dim3(grid), dim3(256), 0, c->stream, (const uint4*)src.p, (uint64_t)pt.n, (unsigned long long*)d.p);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(digest, d.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->release(d);
+    return 0;
+}
+
 int dfk_write_kvec(dfk_ctx* c, const char* path, int pre)
 {
     if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");

@@ -1244,6 +1244,33 @@ k_fill_holes(uint4* __restrict__ out, const uint64_t* __restrict__ src, const ui
     out[2 * dst[i] + 1] = out[2 * src[i] + 1];
 }
 
+// Order-independent digest of a run of dictionary entries: digest[0] += sum of h(entry), digest[1] ^= xor of
+// h'(entry), h = a 64-bit mix of all 32 bytes.  For checking at sizes where the entries cannot be compared one
+// by one (the same dictionary through different pass geometries, single GPU against sharded): digests of
+// disjoint sets add / xor.  tests/util.py computes the same value in numpy from the oracle's entries.
+__device__ __forceinline__ uint64_t digest_mix(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(256)
+k_digest(const uint4* __restrict__ entries, uint64_t n, unsigned long long* __restrict__ digest)
+{
+    uint64_t sum = 0, xr = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 a = entries[2 * i], b = entries[2 * i + 1];
+        const uint64_t w0 = a.x | ((uint64_t)a.y << 32), w1 = a.z | ((uint64_t)a.w << 32);
+        const uint64_t w2 = b.x | ((uint64_t)b.y << 32), w3 = b.z | ((uint64_t)b.w << 32);
+        const uint64_t h = digest_mix(w0 ^ digest_mix(w1 ^ digest_mix(w2 ^ digest_mix(w3 + 0x9E3779B97F4A7C15ull))));
+        sum += h; xr ^= digest_mix(h + 0xD1B54A32D192ED03ull);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d, 64); xr ^= __shfl_down(xr, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&digest[0], sum); atomicXor(&digest[1], xr); }
+}
+
 // ============================================================================ a6: adjacency clean-up
 // KmerDict::recomputeAdjacencies (ReadPather.h:329-364): a context bit survives only if the
 // neighbouring canonical k-mer is itself solid.  The solid set is put in an HBM open-addressing

@@ -21,7 +21,7 @@ ENTRY_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("edge_id", "<u4"), ("coun
 
 EXPORTS = [
     "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_device",
-    "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted",
+    "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
     "dfk_write_kvec", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply",
 ]
@@ -162,6 +162,12 @@ class Dfk:
         out = np.zeros(n, dtype=ENTRY_DTYPE)
         _check(lib().dfk_solid_fetch_unsorted(self._ctx, _p(out), C.c_uint64(n), C.c_int(1 if pre_adjacency else 0)))
         return out
+
+    def digest(self, pre_adjacency=False):
+        """(sum, xor) digest of the dictionary entries, order-independent (dfk_solid_digest)."""
+        out = (C.c_uint64 * 2)()
+        _check(lib().dfk_solid_digest(self._ctx, C.c_int(1 if pre_adjacency else 0), out))
+        return int(out[0]), int(out[1])
 
     def write_kvec(self, path, pre_adjacency=False):
         _check(lib().dfk_write_kvec(self._ctx, path.encode(), C.c_int(1 if pre_adjacency else 0)))
