@@ -85,9 +85,18 @@ class TorchComm:
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # gloo moves host memory only: device buffers are staged through the host (the two-process GPU test; a
+        # real run uses nccl)
+        self.staged = dist.get_backend(group) == "gloo"
 
     def _start(self, out, inp, out_split, in_split):
         """Start the exchange; returns the requests still in flight."""
+        if self.staged and inp.is_cuda:
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            for r in self._start(h_out, inp.cpu(), out_split, in_split):
+                r.wait()
+            out.copy_(h_out)
+            return []
         world, rank, dist = self.world, self.rank, self.dist
         if out_split is None:
             out_split = [out.numel() // world] * world
@@ -137,12 +146,12 @@ class TorchComm:
         return _Pending()
 
     def all_reduce_sum(self, value: int, device):
-        t = torch.tensor([value], dtype=torch.int64, device=device)
+        t = torch.tensor([value], dtype=torch.int64, device="cpu" if self.staged else device)
         self.dist.all_reduce(t, group=self.group)
         return int(t.item())
 
     def all_reduce_max(self, value: int, device):
-        t = torch.tensor([value], dtype=torch.int64, device=device)
+        t = torch.tensor([value], dtype=torch.int64, device="cpu" if self.staged else device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 

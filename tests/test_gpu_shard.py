@@ -85,3 +85,52 @@ def test_rccl_path_single_rank(oracle):
         assert np.array_equal(d.spectrum(), ref["hist"])
     finally:
         dist.destroy_process_group()
+
+
+def _rank_main(rank, world, port, shard, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from superplus_amd.dist import DistDfk
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        t = [torch.from_numpy(x).to(dev) for x in shard[:6]]
+        d = DistDfk(K=48, device=0, passes=2, hbm_budget_bytes=8 << 30)
+        d.count_device(*t, read_id0=shard[6])
+        q.put((rank, "ok", d.solid(), np.asarray(d.spectrum()), d.good_lens(), d.stats()["n_inst_global"]))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc(), None, None, None, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_process_per_rank(oracle, world):
+    """DistDfk.count_device as bench.py runs it -- one process per rank, a torch.distributed group, TorchComm's
+    point-to-point rounds, the pipelined passes -- with the ranks sharing this GPU and gloo as the transport
+    (RCCL does not put two ranks on one device; TorchComm stages device buffers through the host for gloo)."""
+    import torch.multiprocessing as mp
+    rs = util.make_set(77, 300000, 20000)
+    ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
+    shards = [tuple(x.cpu().numpy() if torch.is_tensor(x) else x for x in sh) for sh in _shards(rs, world, "cpu")]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + int(np.random.default_rng().integers(0, 200))
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, shards[r], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    allk = np.concatenate([r[2] for r in res])
+    util.assert_same_solid(allk[np.lexsort((allk["w1"], allk["w0"]))], ref["solid"], "one process per rank")
+    n = max(len(r[3]) for r in res)
+    hist = sum(np.pad(r[3], (0, n - len(r[3]))) for r in res)
+    assert np.array_equal(hist, ref["hist"])
+    assert np.array_equal(np.concatenate([r[4] for r in res]), ref["good_len"])
+    assert all(r[5] == ref["n_inst"] for r in res)
