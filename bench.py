@@ -119,6 +119,10 @@ def main():
                     help="plant this many diverged copies of one 300-bp element in the genome (hot minimizer buckets)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (torch.distributed + DistDfk) even with one rank: a check of that path on one GPU")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; gloo (with --one-device) rehearses the multi-rank launch on one GPU")
+    ap.add_argument("--hbm-budget-gb", type=float, default=0.0, help="HBM the library may use (0 = 90 %% of what is free)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="rehearsal on one GPU: run rank 0 of this many ranks against replicas of itself (not a benchmark result)")
     args = ap.parse_args()
@@ -130,6 +134,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libdfk has no CPU path")
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     multi = world > 1 or args.force_dist
@@ -137,9 +143,17 @@ def main():
         import torch.distributed as dist
         if "RANK" not in os.environ:                 # --force-dist without a launcher
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
+            dist.init_process_group(args.backend, rank=0, world_size=1, device_id=dev)
+        elif args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where the bench's own small collectives live
+
+        def allreduce(value, dtype, op):
+            t = torch.tensor([value], dtype=dtype, device=cdev)
+            dist.all_reduce(t, op=op)
+            return t.item()
 
     G = int(args.genome_mb * 1e6)
     total_pairs = int(args.coverage * G / 200.0) if args.coverage > 0 else args.pairs
@@ -150,28 +164,29 @@ def main():
     rs = synth.make_reads(genome, hi - lo, 20261004 + 17 * (rank + 1))
     del genome
     if multi:          # barcode ids must not collide between ranks
-        stride = int(rs.bc.max().item()) + 1
-        st = torch.tensor([stride], dtype=torch.int64, device=dev)
-        dist.all_reduce(st, op=dist.ReduceOp.MAX)
-        rs.bc = torch.where(rs.bc > 0, rs.bc + rank * int(st.item()), rs.bc)
+        stride = int(allreduce(int(rs.bc.max().item()) + 1, torch.int64, dist.ReduceOp.MAX))
+        rs.bc = torch.where(rs.bc > 0, rs.bc + rank * stride, rs.bc)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()          # the library sizes its HBM budget from what is free when the context is created
 
     if args.emulate_world > 1:
         from superplus_amd.dist import DistDfk, ReplicaComm
         d = DistDfk(comm=ReplicaComm(args.emulate_world), K=args.K, device=local, minimizer_len=args.minimizer,
-                    inst_per_item=args.inst_per_item, passes=args.passes)
+                    inst_per_item=args.inst_per_item, passes=args.passes,
+                    hbm_budget_bytes=int(args.hbm_budget_gb * 1e9))
         def step():
             d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc, read_id0=0)
             return d.stats()
     elif not multi:
-        d = Dfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes)
+        d = Dfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes,
+                    hbm_budget_bytes=int(args.hbm_budget_gb * 1e9))
         def step():
             d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc)
             return d.stats()
     else:
         from superplus_amd.dist import DistDfk
-        d = DistDfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes)
+        d = DistDfk(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes,
+                    hbm_budget_bytes=int(args.hbm_budget_gb * 1e9))
         def step():
             d.count_device(rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc, read_id0=2 * lo)
             return d.stats()
@@ -192,12 +207,8 @@ def main():
     elapsed = time.perf_counter() - t0
     n_inst = st["n_inst"]
     if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([n_inst], dtype=torch.int64, device=dev)
-        dist.all_reduce(c)
-        n_inst = int(c.item())
+        elapsed = float(allreduce(elapsed, torch.float64, dist.ReduceOp.MAX))
+        n_inst = int(allreduce(n_inst, torch.int64, dist.ReduceOp.SUM))
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
