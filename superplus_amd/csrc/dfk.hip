@@ -309,6 +309,7 @@ struct BucketTable {
     uint32_t log2_nb = 0;                 // global
     DevBuf acc;                           // u64[nb] records<<32 | instances, global numbering
     DevBuf summ;                          // uint4[n_reads]: run summaries (k_partition<K,false>), what the scatter passes work from
+    DevBuf classes;                       // u32[n_reads]: coarse classes of each read's buckets (the sweeps' prefilter)
     DevBuf ovf_list; uint64_t n_ovf = 0;  // reads with too many runs for a summary: scattered by scanning
     DevBuf class_hist;                    // sharded runs: u64[2][world * PART_CLASSES] records | instances per owner and class (no per-bucket counters)
     std::vector<uint64_t> h_class;        //   ... and its host copy
@@ -324,7 +325,8 @@ template <int K>
 PartParams part_params(const dfk_ctx* c, uint32_t log2_nb, uint32_t log2_world, int64_t read_id0, uint32_t sub_lo, uint32_t sub_n)
 {
     const uint32_t M = c->cfg.minimizer_len;
-    return PartParams{M, (uint32_t)K - M + 1, log2_nb, log2_world, read_id0, sub_lo, sub_n};
+    return PartParams{M, (uint32_t)K - M + 1, log2_nb, log2_world, read_id0, sub_lo, sub_n,
+                      sweep_class_mask(sub_lo, sub_n, log2_nb - log2_world)};
 }
 
 // totals of a counter table (records, instances)
@@ -352,6 +354,7 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     if (by_class) { rc = c->alloc(T->class_hist, n_bins * 8, "class counters", true); if (rc) return rc; HIP_TRY(hipMemsetAsync(T->class_hist.p, 0, n_bins * 8, c->stream)); }
     else { rc = c->alloc(T->acc, nb * 8, "bucket counters", true); if (rc) return rc; }
     rc = c->alloc(T->summ, std::max<uint64_t>(1, in.n_reads) * 16, "run summaries", true); if (rc) return rc;
+    if (!by_class) { rc = c->alloc(T->classes, std::max<uint64_t>(1, in.n_reads) * 4, "read bucket classes", true); if (rc) return rc; }
     if (!by_class) HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
     unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
     static const unsigned scan_blocks = getenv("DFK_SCAN_BLOCKS") ? (unsigned)atoi(getenv("DFK_SCAN_BLOCKS")) : 0;
@@ -365,7 +368,7 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p,
                            (unsigned long long*)nullptr, (uint64_t)0, (uint4*)nullptr, (uint4*)T->summ.p,
-                           (const uint32_t*)nullptr, (uint64_t)0, (const uint64_t*)nullptr);
+                           (const uint32_t*)nullptr, (uint64_t)0, (const uint64_t*)nullptr, (uint32_t*)T->classes.p);
     HIP_TRY(hipGetLastError());
     // reads whose runs did not fit a summary
     T->n_ovf = 0;
@@ -478,9 +481,10 @@ int scatter_begin(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t l
     if (!J->e0) { HIP_TRY(hipEventCreate(&J->e0)); HIP_TRY(hipEventCreate(&J->e1)); }
     HIP_TRY(hipEventRecord(J->e0, c->stream));
     if (in.n_reads)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 256ull * SWEEP_READS - 1) / (256ull * SWEEP_READS))),
+                           dim3(256), 0, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
-                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p,
+                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p, (const uint32_t*)T.classes.p,
                            (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(J->e1, c->stream));
@@ -508,7 +512,7 @@ int scatter_end(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log
                                in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                                (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
                                (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p, (uint4*)nullptr,
-                               (const uint32_t*)T.ovf_list.p, T.n_ovf, (const uint64_t*)nullptr);
+                               (const uint32_t*)T.ovf_list.p, T.n_ovf, (const uint64_t*)nullptr, (uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)((P->nb + 255) / 256)), dim3(256), 0, c->stream, (const unsigned long long*)J->cur.p,
                            (const uint64_t*)P->base.p, P->nb, (unsigned int*)J->d_bad.p);
@@ -1022,6 +1026,9 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
         fit = std::min(fit, std::max(0.0, room + (double)running->bytes_held - fixed) / (2.0 * (per_in + per_seg) + (per_out - per_seg)));
     }
     double n = c->plan_derate * fit;
+    // the range is scattered while the running pass is counted: no larger than what that count hides (a sweep
+    // moves a range's records about 1.5 times as fast as k_count counts them, after ~10 ms of reading masks)
+    if (running && overlap) n = std::min(n, 1.3 * (double)running->n_buckets);
     if (left <= 0.99 * fit && left < 1.06 * n) n = left;              // no sliver of a last pass if the rest (almost certainly) fits
     else if (left > n && left < 1.3 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big and a small one
     n = std::min(n, left);
@@ -1151,7 +1158,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         if (nxt.valid) { cur = nxt; nxt = Job{}; }
         else { cur = Job{}; if (nlo < sub_nb) { rc = start_alone(cur, nlo); if (rc) return rc; } }
     }
-    c->release(T.acc); c->release(T.summ); c->release(T.ovf_list); c->release(T.class_hist);
+    c->release(T.acc); c->release(T.summ); c->release(T.classes); c->release(T.ovf_list); c->release(T.class_hist);
     c->st.reserved[0] = n_passes;
     rc = count_run_end(c, &R); if (rc) return rc;
     rc = stage_adjacency<K>(c); if (rc) return rc;

@@ -99,7 +99,23 @@ struct PartParams {
     int64_t  read_id0;     // global index of this shard's first read (ignBcBelow compares global read ids)
     uint32_t sub_lo;       // pass: fine buckets whose rank-local id (global id without the owner bits) is in
     uint32_t sub_n;        // [sub_lo, sub_lo + sub_n); numbered owner * sub_n + (id - sub_lo) inside the pass
+    uint32_t class_mask;   // the SWEEP_CLASSES-ths of an owner's bucket space that [sub_lo, sub_lo + sub_n) touches (bit per class)
 };
+
+// The counting scan leaves, per read, a bit mask of the coarse classes its runs' buckets fall in (32 equal
+// ranges of an owner's bucket space).  A scatter sweep tests it against the classes its pass touches and does
+// not look at the other reads at all: a read has ~4 runs, so a pass over 1/8 of the buckets needs ~45 % of the
+// reads, one over 1/32 of them 11 %.
+constexpr uint32_t SWEEP_CLASSES = 32;
+__host__ __device__ inline uint32_t sweep_class_of(uint32_t local_bucket, uint32_t log2_local)
+{ return log2_local > 5 ? local_bucket >> (log2_local - 5) : local_bucket; }
+__host__ __device__ inline uint32_t sweep_class_mask(uint32_t sub_lo, uint32_t sub_n, uint32_t log2_local)
+{
+    if (sub_n == 0) return 0u;
+    const uint32_t a = sweep_class_of(sub_lo, log2_local), b = sweep_class_of(sub_lo + sub_n - 1, log2_local);
+    const uint32_t upto_b = b >= 31 ? 0xFFFFFFFFu : ((1u << (b + 1)) - 1u);
+    return upto_b & ~((1u << a) - 1u);
+}
 
 constexpr int PART_THREADS = 128;
 constexpr int PART_RING = 8;          // words of its read a lane of the counting scan keeps staged in LDS
@@ -180,7 +196,7 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
             uint64_t n_reads, const PartParams& pp,
             unsigned long long* __restrict__ bucket_acc, unsigned long long* __restrict__ bucket_cur, uint64_t n_out,
             uint4* __restrict__ records, uint4* __restrict__ summaries, const uint32_t* __restrict__ read_list, uint64_t n_list,
-            const uint64_t* __restrict__ slice_base)
+            const uint64_t* __restrict__ slice_base, uint32_t* __restrict__ read_classes)
 {
     // where a record of pass-local bucket b goes: its bucket's cursor, or (sharded) its owner's slice
     auto place = [&](uint32_t b) -> uint64_t {
@@ -198,8 +214,13 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
     if (WRITE && read_list) { if (r >= n_list) return; r = read_list[r]; }
     const uint32_t M = pp.M, W = pp.W;
     const uint32_t gl = r < n_reads ? good_len[r] : 0;
-    if (gl < (uint32_t)K + 1) { if (!WRITE && r < n_reads) summaries[r] = uint4{0, 0, 0, 0}; return; }   // Kmerizer::map: len < K+1 emits nothing (:153)
+    if (gl < (uint32_t)K + 1) {                                  // Kmerizer::map: len < K+1 emits nothing (:153)
+        if (!WRITE && r < n_reads) { summaries[r] = uint4{0, 0, 0, 0}; if (read_classes) read_classes[r] = 0u; }
+        return;
+    }
     uint32_t Pi = 0, cur_rel = 0;                                // !WRITE: where the prefix minimum sits; minimizer offset of the open run
+    uint32_t cmask = 0;                                          // !WRITE: classes of the runs' buckets (the sweeps' prefilter)
+    const uint32_t log2_local = pp.log2_nb - pp.log2_world;
 
     const uint64_t byte0 = base_off[r];
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);   // hipMalloc'd: 4-byte aligned base
@@ -243,6 +264,7 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
         if (!WRITE) {
             if (lh) { const uint32_t bin = class_bin(cur_b, pp); atomicAdd(&lh[bin], 1u); atomicAdd(&lh[(PART_CLASSES << pp.log2_world) + bin], cur_nk); }
             else atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
+            cmask |= 1u << sweep_class_of(cur_b & ((1u << log2_local) - 1u), log2_local);
             if (qn < (uint32_t)SUMMARY_RUNS) rq[qn * PART_THREADS + tid] = (uint16_t)(cur_nk | (cur_rel << 6));
             ++qn;
         } else {
@@ -333,6 +355,7 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
             else { lo |= fld << b; hi |= fld >> (64 - b); }
         }
         summaries[r] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+        if (read_classes) read_classes[r] = cmask;
     }
     if (WRITE) {
         for (uint32_t e = 0; e < qn; ++e) {
@@ -356,7 +379,8 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
             uint4* __restrict__ summaries,                    // !WRITE: per read, its runs (see SUMMARY_RUNS)
             const uint32_t* __restrict__ read_list,           // WRITE (optional): the reads to process
             uint64_t n_list,
-            const uint64_t* __restrict__ slice_base)          // WRITE, sharded: records go to owner slices; bucket_cur = fill of each slice
+            const uint64_t* __restrict__ slice_base,          // WRITE, sharded: records go to owner slices; bucket_cur = fill of each slice
+            uint32_t* __restrict__ read_classes)              // !WRITE: per read, the classes of its runs' buckets (sweep_class_of)
 {
     extern __shared__ uint32_t smem[];
     // class counts are gathered in LDS by a grid-stride launch (a few thousand blocks) and flushed once per
@@ -371,7 +395,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     const uint64_t n_work = (WRITE && read_list) ? n_list : n_reads;
     for (uint64_t r0 = (uint64_t)blockIdx.x * PART_THREADS; r0 < n_work; r0 += (uint64_t)gridDim.x * PART_THREADS)
         partition_read<K, WRITE>(r0 + threadIdx.x, smem, lh, packed, packed_bytes, base_off, good_len, bc, ign_bc_below, n_reads, pp,
-                                 bucket_acc, bucket_cur, n_out, records, summaries, read_list, n_list, slice_base);
+                                 bucket_acc, bucket_cur, n_out, records, summaries, read_list, n_list, slice_base, read_classes);
     if (lh) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n_bins; i += PART_THREADS) if (lh[i]) atomicAdd(&class_hist[i], (unsigned long long)lh[i]);
@@ -468,26 +492,51 @@ k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, cons
 // run's bucket from the minimizer the summary points at (2M bits of the read, no scan), and writes the
 // records of the runs that belong to this pass.  The cursors start at the buckets' first record indices;
 // afterwards cursor[b] must equal base[b+1] (k_check_cursors).
+constexpr int SWEEP_READS = 8;            // reads per thread of a k_scatter_runs block
 template <int K>
 __global__ void __launch_bounds__(256)
 k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
                const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
-               uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries,
+               uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries, const uint32_t* __restrict__ read_classes,
                unsigned long long* __restrict__ bucket_cur, uint64_t n_out, uint4* __restrict__ records)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_reads) return;
+    // A block owns 256 * SWEEP_READS consecutive reads.  First the class masks (4 bytes per read, coalesced)
+    // pick the reads that can have a run in this pass; their indices are packed into an LDS list, which the
+    // threads then work through densely (lanes whose read is not in the pass would otherwise idle through the
+    // latency chain summary -> bases -> cursor -> record of their neighbours).
+    __shared__ uint16_t list[256 * SWEEP_READS];
+    __shared__ uint32_t n_list;
     (void)good_len;
+    const int lane = threadIdx.x & 63;
+    const uint64_t r_block = (uint64_t)blockIdx.x * 256 * SWEEP_READS;
+    if (threadIdx.x == 0) n_list = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SWEEP_READS; ++j) {
+        const uint32_t rel = 256u * j + threadIdx.x;
+        const uint64_t r = r_block + rel;
+        const bool hit = r < n_reads && (read_classes[r] & pp.class_mask) != 0u;
+        const unsigned long long mk = __ballot(hit);
+        uint32_t at = 0;
+        if (lane == 0 && mk) at = atomicAdd(&n_list, (uint32_t)__popcll(mk));
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (hit) list[at + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)rel;
+    }
+    __syncthreads();
+    const uint32_t n = n_list;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
     const uint64_t n_words = (packed_bytes + 3) >> 2;
-    int32_t tag = -1;
-    if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
-    for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
-        [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t, uint64_t bit0, bool last) {
-            const uint64_t dst = atomicAdd(&bucket_cur[lb], 1ull);             // one random access for base and rank
-            // only the read's last run has no successor base (its last k-mer ends the trimmed read)
-            if (dst < n_out) emit_record<K>(words, n_words, bit0, s0, nk, lb, last ? 0u : 0xFFFFFFFFu, tag, dst, records);
-        });
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint64_t r = r_block + list[i];
+        int32_t tag = -1;
+        if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
+        for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
+            [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t, uint64_t bit0, bool last) {
+                const uint64_t dst = atomicAdd(&bucket_cur[lb], 1ull);             // one random access for base and rank
+                // only the read's last run has no successor base (its last k-mer ends the trimmed read)
+                if (dst < n_out) emit_record<K>(words, n_words, bit0, s0, nk, lb, last ? 0u : 0xFFFFFFFFu, tag, dst, records);
+            });
+    }
 }
 
 // ============================================================================ a2 (second half) + a3 + a4 + a5: count

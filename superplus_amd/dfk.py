@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfk.so")
+LIB_PATH = os.environ.get("DFK_LIB") or os.path.join(_HERE, "libdfk.so")      # DFK_LIB: a developer's timing variant (tools/)
 ABI_VERSION = 1
 F_KEEP_PRE_ADJ = 1
 
