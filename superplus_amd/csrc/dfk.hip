@@ -72,7 +72,10 @@ struct dfk_ctx {
     bool have = false;
     uint64_t n_reads = 0;
     DevBuf good_len;                          // u32[n_reads]
-    struct Part { DevBuf buf, pre; uint64_t n = 0; };   // dfk_entry32[n]: one per pass
+    // dfk_entry32[n], one part per pass.  blist != 0: behind the entries, in the same buffer, 16 bytes of counters
+    // and the indices of the n_blist entries that still have unresolved context bits (k_boundary_list)
+    struct Part { DevBuf buf, pre; uint64_t n = 0; uint64_t blist = 0, n_blist = 0; bool listed = false; };   // listed: n_blist is all of them
+    bool want_blist = false;                  // single-GPU runs: list each part's boundary entries while the next pass is counted
     std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
     unsigned seg_attempt = 0;                 // the room for a pass's solid k-mers is (estimate << seg_attempt)
@@ -540,6 +543,7 @@ struct CountRun {                     // device state shared by the count launch
     DevBuf d_part;                     // room reserved for the dense part of the pass being counted (count_prepare .. count_run)
     DevBuf d_wg;                       // WgOut of every persistent workgroup
     uint64_t solid_seen = 0, inst_seen = 0;   // totals of the passes done so far (sizes the next pass's output)
+    uint64_t boundary_seen = 0;               // entries with unresolved context bits emitted by the passes done so far
 };
 
 int count_run_begin(dfk_ctx* c, CountRun* R)
@@ -849,7 +853,22 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
         HIP_TRY(hipMemcpyAsync((char*)part.buf.p + 32 * n_lds, R.big.p, 32 * hg.big_cursor, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->release(R.big);
-    c->shrink(part.buf, part.n * 32);
+    // the part's boundary list goes behind its entries if the reservation has the room (it almost always has:
+    // 4 bytes for one entry in eight); it is filled on the second stream while the next pass is counted
+    const uint64_t nb_part = hg.n_boundary - R.boundary_seen;
+    R.boundary_seen = hg.n_boundary;
+    uint64_t keep = part.n * 32;
+    part.listed = c->want_blist && nb_part == 0;
+    if (c->want_blist && nb_part && keep + 16 + 4 * nb_part <= part.buf.bytes && part.n < (1ull << 32)) {
+        part.blist = keep; part.n_blist = nb_part; part.listed = true;
+        keep += 16 + 4 * nb_part;
+        unsigned long long* ctl = (unsigned long long*)((char*)part.buf.p + part.blist);
+        HIP_TRY(hipMemsetAsync(ctl, 0, 16, c->stream2));
+        hipLaunchKernelGGL(k_boundary_list, dim3((unsigned)std::min<uint64_t>((part.n + 2047) / 2048, 4096)), dim3(256), 0, c->stream2,
+                           (const uint4*)part.buf.p, part.n, (uint32_t*)(ctl + 2), nb_part, ctl);
+        HIP_TRY(hipGetLastError());
+    }
+    c->shrink(part.buf, keep);
     c->parts.push_back(part);
     c->n_solid += part.n; c->st.n_solid = c->n_solid;
     R.solid_seen += part.n; R.inst_seen += P.n_inst;
@@ -911,13 +930,49 @@ int stage_adjacency(dfk_ctx* c)
     t.start();
     int rc = make_pre_view(c); if (rc) return rc;
     if (c->cfg.min_freq > 1 && c->n_solid && c->n_boundary) {          // BuildReadQGraph48.cc:313
-        rc = build_set(c); if (rc) return rc;
+        // every part listed its boundary entries (k_boundary_list, second stream)?  Then the set is built and
+        // queried from the lists; otherwise by streaming the parts.
+        bool listed = c->want_blist;
+        for (const dfk_ctx::Part& pt : c->parts) listed = listed && pt.listed;
+        if (listed) {
+            HIP_TRY(hipStreamSynchronize(c->stream2));
+            uint64_t total = 0;
+            for (const dfk_ctx::Part& pt : c->parts) {
+                if (!pt.blist) continue;
+                unsigned long long ctl[2] = {0, 0};
+                HIP_TRY(hipMemcpy(ctl, (const char*)pt.buf.p + pt.blist, 16, hipMemcpyDeviceToHost));
+                if (ctl[1] || ctl[0] != pt.n_blist)
+                    return fail(DFK_E_HIP, "boundary list: %llu entries listed, the count kernels reported %llu", ctl[0], (unsigned long long)pt.n_blist);
+                total += pt.n_blist;
+            }
+            // (parts without unresolved bits have no list; the total must be the run's)
+            if (total != c->n_boundary) listed = false;
+        }
+        if (!listed) { rc = build_set(c); if (rc) return rc; }
+        else {
+            uint64_t slots = 1ull << std::max<uint32_t>(10, ceil_log2(2 * c->n_boundary + 2));
+            rc = c->alloc(c->set, slots * sizeof(SetSlot), "boundary k-mer set"); if (rc) return rc;
+            c->set_mask = slots - 1;
+            hipLaunchKernelGGL(k_fill_u64, dim3(2048), dim3(256), 0, c->stream, (uint64_t*)c->set.p, slots * 2, ~0ull);
+            for (const dfk_ctx::Part& pt : c->parts)
+                if (pt.n_blist)
+                    hipLaunchKernelGGL(k_set_insert_list, dim3((unsigned)((pt.n_blist + 255) / 256)), dim3(256), 0, c->stream, (const uint4*)pt.buf.p,
+                                       (const uint32_t*)((const char*)pt.buf.p + pt.blist + 16), pt.n_blist, (SetSlot*)c->set.p, c->set_mask);
+            HIP_TRY(hipGetLastError());
+        }
         DevBuf d_n; rc = c->alloc(d_n, 16, "probe counter"); if (rc) return rc;
         HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
-        for (const dfk_ctx::Part& pt : c->parts)
-            if (pt.n)
+        for (const dfk_ctx::Part& pt : c->parts) {
+            if (!pt.n) continue;
+            if (listed) {
+                if (pt.n_blist)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adjacency_list<K>), dim3((unsigned)std::min<uint64_t>((pt.n_blist + 255) / 256, 16384)), dim3(256), 0,
+                                       c->stream, (uint4*)pt.buf.p, (const uint32_t*)((const char*)pt.buf.p + pt.blist + 16), pt.n_blist,
+                                       (const SetSlot*)c->set.p, c->set_mask, (unsigned long long*)d_n.p);
+            } else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adjacency<K>), dim3((unsigned)std::min<uint64_t>((pt.n + 255) / 256, 8192)), dim3(256), 0,
                                    c->stream, (uint4*)pt.buf.p, pt.n, (const SetSlot*)c->set.p, c->set_mask, (unsigned long long*)d_n.p);
+        }
         HIP_TRY(hipGetLastError());
         uint64_t np = 0;
         HIP_TRY(hipMemcpyAsync(&np, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1059,6 +1114,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
     CountRun R;
     rc = count_run_begin(c, &R); if (rc) return rc;
+    c->want_blist = true;
     // Passes over contiguous ranges of the fine buckets, each as large as the free HBM allows.  While a pass is
     // counted (LDS- and issue-bound) the next range is scattered on a second, low-priority stream (bound by
     // scattered atomics and stores): the two kernels share the CUs.  A pass that runs out of room (its estimate

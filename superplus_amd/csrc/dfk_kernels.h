@@ -1361,6 +1361,59 @@ __device__ __forceinline__ bool set_has(const SetSlot* __restrict__ set, uint64_
     }
 }
 
+// The entries of a part that still have unresolved context bits (pad byte 0), as a dense list of indices: built
+// once per pass while the next pass is counted, so that the set build and the look-ups after the last pass touch
+// those entries only (about one in eight) instead of streaming the whole dictionary twice.
+// ctl[0] = entries listed so far, ctl[1] = set if the list would overflow `cap`.
+constexpr int BLIST_PER_THREAD = 8;
+__global__ void __launch_bounds__(256)
+k_boundary_list(const uint4* __restrict__ entries, uint64_t n, uint32_t* __restrict__ list, uint64_t cap,
+                unsigned long long* __restrict__ ctl)
+{
+    __shared__ uint32_t found[256 * BLIST_PER_THREAD];
+    __shared__ uint32_t n_found;
+    __shared__ unsigned long long at;
+    const int lane = threadIdx.x & 63;
+    const uint64_t per_block = 256ull * BLIST_PER_THREAD;
+    for (uint64_t b0 = (uint64_t)blockIdx.x * per_block; b0 < n; b0 += (uint64_t)gridDim.x * per_block) {
+        if (threadIdx.x == 0) n_found = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < BLIST_PER_THREAD; ++j) {
+            const uint64_t i = b0 + 256ull * j + threadIdx.x;
+            const bool hit = i < n && (entries[2 * i + 1].w & 0xFFu) != 0u;
+            const unsigned long long mk = __ballot(hit);
+            uint32_t w = 0;
+            if (lane == 0 && mk) w = atomicAdd(&n_found, (uint32_t)__popcll(mk));
+            w = __builtin_amdgcn_readfirstlane(w);
+            if (hit) found[w + __popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        }
+        __syncthreads();
+        const uint32_t m = n_found;
+        if (threadIdx.x == 0) at = m ? atomicAdd(&ctl[0], (unsigned long long)m) : 0ull;
+        __syncthreads();
+        const unsigned long long base = at;
+        if (base + m > cap) { if (threadIdx.x == 0) atomicOr(&ctl[1], 1ull); }
+        else for (uint32_t t = threadIdx.x; t < m; t += 256) list[base + t] = found[t];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_set_insert_list(const uint4* __restrict__ entries, const uint32_t* __restrict__ list, uint64_t n, SetSlot* __restrict__ set, uint64_t mask)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint4 a = entries[2 * (uint64_t)list[t]];
+    const uint64_t w0 = (uint64_t)a.x | ((uint64_t)a.y << 32), w1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    uint64_t s = set_hash(w0, w1) & mask;
+    for (;;) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&set[s].w0), ~0ull, (unsigned long long)w0);
+        if (old == ~0ull) { set[s].w1 = w1; return; }
+        s = (s + 1) & mask;
+    }
+}
+
 // canonical left-aligned (w0,w1) of a k-mer given as a 2K-bit big-endian value
 template <int K>
 __device__ __forceinline__ void canon_words(u128 F, uint64_t* w0, uint64_t* w1)
@@ -1375,46 +1428,69 @@ __device__ __forceinline__ void canon_words(u128 F, uint64_t* w0, uint64_t* w1)
     *w0 = kw.hi; *w1 = kw.lo;
 }
 
+// Only the context bits k_count could not settle inside its table (pad byte 0 of the entry) are looked up;
+// the set holds exactly the solid k-mers that have such bits (adjacency is mutual: if X's neighbour Y was
+// counted in another item, then Y's neighbour X was too).  Returns the number of look-ups.
 template <int K>
-__global__ void __launch_bounds__(256)
-k_adjacency(uint4* __restrict__ entries, uint64_t n, const SetSlot* __restrict__ set, uint64_t mask,
-            unsigned long long* __restrict__ n_probes)
+__device__ __forceinline__ uint32_t adjacency_entry(uint4* __restrict__ entries, uint64_t i, const SetSlot* __restrict__ set, uint64_t mask)
 {
-    // Only the context bits k_count could not settle inside its table (pad byte 0 of the entry) are
-    // looked up; the set holds exactly the solid k-mers that have such bits (adjacency is mutual: if
-    // X's neighbour Y was counted in another item, then Y's neighbour X was too).
-    unsigned long long probes = 0;
     const u128 m = KTraits<K>::mask();
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint4 b = entries[2 * i + 1];
-        const uint32_t pending = b.w & 0xFFu;
-        if (!pending) continue;
-        uint4 a = entries[2 * i];
-        u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
-        u128 F = shr128(kw, 128 - KTraits<K>::BITS);                  // 2K-bit big-endian value
-        uint32_t ctx = b.y >> 24;
-        for (uint32_t bit = 0; bit < 8; ++bit) if (pending & (1u << bit)) {
-            u128 v;
-            if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }            // kmer.toSuccessor
-            else {
-                v = shr128(F, 2);                                                                     // kmer.toPredecessor
-                constexpr int TOP = KTraits<K>::BITS - 2;
-                if (TOP >= 64) v.hi |= (uint64_t)(bit - 4) << (TOP - 64); else v.lo |= (uint64_t)(bit - 4) << TOP;
-            }
-            uint64_t w0, w1; canon_words<K>(v, &w0, &w1);
-            ++probes;
-            if (!set_has(set, mask, w0, w1)) ctx &= ~(1u << bit);
+    uint4 b = entries[2 * i + 1];
+    const uint32_t pending = b.w & 0xFFu;
+    if (!pending) return 0;
+    uint4 a = entries[2 * i];
+    u128 kw{(uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)a.x | ((uint64_t)a.y << 32)};
+    u128 F = shr128(kw, 128 - KTraits<K>::BITS);                  // 2K-bit big-endian value
+    uint32_t ctx = b.y >> 24, probes = 0;
+    for (uint32_t bit = 0; bit < 8; ++bit) if (pending & (1u << bit)) {
+        u128 v;
+        if (bit < 4) { v = shl128(F, 2); v.lo &= m.lo; v.hi &= m.hi; v.lo |= bit; }            // kmer.toSuccessor
+        else {
+            v = shr128(F, 2);                                                                     // kmer.toPredecessor
+            constexpr int TOP = KTraits<K>::BITS - 2;
+            if (TOP >= 64) v.hi |= (uint64_t)(bit - 4) << (TOP - 64); else v.lo |= (uint64_t)(bit - 4) << TOP;
         }
-        b.y = (b.y & 0xFFFFFFu) | (ctx << 24);
-        b.w = 0;
-        entries[2 * i + 1] = b;
+        uint64_t w0, w1; canon_words<K>(v, &w0, &w1);
+        ++probes;
+        if (!set_has(set, mask, w0, w1)) ctx &= ~(1u << bit);
     }
+    b.y = (b.y & 0xFFFFFFu) | (ctx << 24);
+    b.w = 0;
+    entries[2 * i + 1] = b;
+    return probes;
+}
+
+__device__ __forceinline__ void add_probes(unsigned long long probes, unsigned long long* __restrict__ n_probes)
+{
     __shared__ unsigned long long sh[4];
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) probes += __shfl_down(probes, d, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = probes;
     __syncthreads();
     if (threadIdx.x == 0 && (sh[0] + sh[1] + sh[2] + sh[3])) atomicAdd(n_probes, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_adjacency(uint4* __restrict__ entries, uint64_t n, const SetSlot* __restrict__ set, uint64_t mask,
+            unsigned long long* __restrict__ n_probes)
+{
+    unsigned long long probes = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        probes += adjacency_entry<K>(entries, i, set, mask);
+    add_probes(probes, n_probes);
+}
+
+// the same over a part's boundary list (k_boundary_list): every lane has an entry to settle
+template <int K>
+__global__ void __launch_bounds__(256)
+k_adjacency_list(uint4* __restrict__ entries, const uint32_t* __restrict__ list, uint64_t n, const SetSlot* __restrict__ set, uint64_t mask,
+                 unsigned long long* __restrict__ n_probes)
+{
+    unsigned long long probes = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x)
+        probes += adjacency_entry<K>(entries, (uint64_t)list[t], set, mask);
+    add_probes(probes, n_probes);
 }
 
 // Test support (DFK_F_KEEP_PRE_ADJ): the kmers.kvec view = entries with their original context byte
