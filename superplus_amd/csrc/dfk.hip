@@ -517,7 +517,7 @@ int scatter_end(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log
                                (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p, (uint4*)nullptr,
                                (const uint32_t*)T.ovf_list.p, T.n_ovf, (const uint64_t*)nullptr, (uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)((P->nb + 255) / 256)), dim3(256), 0, c->stream, (const unsigned long long*)J->cur.p,
+        hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)std::min<uint64_t>((P->nb + 255) / 256, 4096)), dim3(256), 0, c->stream, (const unsigned long long*)J->cur.p,
                            (const uint64_t*)P->base.p, P->nb, (unsigned int*)J->d_bad.p);
         HIP_TRY(hipGetLastError());
         c->st.ms_part_scatter += t.stop();

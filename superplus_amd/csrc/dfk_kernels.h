@@ -1778,9 +1778,10 @@ k_scan_add(uint64_t* __restrict__ out, uint64_t n, const uint64_t* __restrict__ 
 __global__ void __launch_bounds__(256)
 k_check_cursors(const unsigned long long* __restrict__ cur, const uint64_t* __restrict__ base, uint64_t nb, unsigned int* __restrict__ bad)
 {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool wrong = b < nb && cur[b] != base[b + 1];
-    if (__ballot(wrong) && wrong) atomicAdd(bad, 1u);
+    unsigned int wrong = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x)
+        wrong += cur[b] != base[b + 1];
+    if (wrong) atomicAdd(bad, wrong);
 }
 
 // one pass's view of the global counters: local bucket owner * sub_n + d = global bucket (owner << log2_sub) + sub_lo + d
