@@ -484,7 +484,7 @@ int scatter_begin(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t l
     if (!J->e0) { HIP_TRY(hipEventCreate(&J->e0)); HIP_TRY(hipEventCreate(&J->e1)); }
     HIP_TRY(hipEventRecord(J->e0, c->stream));
     if (in.n_reads)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 256ull * SWEEP_READS - 1) / (256ull * SWEEP_READS))),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 256ull * sweep_reads<K>() - 1) / (256ull * sweep_reads<K>()))),
                            dim3(256), 0, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p, (const uint32_t*)T.classes.p,

@@ -492,7 +492,10 @@ k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, cons
 // run's bucket from the minimizer the summary points at (2M bits of the read, no scan), and writes the
 // records of the runs that belong to this pass.  The cursors start at the buckets' first record indices;
 // afterwards cursor[b] must equal base[b+1] (k_check_cursors).
-constexpr int SWEEP_READS = 8;            // reads per thread of a k_scatter_runs block
+// reads per thread of a k_scatter_runs block.  The block's list lives in LDS, and the sweep runs beside k_count,
+// whose two workgroups per CU leave 16 KB of LDS at K=40/48 and 8 KB at K=60: with 4 KB lists a K=60 sweep got one
+// block per CU and ran 3.6 times longer than alone.
+template <int K> constexpr int sweep_reads() { return KTraits<K>::KW == 4 ? 2 : 8; }
 template <int K>
 __global__ void __launch_bounds__(256)
 k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
@@ -504,6 +507,7 @@ k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const 
     // pick the reads that can have a run in this pass; their indices are packed into an LDS list, which the
     // threads then work through densely (lanes whose read is not in the pass would otherwise idle through the
     // latency chain summary -> bases -> cursor -> record of their neighbours).
+    constexpr int SWEEP_READS = sweep_reads<K>();
     __shared__ uint16_t list[256 * SWEEP_READS];
     __shared__ uint32_t n_list;
     (void)good_len;
