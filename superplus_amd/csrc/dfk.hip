@@ -366,32 +366,41 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     const size_t lds_a = (sizeof(uint32_t) + 1) * pp.W * PART_THREADS + sizeof(uint16_t) * SUMMARY_RUNS * PART_THREADS + sizeof(uint32_t) * PART_RING * PART_THREADS + (by_class ? n_bins * 4 : 0);
     Timer t(c->stream);
     t.start();
+    // reads whose runs do not fit a summary are listed by the scan itself (two in 10^5 at 2x100 bp); if the list
+    // outgrows the room set aside for it the summaries are searched instead
+    DevBuf ovf_tmp, d_n;
+    const uint64_t ovf_cap = in.n_reads / 16 + 1024;
+    rc = c->alloc(ovf_tmp, ovf_cap * 4, "overflow read list (scratch)"); if (rc) return rc;
+    rc = c->alloc(d_n, 16, "overflow read count"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
     if (grid)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p,
-                           (unsigned long long*)nullptr, (uint64_t)0, (uint4*)nullptr, (uint4*)T->summ.p,
+                           (unsigned long long*)d_n.p, ovf_cap, (uint4*)ovf_tmp.p, (uint4*)T->summ.p,
                            (const uint32_t*)nullptr, (uint64_t)0, (const uint64_t*)nullptr, (uint32_t*)T->classes.p);
     HIP_TRY(hipGetLastError());
-    // reads whose runs did not fit a summary
     T->n_ovf = 0;
     if (in.n_reads) {
-        DevBuf tmp, d_n;
-        rc = c->alloc(tmp, in.n_reads * 4, "overflow read list (scratch)"); if (rc) return rc;
-        rc = c->alloc(d_n, 16, "overflow read count"); if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
-        hipLaunchKernelGGL(k_select_overflow, dim3((unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192)), dim3(256), 0, c->stream,
-                           (const uint4*)T->summ.p, in.n_reads, (uint32_t*)tmp.p, (unsigned long long*)d_n.p);
-        HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&T->n_ovf, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (T->n_ovf) {
-            rc = c->alloc(T->ovf_list, T->n_ovf * 4, "overflow read list", true); if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(T->ovf_list.p, tmp.p, T->n_ovf * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (T->n_ovf > ovf_cap) {                                       // long reads: most summaries overflow
+            c->release(ovf_tmp);
+            rc = c->alloc(ovf_tmp, in.n_reads * 4, "overflow read list (scratch)"); if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
+            hipLaunchKernelGGL(k_select_overflow, dim3((unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192)), dim3(256), 0, c->stream,
+                               (const uint4*)T->summ.p, in.n_reads, (uint32_t*)ovf_tmp.p, (unsigned long long*)d_n.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&T->n_ovf, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
-        c->release(tmp); c->release(d_n);
+        if (T->n_ovf) {
+            rc = c->alloc(T->ovf_list, T->n_ovf * 4, "overflow read list", true); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(T->ovf_list.p, ovf_tmp.p, T->n_ovf * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
     }
+    c->release(ovf_tmp); c->release(d_n);
     c->st.ms_part_count = t.stop();
     TRACE("%llu of %llu reads have more than %d runs", (unsigned long long)T->n_ovf, (unsigned long long)in.n_reads, SUMMARY_RUNS);
     if (by_class) {

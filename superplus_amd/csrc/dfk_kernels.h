@@ -356,6 +356,12 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
         }
         summaries[r] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
         if (read_classes) read_classes[r] = cmask;
+        // a read with more runs than a summary holds goes on the list of reads the scanning scatter handles (two in
+        // 10^5; in the counting scan `bucket_cur` is that list's counter, `records` the list, `n_out` its capacity)
+        if (qn > (uint32_t)SUMMARY_RUNS && bucket_cur) {
+            const unsigned long long at = atomicAdd(bucket_cur, 1ull);
+            if (at < n_out) reinterpret_cast<uint32_t*>(records)[at] = (uint32_t)r;
+        }
     }
     if (WRITE) {
         for (uint32_t e = 0; e < qn; ++e) {
@@ -375,7 +381,8 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
             unsigned long long* __restrict__ class_hist,      // ... or (sharded) per owner and class: [records | instances][world * PART_CLASSES]
             unsigned long long* __restrict__ bucket_cur,      // WRITE: append cursors, start at each fine bucket's first record index
             uint64_t n_out,                                   // WRITE: records the pass holds (nothing is written beyond)
-            uint4* __restrict__ records,
+            uint4* __restrict__ records,                      // (!WRITE: these three are the list of reads whose summary overflowed:
+                                                              //  its counter, its capacity and -- as uint32_t* -- its entries)
             uint4* __restrict__ summaries,                    // !WRITE: per read, its runs (see SUMMARY_RUNS)
             const uint32_t* __restrict__ read_list,           // WRITE (optional): the reads to process
             uint64_t n_list,
