@@ -943,8 +943,8 @@ int stage_adjacency(dfk_ctx* c)
         // queried from the lists; otherwise by streaming the parts.
         bool listed = c->want_blist;
         for (const dfk_ctx::Part& pt : c->parts) listed = listed && pt.listed;
+        if (c->want_blist) HIP_TRY(hipStreamSynchronize(c->stream2));   // the last part's list is being written there
         if (listed) {
-            HIP_TRY(hipStreamSynchronize(c->stream2));
             uint64_t total = 0;
             for (const dfk_ctx::Part& pt : c->parts) {
                 if (!pt.blist) continue;
