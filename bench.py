@@ -210,6 +210,18 @@ def main():
         elapsed = float(allreduce(elapsed, torch.float64, dist.ReduceOp.MAX))
         n_inst = int(allreduce(n_inst, torch.int64, dist.ReduceOp.SUM))
 
+    # multi-rank runs: where the last step's time went on the slowest and on the fastest rank (host clock per
+    # phase of DistDfk.count_device), and the bytes a rank sent over the links
+    dist_timing = None
+    if hasattr(d, "timing"):
+        tm = d.timing
+        if multi:
+            keys = [k for k in sorted(tm) if k not in ("n_passes",)]
+            dist_timing = {"max_over_ranks": {k: round(float(allreduce(float(tm[k]), torch.float64, dist.ReduceOp.MAX)), 3) for k in keys},
+                           "min_over_ranks": {k: round(float(allreduce(float(tm[k]), torch.float64, dist.ReduceOp.MIN)), 3) for k in keys},
+                           "n_passes": tm["n_passes"]}
+        else:
+            dist_timing = {"rank0": {k: round(float(v), 3) for k, v in tm.items()}}
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = n_inst * args.steps / elapsed
@@ -241,6 +253,8 @@ def main():
                          "algorithmic_bytes_per_launch": B_INST * k_inst // max(1, st["n_passes"]),
                          "kernel_ms_all_launches": k_ms, "launches_per_step": st["n_passes"]},
         }
+        if dist_timing is not None:
+            out["dist_timing_ms"] = dist_timing
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, args.K, args.cpu_sample_reads)
         print(json.dumps(out))

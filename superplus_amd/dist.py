@@ -254,33 +254,53 @@ class DistDfk(Dfk):
 
     # ---- the sharded createDict ----
     def count_device(self, packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0=0):
+        """Runs the sharded pipeline.  Afterwards self.timing holds this rank's host-clock milliseconds per phase of
+        the call (every library call ends with the device idle, so the host clock is the device's):
+        trim, plan (the counting scan), partition (sweeps), exchange_wait (time this rank sat waiting for records:
+        what the transfers cost beyond what hides under the count), count (regroup + count), adjacency (queries,
+        both exchanges, answers), total; and the bytes it sent to other ranks."""
+        import time
+        T = {k: 0.0 for k in ("trim", "plan", "partition", "exchange_wait", "count", "adjacency", "total")}
+        sent = 0
+        t_all = time.perf_counter()
+
+        def timed(key, f, *a):
+            t = time.perf_counter()
+            r = f(*a)
+            T[key] += 1e3 * (time.perf_counter() - t)
+            return r
+
         comm = self.comm or TorchComm()
         world = comm.world
-        n_local = self.begin(packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0)
+        n_local = timed("trim", self.begin, packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0)
         n_global = comm.all_reduce_sum(n_local, packed.device)
         if n_global == 0:
             raise _dfk.DfkError(-7, "Looks like your input data have almost no good bases.")
         self._n_inst_global = n_global
-        log2_passes = comm.all_reduce_max(self.plan(world, n_global), packed.device)   # every rank runs the same passes
+        log2_passes = comm.all_reduce_max(timed("plan", self.plan, world, n_global), packed.device)   # every rank runs the same passes
         # The k-mer shuffle, one bucket range at a time -- and one range ahead: while pass p is counted, the records
         # of pass p+1 have been cut and are on their way (the library keeps a second receive buffer for them).
         n_pass = 1 << log2_passes
-        send, counts = self.partition(world, n_global, log2_passes, 0)
-        recv, _ = exchange_end(exchange_begin(send, counts, 32, comm, self.recv_buffer))
+        send, counts = timed("partition", self.partition, world, n_global, log2_passes, 0)
+        sent += 32 * (sum(counts) - counts[comm.rank])
+        recv, _ = timed("exchange_wait", lambda: exchange_end(exchange_begin(send, counts, 32, comm, self.recv_buffer)))
         for p in range(n_pass):
             token = None
             if p + 1 < n_pass:
-                send, counts = self.partition(world, n_global, log2_passes, p + 1)
-                token = exchange_begin(send, counts, 32, comm, self.recv_buffer)
+                send, counts = timed("partition", self.partition, world, n_global, log2_passes, p + 1)
+                sent += 32 * (sum(counts) - counts[comm.rank])
+                token = timed("exchange_wait", exchange_begin, send, counts, 32, comm, self.recv_buffer)
                 if os.environ.get("DFK_SHARD_SERIAL"):                          # debugging aid: no transfer under the count
                     token = (*exchange_end(token), None, None)
-            self.count_records(recv, p)
+            timed("count", self.count_records, recv, p)
             del recv
             if token is not None:
-                recv, _ = exchange_end(token)
+                recv, _ = timed("exchange_wait", exchange_end, token)
                 del token
         del send
+        t_adj = time.perf_counter()
         keys, kcounts = self.adj_queries(world)
+        sent += 17 * (sum(kcounts) - kcounts[comm.rank])
         rkeys, rcounts = exchange(keys, kcounts, 16, comm)                 # neighbour queries
         answers = self.adj_answer(rkeys)
         if getattr(comm, "rehearsal", False):                              # no peers to answer: see ReplicaComm
@@ -288,6 +308,11 @@ class DistDfk(Dfk):
         else:
             back, _ = exchange(answers, rcounts, 1, comm)                  # answers return in query order
         self.adj_apply(back)
+        T["adjacency"] = 1e3 * (time.perf_counter() - t_adj)
+        T["total"] = 1e3 * (time.perf_counter() - t_all)
+        T["bytes_sent_to_peers"] = sent
+        T["n_passes"] = n_pass
+        self.timing = T
 
     def stats(self):
         s = super().stats()
