@@ -1573,6 +1573,84 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* sc
     return off + incl - v;
 }
 
+// The same regroup without a global atomic: two levels of counting sort, all counters in LDS.
+//   level 1  RG_PARTS partitions by the top bits of the bucket id.  A block owns a contiguous chunk of the input:
+//            it counts its records per partition (k_rg_hist), a device scan of the [partition][block] counts gives
+//            every block its own write position in every partition, and the block copies its records there
+//            (k_rg_scatter; the positions are LDS cursors).
+//   level 2  one workgroup per partition (k_rg_finish): counts the records and instances of its <= RG_FINE fine
+//            buckets in LDS -- these are the pass's bucket counters, written out in the counting scan's format --
+//            scans them and moves every record to its bucket's place inside the partition (again LDS cursors).
+// 6 x 32 B of streaming traffic per record instead of two scattered global atomics and a scattered store.
+constexpr uint32_t RG_LOG2_PARTS = 12, RG_PARTS = 1u << RG_LOG2_PARTS;
+constexpr uint32_t RG_FINE = 4096;                 // fine buckets per partition at most (2^24 buckets per pass / RG_PARTS)
+
+__global__ void __launch_bounds__(256)
+k_rg_hist(const uint4* __restrict__ in, uint64_t n, uint64_t chunk, uint32_t local_mask, uint32_t part_shift, uint32_t n_parts,
+          uint64_t* __restrict__ h1)               // [n_parts][gridDim.x] (+ one trailing zero, written by the host)
+{
+    __shared__ uint32_t hist[RG_PARTS];
+    for (uint32_t i = threadIdx.x; i < n_parts; i += 256) hist[i] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256)
+        atomicAdd(&hist[((in[2 * i].x >> 8) & local_mask) >> part_shift], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_parts; i += 256) h1[(uint64_t)i * gridDim.x + blockIdx.x] = hist[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_rg_scatter(const uint4* __restrict__ in, uint64_t n, uint64_t chunk, uint32_t local_mask, uint32_t part_shift, uint32_t n_parts,
+             const uint64_t* __restrict__ h1off, uint4* __restrict__ out)
+{
+    __shared__ unsigned long long cur[RG_PARTS];
+    for (uint32_t i = threadIdx.x; i < n_parts; i += 256) cur[i] = h1off[(uint64_t)i * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint4 a = in[2 * i], b = in[2 * i + 1];
+        const unsigned long long dst = atomicAdd(&cur[((a.x >> 8) & local_mask) >> part_shift], 1ull);
+        out[2 * dst] = a; out[2 * dst + 1] = b;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_rg_finish(const uint4* __restrict__ in, uint64_t n, uint32_t local_mask, uint32_t part_shift, uint32_t n_parts, uint32_t n_blocks1,
+            const uint64_t* __restrict__ h1off, unsigned long long* __restrict__ bucket_acc, uint4* __restrict__ out)
+{
+    __shared__ uint32_t rec[RG_FINE], inst[RG_FINE];
+    __shared__ uint32_t scratch[8];
+    const uint32_t fine = 1u << part_shift, fmask = fine - 1u;              // fine buckets per partition (<= RG_FINE)
+    for (uint32_t p = blockIdx.x; p < n_parts; p += gridDim.x) {
+        const uint64_t s = h1off[(uint64_t)p * n_blocks1], e = p + 1 < n_parts ? h1off[(uint64_t)(p + 1) * n_blocks1] : n;
+        for (uint32_t i = threadIdx.x; i < fine; i += 256) { rec[i] = 0; inst[i] = 0; }
+        __syncthreads();
+        for (uint64_t i = s + threadIdx.x; i < e; i += 256) {
+            const uint32_t h = in[2 * i].x, f = (h >> 8) & fmask;
+            atomicAdd(&rec[f], 1u); atomicAdd(&inst[f], h & 63u);
+        }
+        __syncthreads();
+        // the bucket counters of the pass (records << 32 | instances), then rec[] becomes each bucket's first index
+        uint32_t carry = 0;
+        for (uint32_t f0 = 0; f0 < fine; f0 += 256) {
+            const uint32_t f = f0 + threadIdx.x;
+            const uint32_t r = f < fine ? rec[f] : 0u;
+            if (f < fine) bucket_acc[(uint64_t)p * fine + f] = ((unsigned long long)r << 32) | inst[f];
+            uint32_t total;
+            const uint32_t ex = block_excl_scan_256(r, scratch, &total);
+            if (f < fine) rec[f] = carry + ex;
+            carry += total;
+        }
+        __syncthreads();
+        for (uint64_t i = s + threadIdx.x; i < e; i += 256) {
+            const uint4 a = in[2 * i], b = in[2 * i + 1];
+            const uint64_t dst = s + atomicAdd(&rec[(a.x >> 8) & fmask], 1u);
+            out[2 * dst] = a; out[2 * dst + 1] = b;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_adj_list(const uint4* __restrict__ entries, uint64_t n, unsigned long long* __restrict__ n_items, uint64_t* __restrict__ list)
 {
