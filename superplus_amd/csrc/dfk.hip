@@ -553,6 +553,7 @@ struct CountRun {                     // device state shared by the count launch
     DevBuf d_wg;                       // WgOut of every persistent workgroup
     uint64_t solid_seen = 0, inst_seen = 0;   // totals of the passes done so far (sizes the next pass's output)
     uint64_t boundary_seen = 0;               // entries with unresolved context bits emitted by the passes done so far
+    uint64_t splits_seen = 0;                 // items cut in two inside k_count by the passes done so far
 };
 
 int count_run_begin(dfk_ctx* c, CountRun* R)
@@ -866,6 +867,8 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     // 4 bytes for one entry in eight); it is filled on the second stream while the next pass is counted
     const uint64_t nb_part = hg.n_boundary - R.boundary_seen;
     R.boundary_seen = hg.n_boundary;
+    c->st.n_overflow_items += hg.n_split - R.splits_seen;             // (+ the single buckets that went to HBM tables, above)
+    R.splits_seen = hg.n_split;
     uint64_t keep = part.n * 32;
     part.listed = c->want_blist && nb_part == 0;
     if (c->want_blist && nb_part && keep + 16 + 4 * nb_part <= part.buf.bytes && part.n < (1ull << 32)) {

@@ -576,7 +576,7 @@ struct CountGlobals {                // device-resident counters
     unsigned int next_item;
     unsigned int n_overflow;         // items that overflowed their table
     unsigned int solid_overflow;     // the output buffer ran out of room
-    unsigned int pad;
+    unsigned int n_split;            // items that overflowed their table and were cut in two by their workgroup
     unsigned long long n_boundary;   // solid entries left with unresolved (cross-item) context bits
     unsigned long long part_cursor;  // entries of the part's reservation handed out to workgroups so far (whole chunks)
 };
@@ -869,7 +869,10 @@ __device__ __forceinline__ u128 canon_value(u128 F)
 // ctl words (LDS)
 enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_USED = 4, CTL_DISTINCT = 5, CTL_NTASK = 6, CTL_BOUNDARY = 7,
        CTL_RB_LO = 8, CTL_RB_HI = 9, CTL_RE_LO = 10, CTL_RE_HI = 11, CTL_NSOLID = 12,
-       CTL_OUT_LO = 13, CTL_OUT_HI = 14, CTL_NEXT_LO = 15, CTL_NEXT_HI = 16, CTL_N = 24 };
+       CTL_OUT_LO = 13, CTL_OUT_HI = 14, CTL_NEXT_LO = 15, CTL_NEXT_HI = 16,
+       CTL_B0 = 17, CTL_B1 = 18,                     // fine buckets [b0, b1) of the item being counted
+       CTL_SP = 19, CTL_STACK = 24, CTL_STACK_CAP = 16,   // bucket ranges waiting to be counted by this workgroup (pairs of words)
+       CTL_N = CTL_STACK + 2 * CTL_STACK_CAP };
 
 // Finish a counted LDS table: decide solidity, clean up adjacencies, emit.  (The HBM-table fallback does
 // the same three steps as separate grid-wide launches: k_big_flags / k_big_resolve / k_big_emit.)
@@ -1056,16 +1059,20 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     // The item loop is software-pipelined: while the workgroup counts item i, thread 0 already holds the
     // ticket and the record range of item i+1 in registers (a returning global atomic plus a dependent
     // load are ~4 us of latency that every wave would otherwise wait for behind a barrier).
+    // An item that overflows its table is cut in two by bucket index on the spot: thread 0 keeps a small stack
+    // of bucket ranges in LDS (the halves, and the ticket it already holds) and the workgroup works that off
+    // before it takes another ticket.  Only single buckets that overflow go back to the host (HBM tables).
     if (tid == 0) {
         const WgOut w = wg_out[blockIdx.x];
         ctl[CTL_OUT_LO] = (uint32_t)w.chunk; ctl[CTL_OUT_HI] = (uint32_t)(w.chunk >> 32); ctl[CTL_USED] = w.used;
         ctl[CTL_NEXT_LO] = 0; ctl[CTL_NEXT_HI] = 0; ctl[CTL_DISTINCT] = 0; ctl[CTL_BOUNDARY] = 0;
-        ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0; ctl[CTL_NSOLID] = 0;
+        ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0; ctl[CTL_NSOLID] = 0; ctl[CTL_SP] = 0;
         const uint32_t it0 = atomicAdd(&g->next_item, 1u);
-        uint64_t b0 = 0, e0 = 0;
-        if (it0 < cp.n_items) { b0 = rec_base[items[it0].b0]; e0 = rec_base[items[it0].b1]; }
+        uint64_t b0 = 0, e0 = 0; ItemRange r0{0, 0};
+        if (it0 < cp.n_items) { r0 = items[it0]; b0 = rec_base[r0.b0]; e0 = rec_base[r0.b1]; }
         ctl[CTL_ITEM] = it0; ctl[CTL_RB_LO] = (uint32_t)b0; ctl[CTL_RB_HI] = (uint32_t)(b0 >> 32);
         ctl[CTL_RE_LO] = (uint32_t)e0; ctl[CTL_RE_HI] = (uint32_t)(e0 >> 32);
+        ctl[CTL_B0] = r0.b0; ctl[CTL_B1] = r0.b1;
     }
     for (;;) {
         __syncthreads();                                               // table empty, counters reset, item published
@@ -1073,10 +1080,10 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         if (item >= cp.n_items) break;
         const uint64_t rb = (uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RB_LO]) | ((uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RB_HI]) << 32);
         const uint64_t re = (uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RE_LO]) | ((uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RE_HI]) << 32);
-        uint32_t nx = 0xFFFFFFFFu; uint64_t nb = 0, ne = 0;
-        if (tid == 0) {
+        uint32_t nx = 0xFFFFFFFFu; uint64_t nb = 0, ne = 0; ItemRange nr{0, 0};
+        if (tid == 0 && ctl[CTL_SP] == 0) {                            // (ranges on the stack come first)
             nx = atomicAdd(&g->next_item, 1u);
-            if (nx < cp.n_items) { nb = rec_base[items[nx].b0]; ne = rec_base[items[nx].b1]; }
+            if (nx < cp.n_items) { nr = items[nx]; nb = rec_base[nr.b0]; ne = rec_base[nr.b1]; }
         }
         // Waves pull chunks of the item from an LDS ticket.  All loop control is made scalar
         // (readfirstlane) so the compiler emits uniform branches, and the trip count is bounded.
@@ -1093,7 +1100,18 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         }
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(ctl[CTL_OVF])) {
-            if (tid == 0) overflow_items[atomicAdd(&g->n_overflow, 1u)] = items[item];
+            if (tid == 0) {
+                const uint32_t b0 = ctl[CTL_B0], b1 = ctl[CTL_B1];
+                uint32_t sp = ctl[CTL_SP];
+                if (b1 - b0 > 1 && sp + 3 <= (uint32_t)CTL_STACK_CAP) {
+                    if (nx < cp.n_items) { ctl[CTL_STACK + 2 * sp] = nr.b0; ctl[CTL_STACK + 2 * sp + 1] = nr.b1; ++sp; nx = 0xFFFFFFFFu; }
+                    const uint32_t mid = b0 + (b1 - b0) / 2;
+                    ctl[CTL_STACK + 2 * sp] = mid; ctl[CTL_STACK + 2 * sp + 1] = b1; ++sp;
+                    ctl[CTL_STACK + 2 * sp] = b0; ctl[CTL_STACK + 2 * sp + 1] = mid; ++sp;
+                    ctl[CTL_SP] = sp;
+                    atomicAdd(&g->n_split, 1u);
+                } else overflow_items[atomicAdd(&g->n_overflow, 1u)] = ItemRange{b0, b1};
+            }
             for (uint32_t i = tid; i < (3 + XW) * S; i += NT) cnt[i] = 0;   // abandon the table
             __syncthreads();                                           // everyone has read CTL_OVF before it is reset
         } else {
@@ -1111,9 +1129,16 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
             for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
             if (lane == 0 && occ) atomicAdd(&ctl[CTL_DISTINCT], occ);
         }
-        if (tid == 0) {                                                // publish the prefetched item, reset the per-item words
+        if (tid == 0) {                                                // publish the next item (stack first), reset the per-item words
+            const uint32_t sp = ctl[CTL_SP];
+            if (sp) {
+                nr = ItemRange{ctl[CTL_STACK + 2 * (sp - 1)], ctl[CTL_STACK + 2 * (sp - 1) + 1]};
+                ctl[CTL_SP] = sp - 1;
+                nx = 0; nb = rec_base[nr.b0]; ne = rec_base[nr.b1];
+            }
             ctl[CTL_ITEM] = nx; ctl[CTL_RB_LO] = (uint32_t)nb; ctl[CTL_RB_HI] = (uint32_t)(nb >> 32);
             ctl[CTL_RE_LO] = (uint32_t)ne; ctl[CTL_RE_HI] = (uint32_t)(ne >> 32);
+            ctl[CTL_B0] = nr.b0; ctl[CTL_B1] = nr.b1;
             ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0;
         }
     }
