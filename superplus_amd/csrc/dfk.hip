@@ -622,7 +622,7 @@ template <int K> unsigned count_grid(const dfk_ctx* c, int nbc = 1)      // pers
 // one k_count launch over `n_items` device-resident items; overflowed items come back as bucket ranges
 template <int K, int NBC>
 int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint64_t n_items, const CountRun& R,
-                 std::vector<ItemRange>* overflowed, float* kernel_ms)
+                 std::vector<ItemRange>* overflowed, float* kernel_ms, const uint32_t* d_sub = nullptr)
 {
     constexpr int LOG2S = CountCfg<K>::LOG2S, NW = CountCfg<K>::NWAVES;
     if (n_items == 0) return 0;
@@ -632,14 +632,14 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
     HIP_TRY(hipMemsetAsync(&R.g->next_item, 0, 8, c->stream));      // next_item, n_overflow
     CountParams cp = R.cp; cp.n_items = (uint32_t)n_items;
     const size_t lds = count_lds_bytes<K, LOG2S, NW, NBC>();
-    auto kern = k_count<K, LOG2S, NW, NBC>;
+    auto kern = d_sub ? k_count<K, LOG2S, NW, NBC, true> : k_count<K, LOG2S, NW, NBC, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     TRACE("k_count: %llu items, grid %u, lds %zu, seg_cap %llu", (unsigned long long)n_items, R.grid, lds, (unsigned long long)R.cp.seg_cap);
     Timer tk(c->stream);
     tk.start();
     hipLaunchKernelGGL(kern, dim3(R.grid), dim3(NW * 64), lds, c->stream,
                        (const uint4*)P.records.p, d_items, (const uint64_t*)P.base.p, cp, R.g, R.seg, (WgOut*)R.d_wg.p, R.hist,
-                       (ItemRange*)d_ovf.p);
+                       (ItemRange*)d_ovf.p, d_sub);
     HIP_TRY(hipGetLastError());
     *kernel_ms += tk.stop();
     CountGlobals g{};
@@ -812,7 +812,50 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
         if (rc) return rc;
     }
     TRACE("fallback: %zu single-bucket items", singles.size());
-    if (!singles.empty()) { rc = launch_count_big<K, NBC>(c, P, singles, R); if (rc) return rc; }
+    if (!singles.empty()) {
+        // A fine bucket too rich for one LDS table is counted in 2^p sub-passes of k_count, each taking the k-mers
+        // of one selector value (all instances of a k-mer share it, so solidity and counts are exact; neighbours in
+        // another sub-pass are settled with the other cross-item bits).  p from the bucket's instance count, which
+        // bounds its distinct k-mers: 1024 per sub-pass at most, in a 2048-slot table that gives up at 1536.
+        // Buckets beyond 64 sub-passes (a minimizer owning a sizeable share of the genome) get an HBM table.
+        const uint32_t n = (uint32_t)singles.size();
+        std::vector<uint32_t> idx(2 * n);
+        for (uint32_t i = 0; i < n; ++i) { idx[2 * i] = singles[i].b0; idx[2 * i + 1] = singles[i].b1; }
+        DevBuf d_idx, d_val;
+        rc = c->alloc(d_idx, 8ull * n, "gather index"); if (rc) return rc;
+        rc = c->alloc(d_val, 16ull * n, "gather values"); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(d_idx.p, idx.data(), 8ull * n, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_u64, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, (const uint64_t*)P.ipre.p,
+                           (const uint32_t*)d_idx.p, 2 * n, (uint64_t*)d_val.p);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint64_t> val(2 * n);
+        HIP_TRY(hipMemcpyAsync(val.data(), d_val.p, 16ull * n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->release(d_idx); c->release(d_val);
+        std::vector<ItemRange> sub_items, huge; std::vector<uint32_t> sub_words;
+        constexpr uint64_t PER_SUB = (1ull << CountCfg<K>::LOG2S) / 2;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t inst = val[2 * i + 1] - val[2 * i];
+            const uint32_t p = std::max<uint32_t>(1, ceil_log2((inst + PER_SUB - 1) / PER_SUB));
+            if (p > 6) { huge.push_back(singles[i]); continue; }
+            for (uint32_t k = 0; k < (1u << p); ++k) { sub_items.push_back(singles[i]); sub_words.push_back((p << 8) | k); }
+        }
+        TRACE("fallback: %zu sub-passes over %zu buckets in LDS tables, %zu buckets in HBM tables", sub_items.size(), singles.size() - huge.size(), huge.size());
+        if (!sub_items.empty()) {
+            DevBuf d_it, d_sub;
+            rc = c->alloc(d_it, sub_items.size() * sizeof(ItemRange), "sub-pass items"); if (rc) return rc;
+            rc = c->alloc(d_sub, sub_words.size() * 4, "sub-pass words"); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(d_it.p, sub_items.data(), sub_items.size() * sizeof(ItemRange), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_sub.p, sub_words.data(), sub_words.size() * 4, hipMemcpyHostToDevice, c->stream));
+            std::vector<ItemRange> again;
+            float ignored = 0;
+            rc = launch_count<K, NBC>(c, P, (const ItemRange*)d_it.p, sub_items.size(), R, &again, &ignored, (const uint32_t*)d_sub.p);
+            c->release(d_it); c->release(d_sub);
+            if (rc) return rc;
+            if (!again.empty()) return fail(DFK_E_HIP, "%zu sub-passes overflowed their table (a sub-pass holds at most %llu instances)", again.size(), (unsigned long long)PER_SUB);
+        }
+        if (!huge.empty()) { rc = launch_count_big<K, NBC>(c, P, huge, R); if (rc) return rc; }
+    }
     c->st.ms_fallback += t.stop();
 
     CountGlobals hg{};

@@ -783,12 +783,15 @@ __device__ __forceinline__ Probe make_probe(const InstRegs& in, uint32_t S, bool
 
 // Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
 // block barriers).  Lanes load half a record each (1 KiB per wave, coalesced).
-template <int K, int NBC, bool LDS_TABLE>
+template <int K, int NBC, bool LDS_TABLE, bool SUB = false>
 __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
                                                  WaveStage<K>* __restrict__ st, int lane,
                                                  uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
-                                                 uint32_t S, uint32_t* n_fill, uint32_t* overflow)
+                                                 uint32_t S, uint32_t* n_fill, uint32_t* overflow, uint32_t sub = 0)
 {
+    // sub != 0: one of 2^(sub >> 8) sub-passes over a fine bucket too rich for one table -- only the k-mers whose
+    // selector (a mix of the key's low word) equals sub & 0xFF are counted in this one
+    const uint32_t sel_mask = (1u << (sub >> 8)) - 1u, sel = sub & 0xFFu;
     static_assert(COUNT_CHUNK == 32, "one uint4 per lane");
     const uint64_t hidx = 2 * rb + lane;
     uint4 v{0, 0, 0, 0};
@@ -811,7 +814,8 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     const uint32_t total_u = __builtin_amdgcn_readfirstlane(total);     // scalar loop control
     for (uint32_t t0 = 0; t0 < total_u; t0 += 64) {
         const uint32_t t = t0 + lane;
-        const Probe A = make_probe<K>(fetch_instance<K>(st, min(t, total_u - 1u)), S, t < total_u);
+        Probe A = make_probe<K>(fetch_instance<K>(st, min(t, total_u - 1u)), S, t < total_u);
+        if (SUB) A.active = A.active && (((A.k0 * 0x9E3779B1u) >> 26) & sel_mask) == sel;
 #ifdef DFK_ABLATE_INSERT        // timing experiment only: keep the extraction alive, skip the table
         if ((A.k0 ^ A.k1 ^ A.ctx) == 0x12345u) ++n_claimed;
 #else
@@ -871,8 +875,9 @@ enum { CTL_ITEM = 0, CTL_OVF = 1, CTL_FILL = 2, CTL_CHUNK = 3, CTL_USED = 4, CTL
        CTL_RB_LO = 8, CTL_RB_HI = 9, CTL_RE_LO = 10, CTL_RE_HI = 11, CTL_NSOLID = 12,
        CTL_OUT_LO = 13, CTL_OUT_HI = 14, CTL_NEXT_LO = 15, CTL_NEXT_HI = 16,
        CTL_B0 = 17, CTL_B1 = 18,                     // fine buckets [b0, b1) of the item being counted
-       CTL_SP = 19, CTL_STACK = 24, CTL_STACK_CAP = 16,   // bucket ranges waiting to be counted by this workgroup (pairs of words)
-       CTL_N = CTL_STACK + 2 * CTL_STACK_CAP };
+       CTL_SP = 19, CTL_SUB = 20,                    // ... and its sub-pass word (wave_count_chunk)
+       CTL_STACK = 24, CTL_STACK_CAP = 16,           // bucket ranges waiting to be counted by this workgroup (b0, b1, sub)
+       CTL_N = CTL_STACK + 3 * CTL_STACK_CAP };
 
 // Finish a counted LDS table: decide solidity, clean up adjacencies, emit.  (The HBM-table fallback does
 // the same three steps as separate grid-wide launches: k_big_flags / k_big_resolve / k_big_emit.)
@@ -1030,11 +1035,12 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
 }
 
 
-template <int K, int LOG2S, int NWAVES, int NBC>
+template <int K, int LOG2S, int NWAVES, int NBC, bool SUB>    // SUB: the launch over sub-passes of single buckets (item_sub given)
 __global__ void __launch_bounds__(NWAVES * 64)
 k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, const uint64_t* __restrict__ rec_base,
         CountParams cp, CountGlobals* __restrict__ g, uint4* __restrict__ out, WgOut* __restrict__ wg_out,
-        unsigned long long* __restrict__ hist_global, ItemRange* __restrict__ overflow_items)
+        unsigned long long* __restrict__ hist_global, ItemRange* __restrict__ overflow_items,
+        const uint32_t* __restrict__ item_sub)        // optional: per item, its sub-pass word (single buckets counted in several sub-passes)
 {
     constexpr uint32_t S = 1u << LOG2S;
     constexpr int KW = KTraits<K>::KW;
@@ -1068,11 +1074,11 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         ctl[CTL_NEXT_LO] = 0; ctl[CTL_NEXT_HI] = 0; ctl[CTL_DISTINCT] = 0; ctl[CTL_BOUNDARY] = 0;
         ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0; ctl[CTL_NSOLID] = 0; ctl[CTL_SP] = 0;
         const uint32_t it0 = atomicAdd(&g->next_item, 1u);
-        uint64_t b0 = 0, e0 = 0; ItemRange r0{0, 0};
-        if (it0 < cp.n_items) { r0 = items[it0]; b0 = rec_base[r0.b0]; e0 = rec_base[r0.b1]; }
+        uint64_t b0 = 0, e0 = 0; ItemRange r0{0, 0}; uint32_t s0 = 0;
+        if (it0 < cp.n_items) { r0 = items[it0]; b0 = rec_base[r0.b0]; e0 = rec_base[r0.b1]; if (SUB) s0 = item_sub[it0]; }
         ctl[CTL_ITEM] = it0; ctl[CTL_RB_LO] = (uint32_t)b0; ctl[CTL_RB_HI] = (uint32_t)(b0 >> 32);
         ctl[CTL_RE_LO] = (uint32_t)e0; ctl[CTL_RE_HI] = (uint32_t)(e0 >> 32);
-        ctl[CTL_B0] = r0.b0; ctl[CTL_B1] = r0.b1;
+        ctl[CTL_B0] = r0.b0; ctl[CTL_B1] = r0.b1; ctl[CTL_SUB] = s0;
     }
     for (;;) {
         __syncthreads();                                               // table empty, counters reset, item published
@@ -1080,10 +1086,13 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         if (item >= cp.n_items) break;
         const uint64_t rb = (uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RB_LO]) | ((uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RB_HI]) << 32);
         const uint64_t re = (uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RE_LO]) | ((uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RE_HI]) << 32);
-        uint32_t nx = 0xFFFFFFFFu; uint64_t nb = 0, ne = 0; ItemRange nr{0, 0};
+        const uint32_t sub = __builtin_amdgcn_readfirstlane(ctl[CTL_SUB]);
+        // (thread 0 keeps the prefetched ticket in registers: storing it to LDS here would make its wave wait
+        // for the loads at the top of every item -- measured, +1 % on the whole kernel)
+        uint32_t nx = 0xFFFFFFFFu; uint64_t nb = 0, ne = 0; ItemRange nr{0, 0}; uint32_t nsub = 0;
         if (tid == 0 && ctl[CTL_SP] == 0) {                            // (ranges on the stack come first)
             nx = atomicAdd(&g->next_item, 1u);
-            if (nx < cp.n_items) { nr = items[nx]; nb = rec_base[nr.b0]; ne = rec_base[nr.b1]; }
+            if (nx < cp.n_items) { nr = items[nx]; nb = rec_base[nr.b0]; ne = rec_base[nr.b1]; if (SUB) nsub = item_sub[nx]; }
         }
         // Waves pull chunks of the item from an LDS ticket.  All loop control is made scalar
         // (readfirstlane) so the compiler emits uniform branches, and the trip count is bounded.
@@ -1094,8 +1103,8 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
             ci = __builtin_amdgcn_readfirstlane(ci);
             if (ci >= n_chunks) break;
             if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
-            wave_count_chunk<K, NBC, true>(records, rb + (uint64_t)ci * COUNT_CHUNK, re, st, lane, keys, cnt, ctxs, bcw, S,
-                                        &ctl[CTL_FILL], &ctl[CTL_OVF]);
+            wave_count_chunk<K, NBC, true, SUB>(records, rb + (uint64_t)ci * COUNT_CHUNK, re, st, lane, keys, cnt, ctxs, bcw, S,
+                                             &ctl[CTL_FILL], &ctl[CTL_OVF], sub);
             if (lane == 0 && tld(&ctl[CTL_FILL]) > (S / 4) * 3) tst(&ctl[CTL_OVF], 1u);   // stop when 3/4 full
         }
         __syncthreads();
@@ -1104,10 +1113,10 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
                 const uint32_t b0 = ctl[CTL_B0], b1 = ctl[CTL_B1];
                 uint32_t sp = ctl[CTL_SP];
                 if (b1 - b0 > 1 && sp + 3 <= (uint32_t)CTL_STACK_CAP) {
-                    if (nx < cp.n_items) { ctl[CTL_STACK + 2 * sp] = nr.b0; ctl[CTL_STACK + 2 * sp + 1] = nr.b1; ++sp; nx = 0xFFFFFFFFu; }
+                    if (nx < cp.n_items) { ctl[CTL_STACK + 3 * sp] = nr.b0; ctl[CTL_STACK + 3 * sp + 1] = nr.b1; ctl[CTL_STACK + 3 * sp + 2] = nsub; ++sp; nx = 0xFFFFFFFFu; }
                     const uint32_t mid = b0 + (b1 - b0) / 2;
-                    ctl[CTL_STACK + 2 * sp] = mid; ctl[CTL_STACK + 2 * sp + 1] = b1; ++sp;
-                    ctl[CTL_STACK + 2 * sp] = b0; ctl[CTL_STACK + 2 * sp + 1] = mid; ++sp;
+                    ctl[CTL_STACK + 3 * sp] = mid; ctl[CTL_STACK + 3 * sp + 1] = b1; ctl[CTL_STACK + 3 * sp + 2] = 0u; ++sp;
+                    ctl[CTL_STACK + 3 * sp] = b0; ctl[CTL_STACK + 3 * sp + 1] = mid; ctl[CTL_STACK + 3 * sp + 2] = 0u; ++sp;
                     ctl[CTL_SP] = sp;
                     atomicAdd(&g->n_split, 1u);
                 } else overflow_items[atomicAdd(&g->n_overflow, 1u)] = ItemRange{b0, b1};
@@ -1131,14 +1140,15 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         }
         if (tid == 0) {                                                // publish the next item (stack first), reset the per-item words
             const uint32_t sp = ctl[CTL_SP];
+            uint32_t n0 = nr.b0, n1 = nr.b1;
             if (sp) {
-                nr = ItemRange{ctl[CTL_STACK + 2 * (sp - 1)], ctl[CTL_STACK + 2 * (sp - 1) + 1]};
+                n0 = ctl[CTL_STACK + 3 * (sp - 1)]; n1 = ctl[CTL_STACK + 3 * (sp - 1) + 1]; nsub = ctl[CTL_STACK + 3 * (sp - 1) + 2];
                 ctl[CTL_SP] = sp - 1;
-                nx = 0; nb = rec_base[nr.b0]; ne = rec_base[nr.b1];
+                nx = 0; nb = rec_base[n0]; ne = rec_base[n1];
             }
             ctl[CTL_ITEM] = nx; ctl[CTL_RB_LO] = (uint32_t)nb; ctl[CTL_RB_HI] = (uint32_t)(nb >> 32);
             ctl[CTL_RE_LO] = (uint32_t)ne; ctl[CTL_RE_HI] = (uint32_t)(ne >> 32);
-            ctl[CTL_B0] = nr.b0; ctl[CTL_B1] = nr.b1;
+            ctl[CTL_B0] = n0; ctl[CTL_B1] = n1; ctl[CTL_SUB] = nsub;
             ctl[CTL_OVF] = 0; ctl[CTL_FILL] = 0; ctl[CTL_CHUNK] = 0; ctl[CTL_NTASK] = 0;
         }
     }
