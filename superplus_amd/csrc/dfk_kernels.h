@@ -1903,8 +1903,14 @@ __global__ void __launch_bounds__(256)
 k_check_cursors(const unsigned long long* __restrict__ cur, const uint64_t* __restrict__ base, uint64_t nb, unsigned int* __restrict__ bad)
 {
     unsigned int wrong = 0;
-    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (uint64_t)gridDim.x * blockDim.x)
-        wrong += cur[b] != base[b + 1];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b0 < nb; b0 += 4 * stride) {
+        unsigned long long c[4]; uint64_t e[4];                        // eight loads in flight per lane
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint64_t b = b0 + k * stride; c[k] = b < nb ? cur[b] : 0ull; e[k] = b < nb ? base[b + 1] : 0ull; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wrong += c[k] != e[k];
+    }
     if (wrong) atomicAdd(bad, wrong);
 }
 
