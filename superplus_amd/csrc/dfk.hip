@@ -834,14 +834,22 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
         c->release(d_idx); c->release(d_val);
         std::vector<ItemRange> sub_items, huge; std::vector<uint32_t> sub_words;
         constexpr uint64_t PER_SUB = (1ull << CountCfg<K>::LOG2S) / 2;
+        constexpr uint32_t MAX_P = 8;                                    // selector bits (wave_count_chunk)
+        // p is first guessed from the distinct k-mers per instance seen so far (a repeat-rich bucket has far fewer
+        // distinct k-mers than instances); a sub-pass that overflows anyway is cut in two by one more selector bit
+        // and counted again -- its siblings are done and stay -- until p = MAX_P, where 1024 *instances* per sub-pass
+        // are guaranteed.
+        const double dpi = c->distinct_per_inst > 0.0 ? std::min(1.0, 2.0 * c->distinct_per_inst) : 0.5;   // (first pass: a guess)
         for (uint32_t i = 0; i < n; ++i) {
             const uint64_t inst = val[2 * i + 1] - val[2 * i];
-            const uint32_t p = std::max<uint32_t>(1, ceil_log2((inst + PER_SUB - 1) / PER_SUB));
-            if (p > 6) { huge.push_back(singles[i]); continue; }
+            // (beyond MAX_P selector bits x 1024 instances the refinement below could not be guaranteed to end)
+            if (ceil_log2((inst + PER_SUB - 1) / PER_SUB) > MAX_P) { huge.push_back(singles[i]); continue; }
+            const uint64_t guess = (uint64_t)((double)inst * dpi) + 1;
+            const uint32_t p = std::max<uint32_t>(1, ceil_log2((guess + PER_SUB - 1) / PER_SUB));
             for (uint32_t k = 0; k < (1u << p); ++k) { sub_items.push_back(singles[i]); sub_words.push_back((p << 8) | k); }
         }
         TRACE("fallback: %zu sub-passes over %zu buckets in LDS tables, %zu buckets in HBM tables", sub_items.size(), singles.size() - huge.size(), huge.size());
-        if (!sub_items.empty()) {
+        while (!sub_items.empty()) {
             DevBuf d_it, d_sub;
             rc = c->alloc(d_it, sub_items.size() * sizeof(ItemRange), "sub-pass items"); if (rc) return rc;
             rc = c->alloc(d_sub, sub_words.size() * 4, "sub-pass words"); if (rc) return rc;
@@ -852,7 +860,15 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
             rc = launch_count<K, NBC>(c, P, (const ItemRange*)d_it.p, sub_items.size(), R, &again, &ignored, (const uint32_t*)d_sub.p);
             c->release(d_it); c->release(d_sub);
             if (rc) return rc;
-            if (!again.empty()) return fail(DFK_E_HIP, "%zu sub-passes overflowed their table (a sub-pass holds at most %llu instances)", again.size(), (unsigned long long)PER_SUB);
+            sub_items.clear(); sub_words.clear();
+            for (const ItemRange& r : again) {                           // {bucket, 0x80000000 | sub-pass word}
+                const uint32_t w = r.b1 & 0x7FFFFFFFu, p = w >> 8, k = w & 0xFFu;
+                if (!(r.b1 & 0x80000000u) || p >= MAX_P)
+                    return fail(DFK_E_HIP, "a sub-pass (%u of 2^%u) of bucket %u overflowed its table (it holds at most %llu instances)", k, p, r.b0, (unsigned long long)PER_SUB);
+                sub_items.push_back(ItemRange{r.b0, r.b0 + 1}); sub_words.push_back(((p + 1) << 8) | k);
+                sub_items.push_back(ItemRange{r.b0, r.b0 + 1}); sub_words.push_back(((p + 1) << 8) | (k + (1u << p)));
+            }
+            if (!sub_items.empty()) TRACE("fallback: %zu sub-passes cut in two", again.size());
         }
         if (!huge.empty()) { rc = launch_count_big<K, NBC>(c, P, huge, R); if (rc) return rc; }
     }

@@ -790,7 +790,7 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
                                                  uint32_t S, uint32_t* n_fill, uint32_t* overflow, uint32_t sub = 0)
 {
     // sub != 0: one of 2^(sub >> 8) sub-passes over a fine bucket too rich for one table -- only the k-mers whose
-    // selector (a mix of the key's low word) equals sub & 0xFF are counted in this one
+    // selector (a mix of the key words, 8 bits) equals sub & 0xFF are counted in this one
     const uint32_t sel_mask = (1u << (sub >> 8)) - 1u, sel = sub & 0xFFu;
     static_assert(COUNT_CHUNK == 32, "one uint4 per lane");
     const uint64_t hidx = 2 * rb + lane;
@@ -815,7 +815,9 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     for (uint32_t t0 = 0; t0 < total_u; t0 += 64) {
         const uint32_t t = t0 + lane;
         Probe A = make_probe<K>(fetch_instance<K>(st, min(t, total_u - 1u)), S, t < total_u);
-        if (SUB) A.active = A.active && (((A.k0 * 0x9E3779B1u) >> 26) & sel_mask) == sel;
+        // (every key word goes into the selector: the k-mers of a hot bucket share their minimizer, often at the
+        // same offset, i.e. whole words of the key)
+        if (SUB) A.active = A.active && ((((A.k0 * 0x9E3779B1u) ^ (A.k1 * 0x85EBCA77u) ^ (A.k2 * 0xC2B2AE3Du) ^ (A.k3 * 0x27D4EB2Fu)) >> 24) & sel_mask) == sel;
 #ifdef DFK_ABLATE_INSERT        // timing experiment only: keep the extraction alive, skip the table
         if ((A.k0 ^ A.k1 ^ A.ctx) == 0x12345u) ++n_claimed;
 #else
@@ -1119,7 +1121,7 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
                     ctl[CTL_STACK + 3 * sp] = b0; ctl[CTL_STACK + 3 * sp + 1] = mid; ctl[CTL_STACK + 3 * sp + 2] = 0u; ++sp;
                     ctl[CTL_SP] = sp;
                     atomicAdd(&g->n_split, 1u);
-                } else overflow_items[atomicAdd(&g->n_overflow, 1u)] = ItemRange{b0, b1};
+                } else overflow_items[atomicAdd(&g->n_overflow, 1u)] = ItemRange{b0, SUB ? (0x80000000u | ctl[CTL_SUB]) : b1};   // (a sub-pass reports which one it was)
             }
             for (uint32_t i = tid; i < (3 + XW) * S; i += NT) cnt[i] = 0;   // abandon the table
             __syncthreads();                                           // everyone has read CTL_OVF before it is reset
