@@ -118,7 +118,7 @@ __host__ __device__ inline uint32_t sweep_class_mask(uint32_t sub_lo, uint32_t s
 }
 
 constexpr int PART_THREADS = 128;
-constexpr int PART_RING = 8;          // words of its read a lane of the counting scan keeps staged in LDS
+constexpr int PART_RING = 2;          // words of its read a lane of the counting scan keeps staged in LDS
 // Per-read run summary written by the counting scan (16 bytes): bits 0-3 = number of runs (super-k-mers) or
 // SUMMARY_OVERFLOW, then from bit 8 twelve bits per run: nk (6) | offset of its minimizer from the run's
 // first k-mer (6, < W).  The scatter passes rebuild each run's bucket from the 2M bits at that offset
@@ -208,8 +208,8 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
     uint32_t* arr = smem;                                        // [W][PART_THREADS] hashes -> suffix minima
     uint32_t* queue = smem + pp.W * PART_THREADS;                // WRITE: [PART_QCAP][2][PART_THREADS]
     uint8_t* sidx = reinterpret_cast<uint8_t*>(smem + pp.W * PART_THREADS);              // !WRITE: [W][PART_THREADS] where each suffix minimum sits
-    uint16_t* rq = reinterpret_cast<uint16_t*>(sidx + pp.W * PART_THREADS);              // !WRITE: [SUMMARY_RUNS][PART_THREADS] run fields
-    uint32_t* ring = reinterpret_cast<uint32_t*>(rq + SUMMARY_RUNS * PART_THREADS);       // !WRITE: [PART_RING][PART_THREADS] words of the read
+    uint32_t* ring = reinterpret_cast<uint32_t*>(sidx + pp.W * PART_THREADS);            // !WRITE: [PART_RING][PART_THREADS] words of the read
+    uint64_t sum_lo = 0, sum_hi = 0;                                                     // !WRITE: the run fields of the summary, packed as they come
     const int tid = threadIdx.x;
     if (WRITE && read_list) { if (r >= n_list) return; r = read_list[r]; }
     const uint32_t M = pp.M, W = pp.W;
@@ -265,7 +265,12 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
             if (lh) { const uint32_t bin = class_bin(cur_b, pp); atomicAdd(&lh[bin], 1u); atomicAdd(&lh[(PART_CLASSES << pp.log2_world) + bin], cur_nk); }
             else atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
             cmask |= 1u << sweep_class_of(cur_b & ((1u << log2_local) - 1u), log2_local);
-            if (qn < (uint32_t)SUMMARY_RUNS) rq[qn * PART_THREADS + tid] = (uint16_t)(cur_nk | (cur_rel << 6));
+            if (qn < (uint32_t)SUMMARY_RUNS) {                          // 12 bits per run from bit 8 (kept in registers: LDS is what limits this kernel's occupancy)
+                const uint64_t fld = cur_nk | (cur_rel << 6);
+                const uint32_t b = 8u + 12u * qn;
+                if (b < 64u) { sum_lo |= fld << b; if (b > 52u) sum_hi |= fld >> (64u - b); }
+                else sum_hi |= fld << (b - 64u);
+            }
             ++qn;
         } else {
             if (qn == PART_QCAP) {        // rare: flush early
@@ -344,16 +349,7 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
     if (!WRITE) {
         // pack the runs: bits 0-3 their number (SUMMARY_OVERFLOW: too many, the read goes through the scanning
         // scatter), then 12 bits per run from bit 8
-        uint64_t lo = qn <= (uint32_t)SUMMARY_RUNS ? qn : SUMMARY_OVERFLOW, hi = 0;
-#pragma unroll
-        for (int i = 0; i < SUMMARY_RUNS; ++i) {
-            const uint64_t fld = (uint32_t)i < qn ? rq[i * PART_THREADS + tid] : 0u;
-            constexpr int B0 = 8;
-            const int b = B0 + 12 * i;
-            if (b + 12 <= 64) lo |= fld << b;
-            else if (b >= 64) hi |= fld << (b - 64);
-            else { lo |= fld << b; hi |= fld >> (64 - b); }
-        }
+        const uint64_t lo = sum_lo | (qn <= (uint32_t)SUMMARY_RUNS ? qn : SUMMARY_OVERFLOW), hi = sum_hi;
         summaries[r] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
         if (read_classes) read_classes[r] = cmask;
         // a read with more runs than a summary holds goes on the list of reads the scanning scatter handles (two in
@@ -395,7 +391,7 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     uint32_t* lh = nullptr;
     const uint32_t n_bins = 2u * (PART_CLASSES << pp.log2_world);
     if (!WRITE && class_hist) {
-        lh = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + 5 * pp.W * PART_THREADS + 2 * SUMMARY_RUNS * PART_THREADS + 4 * PART_RING * PART_THREADS);
+        lh = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + 5 * pp.W * PART_THREADS + 4 * PART_RING * PART_THREADS);
         for (uint32_t i = threadIdx.x; i < n_bins; i += PART_THREADS) lh[i] = 0;
         __syncthreads();
     }
