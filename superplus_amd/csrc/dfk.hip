@@ -1058,10 +1058,12 @@ int stage_adjacency(dfk_ctx* c)
 
 uint32_t pick_log2_nb(uint64_t n_inst, uint32_t log2_world)
 {
-    // fine buckets of ~256-512 instances; an item packs several of them up to its instance budget.
+    // fine buckets of ~430-850 instances (the count is a power of two); an item packs several of them up to its
+    // instance budget.  Measured on configs[1] at K = 40/48/60: 2^27 buckets beat 2^28 (the scan's atomics run on a
+    // 1 GB counter table instead of 2 GB: -7..-23 ms) and 2^26 (items overflow their tables: +190 ms).
     // (When sharded, the record header keeps 24 bits of the bucket id inside the pass for the receiver's
     // regroup: dfk_shard_plan asks for enough passes that a pass has <= 2^24 buckets per owner.)
-    static const uint64_t per = getenv("DFK_INST_PER_BUCKET") ? (uint64_t)atoll(getenv("DFK_INST_PER_BUCKET")) : 512;
+    static const uint64_t per = getenv("DFK_INST_PER_BUCKET") ? (uint64_t)atoll(getenv("DFK_INST_PER_BUCKET")) : 850;
     uint32_t l = ceil_log2(n_inst / per + 1);
     l = std::max<uint32_t>(l, 4 + log2_world);
     return std::min<uint32_t>(l, 28);
