@@ -76,6 +76,7 @@ struct dfk_ctx {
     // and the indices of the n_blist entries that still have unresolved context bits (k_boundary_list)
     struct Part { DevBuf buf, pre; uint64_t n = 0; uint64_t blist = 0, n_blist = 0; bool listed = false; };   // listed: n_blist is all of them
     bool want_blist = false;                  // single-GPU runs: list each part's boundary entries while the next pass is counted
+    int pending_blist = -1;                   // part whose list is still to be launched (see launch_boundary_list)
     std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
     unsigned seg_attempt = 0;                 // the room for a pass's solid k-mers is (estimate << seg_attempt)
@@ -619,6 +620,22 @@ template <int K> unsigned count_grid(const dfk_ctx* c, int nbc = 1)      // pers
     return (unsigned)c->prop.multiProcessorCount * per_cu;
 }
 
+// The boundary list of the part finished last is launched on the second stream once the NEXT pass's k_count is
+// running: launched right after its own pass it streams the part (12 GB) through the window between two counts,
+// where the small kernels of the main stream (overflow reads, cursor check) then take 1-2 ms each instead of 0.2.
+int launch_boundary_list(dfk_ctx* c)
+{
+    if (c->pending_blist < 0) return 0;
+    const dfk_ctx::Part& part = c->parts[(size_t)c->pending_blist];
+    c->pending_blist = -1;
+    unsigned long long* ctl = (unsigned long long*)((char*)part.buf.p + part.blist);
+    HIP_TRY(hipMemsetAsync(ctl, 0, 16, c->stream2));
+    hipLaunchKernelGGL(k_boundary_list, dim3((unsigned)std::min<uint64_t>((part.n + 2047) / 2048, 4096)), dim3(256), 0, c->stream2,
+                       (const uint4*)part.buf.p, part.n, (uint32_t*)(ctl + 2), part.n_blist, ctl);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // one k_count launch over `n_items` device-resident items; overflowed items come back as bucket ranges
 template <int K, int NBC>
 int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint64_t n_items, const CountRun& R,
@@ -641,6 +658,7 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
                        (const uint4*)P.records.p, d_items, (const uint64_t*)P.base.p, cp, R.g, R.seg, (WgOut*)R.d_wg.p, R.hist,
                        (ItemRange*)d_ovf.p, d_sub);
     HIP_TRY(hipGetLastError());
+    rc = launch_boundary_list(c); if (rc) return rc;
     *kernel_ms += tk.stop();
     CountGlobals g{};
     HIP_TRY(hipMemcpyAsync(&g, R.g, sizeof g, hipMemcpyDeviceToHost, c->stream));
@@ -933,14 +951,10 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     if (c->want_blist && nb_part && keep + 16 + 4 * nb_part <= part.buf.bytes && part.n < (1ull << 32)) {
         part.blist = keep; part.n_blist = nb_part; part.listed = true;
         keep += 16 + 4 * nb_part;
-        unsigned long long* ctl = (unsigned long long*)((char*)part.buf.p + part.blist);
-        HIP_TRY(hipMemsetAsync(ctl, 0, 16, c->stream2));
-        hipLaunchKernelGGL(k_boundary_list, dim3((unsigned)std::min<uint64_t>((part.n + 2047) / 2048, 4096)), dim3(256), 0, c->stream2,
-                           (const uint4*)part.buf.p, part.n, (uint32_t*)(ctl + 2), nb_part, ctl);
-        HIP_TRY(hipGetLastError());
     }
     c->shrink(part.buf, keep);
     c->parts.push_back(part);
+    if (part.blist) c->pending_blist = (int)c->parts.size() - 1;     // launched under the next pass's count (launch_boundary_list)
     c->n_solid += part.n; c->st.n_solid = c->n_solid;
     R.solid_seen += part.n; R.inst_seen += P.n_inst;
     if (R.inst_seen) c->distinct_per_inst = (double)hg.n_distinct / (double)R.inst_seen;
@@ -1005,7 +1019,10 @@ int stage_adjacency(dfk_ctx* c)
         // queried from the lists; otherwise by streaming the parts.
         bool listed = c->want_blist;
         for (const dfk_ctx::Part& pt : c->parts) listed = listed && pt.listed;
-        if (c->want_blist) HIP_TRY(hipStreamSynchronize(c->stream2));   // the last part's list is being written there
+        if (c->want_blist) {                                            // the last part's list is still to be made
+            rc = launch_boundary_list(c); if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream2));
+        }
         if (listed) {
             uint64_t total = 0;
             for (const dfk_ctx::Part& pt : c->parts) {
@@ -1187,7 +1204,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
     CountRun R;
     rc = count_run_begin(c, &R); if (rc) return rc;
-    c->want_blist = true;
+    c->want_blist = true; c->pending_blist = -1;
     // Passes over contiguous ranges of the fine buckets, each as large as the free HBM allows.  While a pass is
     // counted (LDS- and issue-bound) the next range is scattered on a second, low-priority stream (bound by
     // scattered atomics and stores): the two kernels share the CUs.  A pass that runs out of room (its estimate
