@@ -451,35 +451,49 @@ template <int K>
 __global__ void __launch_bounds__(256)
 k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
                  const uint32_t* __restrict__ good_len, const int32_t* __restrict__ bc, int64_t ign_bc_below,
-                 uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries,
+                 uint64_t n_reads, PartParams pp, const uint4* __restrict__ summaries, const uint32_t* __restrict__ read_classes,
                  const uint64_t* __restrict__ slice_base,        // [world + 1] first record index of every owner's slice
                  unsigned long long* __restrict__ slice_fill,    // [world] records reserved so far in every slice
                  uint4* __restrict__ records)
 {
     __shared__ uint32_t cnt[256];                                 // per owner: records of this block, then its write cursor
     __shared__ unsigned long long at[256];
+    __shared__ uint16_t list[256 * SLICE_READS];                  // the block's reads that can have a run in this pass (class masks)
+    __shared__ uint32_t n_list;
     const uint32_t world = 1u << pp.log2_world;
-    const uint64_t r_first = (uint64_t)blockIdx.x * 256 * SLICE_READS + threadIdx.x;   // reads r_first + 256 j: neighbouring lanes, neighbouring reads
+    const int lane = threadIdx.x & 63;
+    const uint64_t r_block = (uint64_t)blockIdx.x * 256 * SLICE_READS;
     if (threadIdx.x < world) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) n_list = 0;
     __syncthreads();
+#pragma unroll
     for (int j = 0; j < SLICE_READS; ++j) {
-        const uint64_t r = r_first + 256ull * j;
-        if (r < n_reads)
-            for_each_run_in_pass<K, false>(r, packed, packed_bytes, base_off, pp, summaries,
-                                           [&](uint32_t, uint32_t, uint32_t, uint32_t owner, uint64_t, bool) { atomicAdd(&cnt[owner], 1u); });
+        const uint32_t rel = 256u * j + threadIdx.x;
+        const uint64_t r = r_block + rel;
+        const bool hit = r < n_reads && (!read_classes || (read_classes[r] & pp.class_mask) != 0u);
+        const unsigned long long mk = __ballot(hit);
+        uint32_t w = 0;
+        if (lane == 0 && mk) w = atomicAdd(&n_list, (uint32_t)__popcll(mk));
+        w = __builtin_amdgcn_readfirstlane(w);
+        if (hit) list[w + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)rel;
     }
     __syncthreads();
+    const uint32_t n = n_list;
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        for_each_run_in_pass<K, false>(r_block + list[i], packed, packed_bytes, base_off, pp, summaries,
+                                       [&](uint32_t, uint32_t, uint32_t, uint32_t owner, uint64_t, bool) { atomicAdd(&cnt[owner], 1u); });
+    __syncthreads();
     if (threadIdx.x < world) {
-        const uint32_t n = cnt[threadIdx.x];
-        at[threadIdx.x] = slice_base[threadIdx.x] + (n ? atomicAdd(&slice_fill[threadIdx.x], (unsigned long long)n) : 0ull);
+        const uint32_t m = cnt[threadIdx.x];
+        at[threadIdx.x] = slice_base[threadIdx.x] + (m ? atomicAdd(&slice_fill[threadIdx.x], (unsigned long long)m) : 0ull);
         cnt[threadIdx.x] = 0;
     }
     __syncthreads();
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
     const uint64_t n_words = (packed_bytes + 3) >> 2;
-    for (int j = 0; j < SLICE_READS; ++j) {
-        const uint64_t r = r_first + 256ull * j;
-        if (r >= n_reads) continue;
+    (void)good_len;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint64_t r = r_block + list[i];
         int32_t tag = -1;
         if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
         for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
