@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--K", type=int, default=48)
     ap.add_argument("--minimizer", type=int, default=0)
     ap.add_argument("--inst-per-item", type=int, default=0)
-    ap.add_argument("--cpu-sample-reads", type=int, default=600000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=6000000,
+                    help="reads of the workload the CPU baseline runs on (about 10 s of reference code on 32 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--family-copies", type=int, default=0,
                     help="plant this many diverged copies of one 300-bp element in the genome (hot minimizer buckets)")
