@@ -782,7 +782,7 @@ int count_prepare(dfk_ctx* c, const Partition& P, CountRun& R, int nbc)
     // solid/instance ratio holds to a fraction of a percent (buckets are hash-distributed).
     R.grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(P.n_items, count_grid<K>(c, nbc)));
     uint64_t res = solid_cap(c, R, P.n_inst);
-    if (R.inst_seen) res = std::min<uint64_t>(res, (uint64_t)(1.08 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
+    if (R.inst_seen) res = std::min<uint64_t>(res, (uint64_t)(1.10 * (double)R.solid_seen / (double)R.inst_seen * (double)P.n_inst) + 65536);
     res = (res << attempt) + (uint64_t)R.grid * out_chunk<K>();       // + the chunk ends the workgroups leave empty
     const uint64_t room = c->budget > c->held ? (c->budget - c->held) : 0;
     if (res * 32 > room) res = room / 32;
