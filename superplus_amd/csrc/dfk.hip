@@ -806,7 +806,10 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     Timer t(c->stream);
     std::vector<ItemRange> overflowed;
     c->st.n_items += P.n_items;
+    const float ms_before = c->st.ms_count;
     rc = launch_count<K, NBC>(c, P, (const ItemRange*)P.items.p, P.n_items, R, &overflowed, &c->st.ms_count); if (rc) return rc;
+    TRACE("k_count: %llu instances in %.1f ms (%.1f G instances/s), reservation %.2f GB", (unsigned long long)P.n_inst, c->st.ms_count - ms_before,
+          1e-6 * (double)P.n_inst / (double)(c->st.ms_count - ms_before), R.d_part.bytes / 1e9);
     t.start();
     // items that overflowed their LDS table are halved by bucket index and retried; a single fine bucket
     // that still overflows is counted in an HBM table
@@ -1175,7 +1178,7 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
     // moves a range's records about 1.5 times as fast as k_count counts them, after ~10 ms of reading masks)
     if (running && overlap) n = std::min(n, 1.3 * (double)running->n_buckets);
     if (left <= 0.99 * fit && left < 1.06 * n) n = left;              // no sliver of a last pass if the rest (almost certainly) fits
-    else if (left > n && left < 1.3 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big and a small one
+    else if (left > n && left < 1.7 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big and a small one
     n = std::min(n, left);
     if (n < 16.0) return running ? 0u : (uint32_t)std::min(16.0, left);
     return (uint32_t)n;
