@@ -81,3 +81,38 @@ def test_exchange_routing_gloo(world, piece):
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
     assert len({r[2] for r in res}) == 1
+
+
+def _single(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from superplus_amd.dist import TorchComm, exchange
+        comm = TorchComm()
+        send = torch.arange(96, dtype=torch.uint8)
+        recv, rc = exchange(send, [3], 32, comm)                   # a rank alone keeps its slice: a copy, no message
+        assert rc == [3] and torch.equal(recv, send)
+        out = torch.empty(64, dtype=torch.uint8)
+        for bad in (([32], [96]), ([64], [64])):                   # splits that do not cover the buffers / do not agree
+            try:
+                comm.all_to_all_single(out, send, bad[0], bad[1])
+                q.put("no error for %r" % (bad,)); return
+            except ValueError:
+                pass
+        q.put("ok")
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put("fail: " + traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_and_bad_splits():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single, args=(29400 + int(np.random.default_rng().integers(0, 90)), q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(timeout=60)
+    assert res == "ok", res
