@@ -50,7 +50,7 @@ typedef struct dfk_config {
     uint32_t min_bc;            /* MIN_BC,   default 2; 0..4 */
     int32_t  device;            /* HIP device ordinal */
     int64_t  ign_bc_below;      /* createDict ignBcBelow (= bc_start, DF.cc:344-349) */
-    uint64_t hbm_budget_bytes;  /* 0 = 90 % of free HBM (mem_frac analogue, GRAPHMEM=0.9) */
+    uint64_t hbm_budget_bytes;  /* 0 = 90 % of free HBM (mem_frac analogue, GRAPHMEM=0.9); larger requests are clamped to that */
     uint32_t minimizer_len;     /* 0 = default; 8..16 */
     uint32_t flags;             /* DFK_F_* */
     uint64_t inst_per_item;     /* 0 = default; k-mer instances packed into one LDS table pass */
@@ -106,6 +106,11 @@ int         dfk_abi_version(void);
  * Runs: quality-tail trim (:218-225), canonical k-mer extraction with contexts (:148-165),
  * counting and the MIN_FREQ/MIN_BC solid filter (:167-174), the spectrum (:192-209) and
  * recomputeAdjacencies (ReadPather.h:329-364, gated by minFreq > 1 as at :313). */
+/* Input contract (both calls): the offset tables are checked on the device before anything is read through them
+ * (monotone, last offset <= the array size, base_off[r+1]-base_off[r] >= ceil(read_len[r]/4)) and a violation is
+ * DFK_E_INPUT.  packed_bases need not start at the first read (a mapped .fastb file with its absolute offset table
+ * is a valid input).  Device arrays: packed_bases 4-byte aligned and readable up to 3 bytes past packed_bytes (the
+ * 2-bit stream is read as aligned 32-bit words); the offset tables 8-byte aligned. */
 int dfk_count(dfk_ctx* ctx,
               const uint8_t* packed_bases, const uint64_t* base_off, const uint32_t* read_len,
               const uint8_t* pq_bytes, const uint64_t* pq_off, const int32_t* bc,
@@ -146,8 +151,15 @@ int dfk_solid_fetch_unsorted(dfk_ctx* ctx, dfk_entry32* out, uint64_t cap, int p
 int dfk_solid_digest(dfk_ctx* ctx, int pre_adjacency, uint64_t* digest /* [2] */);
 
 /* kmers.kvec image ("BINWRITE" | u64 n | n x 32-B entries; BuildReadQGraph48.cc:287-288,
- * feudal/BinaryStream.h:33-46) written straight to a file. */
-int dfk_write_kvec(dfk_ctx* ctx, const char* path, int pre_adjacency);
+ * feudal/BinaryStream.h:33-46) written straight to a file, streamed from the device in the order the
+ * device holds the entries -- the reference's own file is in thread-arrival order (ReadPather.h:406-418)
+ * and its reader inserts the entries into a hash set (BuildReadQGraph48.cc:294-301), so no order is
+ * promised by either side.  flags: DFK_KVEC_PRE_ADJ = contexts before recomputeAdjacencies (needs
+ * DFK_F_KEEP_PRE_ADJ); DFK_KVEC_SORTED = ascending (w0,w1), sorted on the host (parity tests: needs two
+ * host copies of the dictionary). */
+#define DFK_KVEC_PRE_ADJ 1
+#define DFK_KVEC_SORTED  2
+int dfk_write_kvec(dfk_ctx* ctx, const char* path, int flags);
 
 int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
 

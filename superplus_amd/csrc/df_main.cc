@@ -8,28 +8,43 @@
 //          work_dir/subsam.{names,starts}                                    (DF.cc:263-265,477-482)
 //          work_dir/stats/histogram_kmer_count.json          WriteKmerSpectrum (BuildReadQGraph48.cc:283-285)
 //          work_dir/kmers.kvec                               the dictionary  (BuildReadQGraph48.cc:287-288)
-//
 //          work_dir/data/frag_reads_orig.1000.{fastb,qualp}  WriteSubSample  (10X/DfTools.cc:32-67)
 //
-// The hot path itself runs in libdfk (HIP); this file is host plumbing only.  Not reproduced: everything
-// after createDict (graph build, pathing, the other seven stages), which are out of scope.
+// The hot path itself runs in libdfk (HIP); this file is host plumbing only -- but plumbing for 1.8 G reads:
+// the inputs are mapped, not copied; the one-input LR_SELECT_FRAC=1 case (what runall.sh:127 runs) re-emits
+// the read files as parallel range copies while the GPU counts; lens, the quality histogram and the barcode
+// expansion run on NUM_THREADS host threads.  Not reproduced: everything after createDict (graph build,
+// pathing, the other seven stages), which are out of scope.
+//
+// Arguments beyond the reference's: HBM_GB= (device memory the library may use; 0 = 90 % of what is free --
+// MAX_MEM_GB keeps its reference meaning, a HOST memory cap (system/System.cc:1073-1078), and is not a device
+// budget), DEVICE=, KVEC= / KVEC_SORTED= (write kmers.kvec; in ascending k-mer order), MINIMIZER=.
 #include "../../include/dfk.h"
 #include "feudal_io.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <ctime>
+#include <fcntl.h>
+#include <functional>
+#include <exception>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <thread>
 #include <unistd.h>
 
 namespace {
 
 std::string date()
 { time_t t = time(nullptr); char b[64]; strftime(b, sizeof b, "%a %b %d %H:%M:%S %Y", localtime(&t)); return b; }
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void mkpath(const std::string& p)
 {
@@ -72,26 +87,179 @@ struct RefRandom {
 struct DataSet { uint8_t dt; uint8_t pad[7]; int64_t start; };   // 10X/DfTools.h:23-45; dt 2 = UNBAR_10X, 3 = BAR_10X
 static_assert(sizeof(DataSet) == 16, "DataSet is 16 bytes");
 
+unsigned g_threads = 1;
+
+// fn(t, lo, hi) over [0, n) cut into one contiguous range per thread
+void parallel_ranges(uint64_t n, const std::function<void(unsigned, uint64_t, uint64_t)>& fn, uint64_t min_per_thread = 1 << 16)
+{
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g_threads, n / std::max<uint64_t>(1, min_per_thread)));
+    if (T <= 1) { fn(0, 0, n); return; }
+    std::vector<std::thread> th;
+    std::exception_ptr err; std::atomic<bool> failed{false};
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([&, t] { try { fn(t, n * t / T, n * (t + 1) / T); } catch (...) { if (!failed.exchange(true)) err = std::current_exception(); } });
+    for (auto& x : th) x.join();
+    if (failed) std::rethrow_exception(err);
+}
+
+// unaligned little-endian loads (tables inside a mapped feudal file sit wherever the var data ends)
+inline uint64_t ld64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline uint32_t ld32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+struct Mapped {
+    const uint8_t* p = nullptr; size_t n = 0; int fd = -1;
+    void open(const std::string& path)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat s; if (fstat(fd, &s) != 0) throw std::runtime_error("cannot stat " + path);
+        n = (size_t)s.st_size;
+        if (n) {
+            void* m = mmap(nullptr, n, PROT_READ, MAP_SHARED, fd, 0);
+            if (m == MAP_FAILED) throw std::runtime_error("cannot map " + path);
+            p = (const uint8_t*)m;
+            (void)madvise(m, n, MADV_WILLNEED);
+        }
+    }
+    ~Mapped() { if (p) munmap((void*)p, n); if (fd >= 0) close(fd); }
+};
+
+// a mapped feudal file: control block, var data, absolute offset table, fixed data (feudal_io.h has the layout)
+struct FeudalMap {
+    Mapped m; std::string path; uint64_t n = 0, varTab = 0, fixedOff = 0;
+    void open(const std::string& pth)
+    {
+        path = pth; m.open(pth);
+        if (m.n < 24) throw std::runtime_error(path + ": too short for a feudal file");
+        feudal::Header h; memcpy(&h, m.p, 24);
+        if ((h.flags & 3) != 1) throw std::runtime_error(path + ": not a single-file feudal file");
+        if (h.varTab < 24 || h.fixedOff < h.varTab || h.fixedOff > m.n || (h.fixedOff - h.varTab) % 8 || h.fixedOff == h.varTab)
+            throw std::runtime_error(path + ": inconsistent feudal control block");
+        n = (h.fixedOff - h.varTab) / 8 - 1; varTab = h.varTab; fixedOff = h.fixedOff;
+        if ((uint32_t)n != h.n) throw std::runtime_error(path + ": element count mismatch");
+        // offsets: absolute, inside the var data, ascending
+        std::atomic<bool> bad{false};
+        parallel_ranges(n + 1, [&](unsigned, uint64_t lo, uint64_t hi) {
+            uint64_t prev = lo ? off(lo - 1) : 24;
+            for (uint64_t i = lo; i < hi; ++i) { const uint64_t o = off(i); if (o < prev || o > varTab) { bad = true; return; } prev = o; }
+        });
+        if (bad) throw std::runtime_error(path + ": offset table is not ascending or runs past the data");
+    }
+    uint64_t off(uint64_t i) const { return ld64(m.p + varTab + 8 * i); }       // absolute file offset of element i
+    const uint8_t* off_table() const { return m.p + varTab; }
+    const uint8_t* fixed() const { return m.p + fixedOff; }
+};
+
+// pwrite the whole range, from several threads
+void write_range(int fd, const uint8_t* src, uint64_t bytes, uint64_t file_off)
+{
+    constexpr uint64_t PIECE = 8ull << 20;
+    const uint64_t n_pieces = (bytes + PIECE - 1) / PIECE;
+    std::atomic<uint64_t> next{0};
+    std::atomic<bool> bad{false};
+    auto work = [&] {
+        for (uint64_t i; (i = next.fetch_add(1)) < n_pieces && !bad;) {
+            const uint64_t o = i * PIECE, len = std::min(PIECE, bytes - o);
+            for (uint64_t done = 0; done < len;) {
+                const ssize_t w = pwrite(fd, src + o + done, len - done, (off_t)(file_off + o + done));
+                if (w <= 0) { bad = true; return; }
+                done += (uint64_t)w;
+            }
+        }
+    };
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g_threads, n_pieces));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    if (bad) throw std::runtime_error("short write");
+}
+
+// A feudal file re-emitted from its mapped image: our control block (the reference's writer constants), then the
+// var data, offset table and fixed data as they are.
+void copy_feudal(const FeudalMap& in, const std::string& path, uint8_t szFixed, uint8_t szX, uint8_t szA)
+{
+    const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) throw std::runtime_error("cannot create " + path);
+    feudal::Header h{(uint32_t)in.n, 1, szFixed, szX, szA, in.varTab, in.fixedOff};
+    bool ok = pwrite(fd, &h, 24, 0) == 24;
+    if (ok) { try { write_range(fd, in.m.p + 24, in.m.n - 24, 24); } catch (...) { ok = false; } }
+    ok = (close(fd) == 0) && ok;
+    if (!ok) throw std::runtime_error("short write " + path);
+}
+
+// GetQualStats (10X/DfTools.cc:172-238): hist[parity][pos][q] over all reads, q in 0..255 while counting.  A block
+// of equal quals (nBits = 0: every constant-quality stretch) is booked as a +1/-1 pair on a per-(parity,q) difference
+// row and integrated at the end; other blocks base by base.
+struct QualHist {
+    int max_len; std::vector<int64_t> direct, diff;   // [2][max_len][256], [2][256][max_len + 1]
+    explicit QualHist(int ml) : max_len(ml), direct((size_t)2 * ml * 256, 0), diff((size_t)2 * 256 * (ml + 1), 0) {}
+    void add_read(uint64_t r, const uint8_t* p, const uint8_t* end)
+    {
+        const size_t par = r & 1;
+        int pos = 0;
+        while (p < end && *p) {                                            // PQVec blocks (feudal/PQVec.cc:87-127)
+            if (p + 3 > end) break;
+            const unsigned nQs = p[0], hdr = p[1] | (p[2] << 8), nBits = hdr & 7, minQ = (hdr >> 3) & 63;
+            const uint64_t blk = ((uint64_t)nQs * nBits + 24) >> 3;
+            if (p + blk > end) break;
+            if (nBits == 0) {
+                const int a = std::min(pos, max_len), b = std::min(pos + (int)nQs, max_len);
+                int64_t* row = &diff[(par * 256 + minQ) * (size_t)(max_len + 1)];
+                row[a]++; row[b]--;
+                pos += (int)nQs;
+            } else {
+                uint64_t bit = 17;
+                for (unsigned i = 0; i < nQs; ++i, bit += nBits) {
+                    const unsigned w = p[bit >> 3] | ((bit >> 3) + 1 < blk ? (unsigned)p[(bit >> 3) + 1] << 8 : 0u);
+                    const unsigned q = minQ + ((w >> (bit & 7)) & ((1u << nBits) - 1));
+                    if (pos < max_len) direct[(par * max_len + pos) * 256 + q]++;
+                    ++pos;
+                }
+            }
+            p += blk;
+        }
+    }
+    void merge_into(std::vector<int64_t>& total) const            // total: [2][max_len][256]
+    {
+        for (size_t i = 0; i < direct.size(); ++i) total[i] += direct[i];
+        for (size_t par = 0; par < 2; ++par)
+            for (size_t q = 0; q < 256; ++q) {
+                const int64_t* row = &diff[(par * 256 + q) * (size_t)(max_len + 1)];
+                int64_t run = 0;
+                for (int pos = 0; pos < max_len; ++pos) { run += row[pos]; total[(par * max_len + pos) * 256 + q] += run; }
+            }
+    }
+};
+
+struct Timing { double read = 0, ingest_out = 0, upload = 0, count = 0, fetch_write = 0, total = 0; };
+
 } // namespace
 
 int main(int argc, char** argv)
 {
+    const double t_start = now_s();
     std::map<std::string, std::string> a = {
         {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
         {"OUT_DIR", ""}, {"LR", ""}, {"LR_SELECT_FRAC", "1.0"}, {"EXIT_LOAD", "False"}, {"DEVICE", "0"}, {"MAX_MEM_GB", "0"},
-        {"MINIMIZER", "0"}, {"KVEC", "True"}};
+        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "True"}, {"KVEC_SORTED", "False"}};
     std::string command = "DF";
     for (int i = 1; i < argc; ++i) {
         std::string s = argv[i]; command += " " + s;
         size_t eq = s.find('=');
         if (eq == std::string::npos) give_up("DF: arguments are KEY=VALUE; got '" + s + "'");
-        a[s.substr(0, eq)] = s.substr(eq + 1);        // other reference arguments (PIPELINE, ALIGN, NUM_THREADS ...) are accepted and unused
+        a[s.substr(0, eq)] = s.substr(eq + 1);        // other reference arguments (PIPELINE, ALIGN, ...) are accepted and unused
     }
     const unsigned K = (unsigned)atoi(a["K"].c_str());
     if (K != 40 && K != 48 && K != 60) give_up("K must be 40, 48 or 60");                        // DF.cc:209
     if (a["LR"].empty()) give_up("I'm not sure you really want to do this, since it may\ndelete your starting files.  So I'm going to quit.");
     std::vector<double> select_frac;
     for (const std::string& f : parse_set(a["LR_SELECT_FRAC"])) select_frac.push_back(atof(f.c_str()));
+    {   // NUM_THREADS: SetThreads (system/System.cc:1031-1046): <= 0 means all the machine has
+        const int nt = atoi(a["NUM_THREADS"].c_str());
+        g_threads = nt > 0 ? (unsigned)nt : std::max(1u, std::thread::hardware_concurrency());
+        g_threads = std::min(g_threads, 64u);
+    }
 
     std::string work_dir = a["ROOT"] + "/GapToy/" + a["INSTANCE"];                                  // DF.cc:221-222
     if (!a["OUT_DIR"].empty()) work_dir = a["OUT_DIR"];
@@ -106,104 +274,153 @@ int main(int argc, char** argv)
             give_up("Can't file your LR input files " + head + ".*.");                             // DF.cc:251-258
         heads.push_back(head);
     }
+    Timing T;
     try {
-        auto t0 = std::chrono::steady_clock::now();
         // ---- LoadData (10X/DfTools.cc:69-170): unbarcoded pairs of every input first, then barcoded pairs
         //      barcode by barcode; bci rebuilt; pairs stay together (even = R1, odd = R2).
         printf("%s: reading in linked read data\n", date().c_str());
-        struct In { std::vector<uint8_t> packed, pq; std::vector<uint64_t> boff, qoff; std::vector<uint32_t> len; std::vector<int64_t> bci; };
+        double t0 = now_s();
+        struct In { FeudalMap fb, qp; std::vector<int64_t> bci; };
         std::vector<In> ins(heads.size());
         for (size_t i = 0; i < heads.size(); ++i) {
-            feudal::read_fastb(heads[i] + ".fastb", &ins[i].packed, &ins[i].boff, &ins[i].len);
-            feudal::read_qualp(heads[i] + ".qualp", &ins[i].pq, &ins[i].qoff);
-            ins[i].bci = feudal::read_bci(heads[i] + ".bci");
-            const In& x = ins[i];
-            if (x.qoff.size() != x.boff.size()) throw std::runtime_error(heads[i] + ": .fastb and .qualp disagree on the number of reads");
+            In& x = ins[i];
+            x.fb.open(heads[i] + ".fastb");
+            x.qp.open(heads[i] + ".qualp");
+            x.bci = feudal::read_bci(heads[i] + ".bci");
+            if (x.qp.n != x.fb.n) throw std::runtime_error(heads[i] + ": .fastb and .qualp disagree on the number of reads");
+            if (x.fb.m.n - x.fb.fixedOff < 4 * x.fb.n) throw std::runtime_error(heads[i] + ".fastb: fixed data too short");
             if (x.bci.size() < 2 || x.bci[0] != 0) throw std::runtime_error("barcode 0 is unbarcoded data and must start at 0");
-            if (x.bci[1] % 2 || (uint64_t)x.bci[1] > x.len.size() || (uint64_t)x.bci.back() > x.len.size())
+            if (x.bci[1] % 2 || (uint64_t)x.bci[1] > x.fb.n || (uint64_t)x.bci.back() > x.fb.n)
                 throw std::runtime_error(heads[i] + ": .bci does not describe these reads");
+            for (size_t b = 0; b + 1 < x.bci.size(); ++b)
+                if (x.bci[b] > x.bci[b + 1]) throw std::runtime_error(heads[i] + ": .bci is not ascending");
+            std::atomic<bool> bad{false};
+            parallel_ranges(x.fb.n, [&](unsigned, uint64_t lo, uint64_t hi) {
+                for (uint64_t r = lo; r < hi; ++r)
+                    if (x.fb.off(r + 1) - x.fb.off(r) != ((uint64_t)ld32(x.fb.fixed() + 4 * r) + 3) / 4) { bad = true; return; }
+            });
+            if (bad) throw std::runtime_error(heads[i] + ".fastb: read length disagrees with its byte count");
         }
-        feudal::Reads R;
-        std::vector<int64_t> bci{0};
-        std::vector<DataSet> datasets;
-        R.base_off.push_back(0); R.pq_off.push_back(0);
-        // every pair asks the reference's random stream whether it stays (DfTools.cc:115-117): always at
-        // LR_SELECT_FRAC = 1, but the number is drawn all the same, and WriteSubSample continues the stream
         if (select_frac.size() == 1 && heads.size() > 1) select_frac.assign(heads.size(), select_frac[0]);
         if (select_frac.size() != heads.size()) throw std::runtime_error("LR_SELECT_FRAC needs one value per LR input");   // DfTools.cc:96
-        RefRandom rng;
-        auto append = [&](const In& x, double frac, int64_t lo, int64_t hi) {
-            for (int64_t r = lo; r + 1 < hi + (hi - lo) % 2; r += 2) {
-                if (!((1. * rng.next() / 2147483647.0) <= frac)) continue;
-                for (int64_t k = r; k < std::min<int64_t>(r + 2, hi); ++k) {
-                    R.packed.insert(R.packed.end(), x.packed.begin() + x.boff[k], x.packed.begin() + x.boff[k + 1]);
-                    R.pq.insert(R.pq.end(), x.pq.begin() + x.qoff[k], x.pq.begin() + x.qoff[k + 1]);
-                    R.base_off.push_back(R.base_off.back() + (x.boff[k + 1] - x.boff[k]));
-                    R.pq_off.push_back(R.pq_off.back() + (x.qoff[k + 1] - x.qoff[k]));
-                    R.read_len.push_back(x.len[k]);
-                }
-            }
-        };
-        for (size_t i = 0; i < ins.size(); ++i) {                                                   // PASS_UNBARCODED
-            DataSet d{}; d.dt = 2; d.start = (int64_t)R.size(); datasets.push_back(d);
-            append(ins[i], select_frac[i], 0, ins[i].bci[1]);
-        }
-        for (size_t i = 0; i < ins.size(); ++i) {                                                   // PASS_BARCODED
-            const In& x = ins[i];
-            DataSet d{}; d.dt = 3; d.start = (int64_t)R.size(); datasets.push_back(d);
-            for (size_t b = 1; b + 1 < x.bci.size(); ++b) { bci.push_back((int64_t)R.size()); append(x, select_frac[i], x.bci[b], x.bci[b + 1]); }
-        }
-        bci.push_back((int64_t)R.size());
-        ins.clear();
+        T.read = now_s() - t0;
+
+        // The arrays createDict sees.  Fast path (one input, every pair kept, every barcode an even number of reads:
+        // what ParseBarcodedFastqs writes and runall.sh:127 passes): LoadData's order IS the input's order, so the
+        // mapped files are the arrays -- var data addressed through the files' own absolute offset tables.
+        bool fast = heads.size() == 1 && select_frac[0] >= 1.0;
+        if (fast) for (size_t b = 0; b + 1 < ins[0].bci.size(); ++b) if ((ins[0].bci[b + 1] - ins[0].bci[b]) % 2) { fast = false; break; }
+        if (fast && (uint64_t)ins[0].bci.back() != ins[0].fb.n) fast = false;
+        feudal::Reads R;                                  // general path only
+        std::vector<int64_t> bci;
+        std::vector<DataSet> datasets;
+        uint64_t n_reads = 0;
+        const uint8_t *h_packed, *h_boff, *h_len, *h_pq, *h_qoff;   // (possibly unaligned: inside mapped files)
         const std::string rh = work_dir + "/data/frag_reads_orig";
-        feudal::write_fastb(rh + ".fastb", R.packed.data(), R.base_off, R.read_len);
-        feudal::write_qualp(rh + ".qualp", R.pq.data(), R.pq_off);
-        { feudal::BinWriter w(rh + ".bci"); w.vec(bci); }
-        {
+        RefRandom rng;
+        std::vector<std::thread> background;              // output files written while the GPU counts
+        std::exception_ptr bg_err; std::atomic<bool> bg_failed{false};
+        struct Joiner { std::vector<std::thread>& v; ~Joiner() { for (auto& t : v) if (t.joinable()) t.join(); } } joiner{background};
+        auto in_background = [&](std::function<void()> fn) {
+            background.emplace_back([&, fn] { try { fn(); } catch (...) { if (!bg_failed.exchange(true)) bg_err = std::current_exception(); } });
+        };
+        t0 = now_s();
+        if (fast) {
+            In& x = ins[0];
+            n_reads = x.fb.n; bci = x.bci;
+            DataSet d{}; d.dt = 2; d.start = 0; datasets.push_back(d);
+            d.dt = 3; d.start = x.bci[1]; datasets.push_back(d);
+            h_packed = x.fb.m.p; h_boff = x.fb.off_table(); h_len = x.fb.fixed();
+            h_pq = x.qp.m.p; h_qoff = x.qp.off_table();
+            in_background([&] { copy_feudal(x.fb, rh + ".fastb", 4, 16, 1); copy_feudal(x.qp, rh + ".qualp", 0, 8, 1); });
+            { feudal::BinWriter w(rh + ".bci"); w.vec(bci); }
+        } else {
+            R.base_off.push_back(0); R.pq_off.push_back(0);
+            bci.push_back(0);
+            // every pair asks the reference's random stream whether it stays (DfTools.cc:115-117): always at
+            // LR_SELECT_FRAC = 1, but the number is drawn all the same, and WriteSubSample continues the stream
+            auto append = [&](const In& x, double frac, int64_t lo, int64_t hi) {
+                for (int64_t r = lo; r + 1 < hi + (hi - lo) % 2; r += 2) {
+                    if (!((1. * rng.next() / 2147483647.0) <= frac)) continue;
+                    for (int64_t k = r; k < std::min<int64_t>(r + 2, hi); ++k) {
+                        const uint64_t b0 = x.fb.off(k), b1 = x.fb.off(k + 1), q0 = x.qp.off(k), q1 = x.qp.off(k + 1);
+                        R.packed.insert(R.packed.end(), x.fb.m.p + b0, x.fb.m.p + b1);
+                        R.pq.insert(R.pq.end(), x.qp.m.p + q0, x.qp.m.p + q1);
+                        R.base_off.push_back(R.base_off.back() + (b1 - b0));
+                        R.pq_off.push_back(R.pq_off.back() + (q1 - q0));
+                        R.read_len.push_back(ld32(x.fb.fixed() + 4 * k));
+                    }
+                }
+            };
+            for (size_t i = 0; i < ins.size(); ++i) {                                                   // PASS_UNBARCODED
+                DataSet d{}; d.dt = 2; d.start = (int64_t)R.size(); datasets.push_back(d);
+                append(ins[i], select_frac[i], 0, ins[i].bci[1]);
+            }
+            for (size_t i = 0; i < ins.size(); ++i) {                                                   // PASS_BARCODED
+                const In& x = ins[i];
+                DataSet d{}; d.dt = 3; d.start = (int64_t)R.size(); datasets.push_back(d);
+                for (size_t b = 1; b + 1 < x.bci.size(); ++b) { bci.push_back((int64_t)R.size()); append(x, select_frac[i], x.bci[b], x.bci[b + 1]); }
+            }
+            bci.push_back((int64_t)R.size());
+            ins.clear();
+            n_reads = R.size();
+            h_packed = R.packed.data(); h_boff = (const uint8_t*)R.base_off.data(); h_len = (const uint8_t*)R.read_len.data();
+            h_pq = R.pq.data(); h_qoff = (const uint8_t*)R.pq_off.data();
+            feudal::write_fastb(rh + ".fastb", R.packed.data(), R.base_off, R.read_len);
+            feudal::write_qualp(rh + ".qualp", R.pq.data(), R.pq_off);
+            { feudal::BinWriter w(rh + ".bci"); w.vec(bci); }
+        }
+        auto boff = [&](uint64_t r) { return ld64(h_boff + 8 * r); };
+        auto qoff = [&](uint64_t r) { return ld64(h_qoff + 8 * r); };
+        auto rlen = [&](uint64_t r) { return ld32(h_len + 4 * r); };
+        auto subsample = [&, n_reads] {
             // WriteSubSample(bases, quals, 500, ".../frag_reads_orig.1000") (DfTools.cc:32-67,169), on the same stream.
             // A pair is kept when its draw says so, or when only as many are left as are wanted.
-            const size_t n = R.size();
-            size_t want = std::min<size_t>(n / 2, 500);
+            const uint64_t n = n_reads;
+            uint64_t want = std::min<uint64_t>(n / 2, 500);
             const double frac = n / 2 ? (double)want / (double)(n / 2) : 0.0;
             std::vector<uint8_t> sp, sq; std::vector<uint64_t> so{0}, sqo{0}; std::vector<uint32_t> sl;
-            for (size_t i = 0; i + 1 < n && want; i += 2) {
+            for (uint64_t i = 0; i + 1 < n && want; i += 2) {
                 const bool take = (1. * rng.next() / 2147483647.0) <= frac;
                 if (!(take || want * 2 >= n - i)) continue;
-                for (size_t k = i; k < i + 2; ++k) {
-                    sp.insert(sp.end(), R.packed.begin() + R.base_off[k], R.packed.begin() + R.base_off[k + 1]); so.push_back(sp.size());
-                    sq.insert(sq.end(), R.pq.begin() + R.pq_off[k], R.pq.begin() + R.pq_off[k + 1]); sqo.push_back(sq.size());
-                    sl.push_back(R.read_len[k]);
+                for (uint64_t k = i; k < i + 2; ++k) {
+                    sp.insert(sp.end(), h_packed + boff(k), h_packed + boff(k + 1)); so.push_back(sp.size());
+                    sq.insert(sq.end(), h_pq + qoff(k), h_pq + qoff(k + 1)); sqo.push_back(sq.size());
+                    sl.push_back(rlen(k));
                 }
                 --want;
             }
             feudal::write_fastb(rh + ".1000.fastb", sp.data(), so, sl);
             feudal::write_qualp(rh + ".1000.qualp", sq.data(), sqo);
-        }
-        printf("%s: loaded %zu reads\n", date().c_str(), R.size());
+        };
+        // fast path: the reference's random stream is advanced by one draw per pair in LoadData (all kept), then
+        // WriteSubSample draws once more per pair -- 2 x 10^9 sequential draws at human scale, off the critical path
+        if (fast) in_background([&, subsample] { for (uint64_t i = 0; i < n_reads / 2; ++i) (void)rng.next(); subsample(); });
+        else subsample();
+        printf("%s: loaded %llu reads\n", date().c_str(), (unsigned long long)n_reads);
         for (const DataSet& d : datasets) printf("\t%s starts at %ld\n", d.dt == 2 ? "UNBAR_10X" : "BAR_10X", (long)d.start);
 
         // ---- lens, quality histogram, datasets (DF.cc:50-68, DfTools.cc:172-238)
-        std::vector<int16_t> lens(R.size()); int max_len = 0;
-        for (size_t i = 0; i < R.size(); ++i) { lens[i] = (int16_t)R.read_len[i]; max_len = std::max<int>(max_len, lens[i]); }
+        std::vector<int16_t> lens(n_reads);
+        std::vector<int> tmax(g_threads + 1, 0);
+        parallel_ranges(n_reads, [&](unsigned t, uint64_t lo, uint64_t hi) {
+            int m = 0;
+            for (uint64_t i = lo; i < hi; ++i) { lens[i] = (int16_t)rlen(i); m = std::max<int>(m, lens[i]); }
+            tmax[t] = m;
+        });
+        const int max_len = *std::max_element(tmax.begin(), tmax.end());
         printf("%s: computing quality histogram\n", date().c_str());
         std::vector<int64_t> qh((size_t)2 * max_len * 256, 0);                  // [parity][pos][q]
-        int max_q = -1;
-        for (size_t r = 0; r < R.size(); ++r) {
-            const uint8_t* p = R.pq.data() + R.pq_off[r]; const uint8_t* end = R.pq.data() + R.pq_off[r + 1];
-            int pos = 0;
-            while (p < end && *p) {                                            // PQVec blocks (feudal/PQVec.cc:87-127)
-                unsigned nQs = p[0], hdr = p[1] | (p[2] << 8), nBits = hdr & 7, minQ = (hdr >> 3) & 63;
-                uint64_t bit = 17;
-                for (unsigned i = 0; i < nQs; ++i, bit += nBits) {
-                    unsigned v = 0;
-                    for (unsigned b = 0; b < nBits; ++b) v |= ((p[(bit + b) >> 3] >> ((bit + b) & 7)) & 1u) << b;
-                    int q = (int)(minQ + v);
-                    if (pos < max_len) { qh[((r & 1) * max_len + pos) * 256 + q]++; max_q = std::max(max_q, q); }
-                    ++pos;
-                }
-                p += ((uint64_t)nQs * nBits + 24) >> 3;
-            }
+        {
+            std::vector<std::unique_ptr<QualHist>> part(g_threads + 1);
+            parallel_ranges(n_reads, [&](unsigned t, uint64_t lo, uint64_t hi) {
+                part[t].reset(new QualHist(max_len));
+                for (uint64_t r = lo; r < hi; ++r) part[t]->add_read(r, h_pq + qoff(r), h_pq + qoff(r + 1));
+            });
+            for (const auto& p : part) if (p) p->merge_into(qh);
         }
+        int max_q = -1;
+        for (size_t i = 0; i < qh.size(); ++i) if (qh[i]) max_q = std::max(max_q, (int)(i & 255));
         { feudal::BinWriter w(rh + ".lens"); w.vec(lens); }
         { feudal::BinWriter w(rh + ".qhist");                                   // vec<vec<vec<int64_t>>> [2][max_len][max_q+1]
           w.pod<uint64_t>(2);
@@ -211,37 +428,61 @@ int main(int argc, char** argv)
               w.pod<uint64_t>((uint64_t)max_len);
               for (int pos = 0; pos < max_len; ++pos) { w.pod<uint64_t>((uint64_t)(max_q + 1)); w.raw(&qh[((size_t)par * max_len + pos) * 256], 8 * (size_t)(max_q + 1)); }
           } }
+        { std::vector<int16_t>().swap(lens); }
         { feudal::BinWriter w(rh + ".dti"); w.vec(datasets); }
         { feudal::BinWriter w(work_dir + "/subsam.names"); w.pod<uint64_t>(1); w.str("C"); }
         { feudal::BinWriter w(work_dir + "/subsam.starts"); w.vec(std::vector<int64_t>{0}); }
-        if (truthy(a["EXIT_LOAD"])) return 0;                                   // DF.cc:483
+        T.ingest_out = now_s() - t0;
+        auto join_background = [&] {
+            for (auto& x : background) x.join();
+            background.clear();
+            if (bg_failed) std::rethrow_exception(bg_err);
+        };
+        if (truthy(a["EXIT_LOAD"])) { join_background(); return 0; }            // DF.cc:483
 
         // ---- barcode expansion (DF.cc:447-452) and createDict on the GPU
-        std::vector<int32_t> bc(R.size(), 0);
-        for (size_t b = 0; b + 1 < bci.size(); ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
+        std::vector<int32_t> bc(n_reads, 0);
+        parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t lo, uint64_t hi) {
+            for (uint64_t b = lo; b < hi; ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
+        }, 1024);
         dfk_config cfg{};
         cfg.abi_version = DFK_ABI_VERSION; cfg.K = K; cfg.min_qual = (uint32_t)atoi(a["MIN_QUAL"].c_str());
         cfg.min_freq = (uint32_t)atoi(a["MIN_FREQ"].c_str()); cfg.min_bc = (uint32_t)atoi(a["MIN_BC"].c_str());
         cfg.device = atoi(a["DEVICE"].c_str()); cfg.ign_bc_below = 0;           // bc_start = 0 for LR-only input (DF.cc:344-349)
         cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
-        cfg.hbm_budget_bytes = (uint64_t)atoll(a["MAX_MEM_GB"].c_str()) << 30;  // 0 = 90 % of free HBM
+        cfg.hbm_budget_bytes = (uint64_t)(atof(a["HBM_GB"].c_str()) * 1073741824.0);   // 0 = 90 % of the free HBM; MAX_MEM_GB is host memory
         dfk_ctx* ctx = nullptr;
-        if (dfk_create(&cfg, &ctx)) { fprintf(stderr, "DF: %s\n", dfk_last_error()); return 1; }
+        if (dfk_create(&cfg, &ctx)) { fprintf(stderr, "DF: %s\n", dfk_last_error()); join_background(); return 1; }
         printf("%s: building dictionary on the GPU\n", date().c_str());
-        int rc = dfk_count(ctx, R.packed.data(), R.base_off.data(), R.read_len.data(), R.pq.data(), R.pq_off.data(), bc.data(), R.size());
-        if (rc == DFK_E_NOGOOD) { printf("\nLooks like your input data have almost no good bases.\nGiving up.\n\n"); return 1; }   // :227-230
-        if (rc) { fprintf(stderr, "DF: %s\n", dfk_last_error()); return rc == DFK_E_NOMEM ? 185 : 1; }                       // Martian::exit code
+        t0 = now_s();
+        int rc = dfk_count(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bc.data(), n_reads);
+        const double t_count = now_s() - t0;
+        if (rc == DFK_E_NOGOOD) { printf("\nLooks like your input data have almost no good bases.\nGiving up.\n\n"); join_background(); return 1; }   // :227-230
+        if (rc) { fprintf(stderr, "DF: %s\n", dfk_last_error()); join_background(); return rc == DFK_E_NOMEM ? 185 : 1; }        // Martian::exit code
+        dfk_stats st{}; dfk_get_stats(ctx, &st);
+        T.upload = 1e-3 * st.ms_upload; T.count = t_count - T.upload;
+        t0 = now_s();
         uint64_t need = 0; dfk_spectrum_json(ctx, nullptr, 0, &need);
         std::string js(need, '\0'); dfk_spectrum_json(ctx, &js[0], need, &need);
         { FILE* f = fopen((work_dir + "/stats/histogram_kmer_count.json").c_str(), "wb"); if (!f) throw std::runtime_error("cannot write spectrum"); fwrite(js.data(), 1, js.size(), f); fclose(f); }
         uint64_t nk = 0; dfk_solid_count(ctx, &nk);
-        if (truthy(a["KVEC"])) { printf("%s: writing kmers.kvec\n", date().c_str()); if (dfk_write_kvec(ctx, (work_dir + "/kmers.kvec").c_str(), 0)) throw std::runtime_error(dfk_last_error()); }
-        dfk_stats st{}; dfk_get_stats(ctx, &st);
+        if (truthy(a["KVEC"])) {
+            printf("%s: writing kmers.kvec\n", date().c_str());
+            if (dfk_write_kvec(ctx, (work_dir + "/kmers.kvec").c_str(), truthy(a["KVEC_SORTED"]) ? DFK_KVEC_SORTED : 0)) throw std::runtime_error(dfk_last_error());
+        }
+        T.fetch_write = now_s() - t0;
         dfk_destroy(ctx);
-        double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        join_background();
+        T.total = now_s() - t_start;
         printf("%s: dictionary covers %llu kmers\n", date().c_str(), (unsigned long long)nk);
         printf("%s: %llu k-mer instances, GPU %.1f ms (count kernel %.1f ms), ingest+count stage %.2f s wall\n", date().c_str(),
-               (unsigned long long)st.n_inst, st.ms_total, st.ms_count, secs);
+               (unsigned long long)st.n_inst, st.ms_total, st.ms_count, T.total);
+        // one machine-readable line (bench.py reads it): where the stage's wall time went
+        printf("DF_TIMING {\"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"threads\": %u, \"open_validate_s\": %.3f, "
+               "\"ingest_outputs_s\": %.3f, \"upload_s\": %.3f, \"count_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, \"total_s\": %.3f, "
+               "\"fast_path\": %s}\n",
+               (unsigned long long)n_reads, (unsigned long long)st.n_inst, (unsigned long long)nk, g_threads, T.read, T.ingest_out,
+               T.upload, T.count, T.fetch_write, T.total, fast ? "true" : "false");
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());
         return 1;

@@ -10,7 +10,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <fcntl.h>
+#include <functional>
+#include <new>
 #include <string>
+#include <unistd.h>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -30,6 +35,15 @@ int fail(int code, const char* fmt, ...)
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     return fail(DFK_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// No exception crosses the C ABI: host containers can throw (a 99 GB sorted fetch asks for 200 GB of host memory).
+template <class F> int guarded(F&& f)
+{
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(DFK_E_NOMEM, "out of host memory"); }
+    catch (const std::exception& e) { return fail(DFK_E_HIP, "internal error: %s", e.what()); }
+    catch (...) { return fail(DFK_E_HIP, "internal error"); }
+}
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -265,7 +279,7 @@ int stage_trim(dfk_ctx* c, const Inputs& in, uint64_t* n_inst)
     if (in.n_reads) {
         unsigned grid = (unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trim<K>), dim3(grid), dim3(256), 0, c->stream,
-                           in.pq, in.pq_off, in.read_len, in.n_reads, c->cfg.min_qual, (uint32_t*)c->good_len.p,
+                           in.pq, in.pq_off, in.pq_bytes, in.base_off, in.packed_bytes, in.read_len, in.n_reads, c->cfg.min_qual, (uint32_t*)c->good_len.p,
                            (unsigned long long*)ctr.p, (unsigned int*)((char*)ctr.p + 8),
                            (unsigned long long*)((char*)ctr.p + 16));
         HIP_TRY(hipGetLastError());
@@ -274,7 +288,7 @@ int stage_trim(dfk_ctx* c, const Inputs& in, uint64_t* n_inst)
     HIP_TRY(hipMemcpyAsync(h, ctr.p, 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->release(ctr);
-    if ((uint32_t)h[1]) return fail(DFK_E_INPUT, "a PQVec stream is malformed or its length differs from read_len");
+    if ((uint32_t)h[1]) return fail(DFK_E_INPUT, "malformed input: an offset table is not monotone or runs past its array, a PQVec stream is broken, or its length differs from read_len");
     // createDict: nKmers = sum of goodLens == 0 -> "almost no good bases", Scram(1) (BuildReadQGraph48.cc:225-230)
     if (h[2] == 0) return fail(DFK_E_NOGOOD, "Looks like your input data have almost no good bases.");
     *n_inst = h[0];
@@ -1356,6 +1370,121 @@ void host_sort_entries(std::vector<dfk_entry32>& v)
     v.swap(tmp);
 }
 
+// ------------------------------------------------------------------ host <-> device transfers at scale
+// A 30x human run uploads ~100 GB of reads and hands back a 99 GB dictionary.  One pageable hipMemcpy moves that at
+// a few GB/s (the runtime stages it through one bounce buffer on one core); here a few host threads each own two
+// pinned buffers and a stream, pull chunks off a shared counter, and overlap their memcpy (or file write) with the
+// DMA of their other buffer.  Small transfers take the plain call.
+// (DFK_XFER_CHUNK: the tests push a few hundred reads through the many-chunk path)
+const size_t XFER_CHUNK = [] { const char* e = getenv("DFK_XFER_CHUNK"); return e && atoll(e) >= 64 ? ((size_t)atoll(e) & ~(size_t)31) : (size_t)16 << 20; }();
+unsigned xfer_threads()
+{
+    static const unsigned n = [] {
+        if (const char* e = getenv("DFK_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
+        return std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    }();
+    return n;
+}
+
+struct XferLane { void* pin[2] = {nullptr, nullptr}; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; unsigned turn = 0; };
+
+// body(t, lane, i) is called for chunk indices i = 0..n_chunks-1, each exactly once, from T = min(n_chunks,
+// xfer_threads()) threads bound to the context's device (t = thread number, lane = its buffers and stream);
+// fin(t, lane) once per thread when the chunks have run out.  The first non-zero return stops the rest.
+using XferBody = std::function<int(unsigned, XferLane&, uint64_t)>;
+using XferFin = std::function<int(unsigned, XferLane&)>;
+int xfer_run(dfk_ctx* c, uint64_t n_chunks, const XferBody& body, const XferFin& fin = nullptr)
+{
+    const unsigned T = (unsigned)std::min<uint64_t>(n_chunks, xfer_threads());
+    if (!T) return 0;
+    std::vector<XferLane> lanes(T);
+    int rc = 0;
+    for (XferLane& l : lanes) {
+        for (int k = 0; k < 2 && !rc; ++k) {
+            if (hipHostMalloc(&l.pin[k], XFER_CHUNK, hipHostMallocDefault) != hipSuccess) rc = fail(DFK_E_NOMEM, "cannot pin %zu bytes of host memory for transfers", XFER_CHUNK);
+            else if (hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming) != hipSuccess) rc = fail(DFK_E_HIP, "hipEventCreate failed");
+        }
+        if (!rc && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess) rc = fail(DFK_E_HIP, "hipStreamCreate failed");
+    }
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> err{0};
+    std::string err_msg;
+    std::mutex mu;
+    if (!rc) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                (void)hipSetDevice(c->device);
+                auto note = [&](int r) { if (r) { std::lock_guard<std::mutex> g(mu); if (!err.load()) { err_msg = g_err; err = r; } } };
+                for (uint64_t i; !err.load() && (i = next.fetch_add(1)) < n_chunks;) note(body(t, lanes[t], i));
+                if (fin && !err.load()) note(fin(t, lanes[t]));
+                (void)hipStreamSynchronize(lanes[t].st);
+            });
+        for (std::thread& x : th) x.join();
+        if (err.load()) { rc = err.load(); g_err = err_msg; }
+    }
+    for (XferLane& l : lanes) {
+        for (int k = 0; k < 2; ++k) { if (l.pin[k]) (void)hipHostFree(l.pin[k]); if (l.ev[k]) (void)hipEventDestroy(l.ev[k]); }
+        if (l.st) (void)hipStreamDestroy(l.st);
+    }
+    return rc;
+}
+
+// host -> device, `bytes` from pageable (or mapped-file) memory
+int upload(dfk_ctx* c, void* d, const void* h, uint64_t bytes)
+{
+    if (!bytes) return 0;
+    if (bytes < 4 * XFER_CHUNK) { HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return 0; }
+    return xfer_run(c, (bytes + XFER_CHUNK - 1) / XFER_CHUNK, [&](unsigned, XferLane& l, uint64_t i) -> int {
+        const int k = l.turn++ & 1;                                  // the lane's two buffers alternate; the one about to be
+        HIP_TRY(hipEventSynchronize(l.ev[k]));                       // overwritten must have left the host
+        const uint64_t off = i * XFER_CHUNK, n = std::min<uint64_t>(XFER_CHUNK, bytes - off);
+        memcpy(l.pin[k], (const char*)h + off, n);
+        HIP_TRY(hipMemcpyAsync((char*)d + off, l.pin[k], n, hipMemcpyHostToDevice, l.st));
+        HIP_TRY(hipEventRecord(l.ev[k], l.st));
+        return 0;
+    });
+}
+
+// The dictionary as the device holds it (pass after pass, no order inside a pass), streamed into a kmers.kvec image:
+// every chunk has its place in the file, so the lanes write independently (pwrite).
+int write_parts_unsorted(dfk_ctx* c, int fd, bool pre)
+{
+    struct Piece { const char* src; uint64_t bytes, file_off; };
+    std::vector<Piece> pieces;
+    uint64_t at = 16;
+    for (const dfk_ctx::Part& pt : c->parts) {
+        const DevBuf& src = pre ? pt.pre : pt.buf;
+        for (uint64_t o = 0; o < pt.n * 32; o += XFER_CHUNK) pieces.push_back(Piece{(const char*)src.p + o, std::min<uint64_t>(XFER_CHUNK, pt.n * 32 - o), at + o});
+        at += pt.n * 32;
+    }
+    struct Pending { uint64_t bytes = 0, file_off = 0; bool live = false; };
+    std::vector<Pending> pend(2 * (size_t)xfer_threads());
+    auto flush = [&](XferLane& l, unsigned t, int k) -> int {      // the chunk sitting in buffer k goes to the file
+        Pending& p = pend[2 * t + k];
+        if (!p.live) return 0;
+        HIP_TRY(hipEventSynchronize(l.ev[k]));
+        for (uint64_t done = 0; done < p.bytes;) {
+            const ssize_t w = pwrite(fd, (const char*)l.pin[k] + done, p.bytes - done, (off_t)(p.file_off + done));
+            if (w <= 0) return fail(DFK_E_ARG, "short write to the k-mer file");
+            done += (uint64_t)w;
+        }
+        p.live = false;
+        return 0;
+    };
+    return xfer_run(c, pieces.size(),
+        [&](unsigned t, XferLane& l, uint64_t i) -> int {
+            const int k = l.turn++ & 1;
+            int r = flush(l, t, k); if (r) return r;
+            const Piece& pc = pieces[i];
+            HIP_TRY(hipMemcpyAsync(l.pin[k], pc.src, pc.bytes, hipMemcpyDeviceToHost, l.st));
+            HIP_TRY(hipEventRecord(l.ev[k], l.st));
+            pend[2 * t + k] = Pending{pc.bytes, pc.file_off, true};
+            return flush(l, t, k ^ 1);                              // the other buffer's chunk is written while this one is in flight
+        },
+        [&](unsigned t, XferLane& l) -> int { int r = flush(l, t, 0); return r ? r : flush(l, t, 1); });
+}
+
 int fetch_sorted(dfk_ctx* c, bool pre, std::vector<dfk_entry32>** out)
 {
     std::vector<dfk_entry32>& v = pre ? c->sorted_pre : c->sorted;
@@ -1386,6 +1515,7 @@ int dfk_abi_version(void) { return DFK_ABI_VERSION; }
 
 int dfk_create(const dfk_config* cfg, dfk_ctx** out)
 {
+    return guarded([&]() -> int {
     if (!cfg || !out) return fail(DFK_E_ARG, "null argument");
     *out = nullptr;
     if (cfg->abi_version != DFK_ABI_VERSION) return fail(DFK_E_ARG, "dfk_config.abi_version %u != %d", cfg->abi_version, DFK_ABI_VERSION);
@@ -1414,9 +1544,17 @@ int dfk_create(const dfk_config* cfg, dfk_ctx** out)
     }
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
-    c->budget = cfg->hbm_budget_bytes ? cfg->hbm_budget_bytes : (uint64_t)(0.9 * (double)fr);
+    // The budget is what the arena may reserve: never more than 90 % of what is free now, whatever was asked for (the
+    // reference's GRAPHMEM=0.9 of the memory actually there, system/System.cc:1073-1078).  A caller that forwards a
+    // host-memory figure -- runall.sh passes MAX_MEM_GB=640 -- gets the device's share, not a plan for room that does
+    // not exist.
+    const uint64_t cap = (uint64_t)(0.9 * (double)fr);
+    c->budget = cfg->hbm_budget_bytes ? std::min<uint64_t>(cfg->hbm_budget_bytes, cap) : cap;
+    if (cfg->hbm_budget_bytes > cap)
+        TRACE("hbm_budget_bytes %.1f GB is more than 90 %% of the free HBM: clamped to %.1f GB", cfg->hbm_budget_bytes / 1e9, cap / 1e9);
     *out = c;
     return 0;
+    });
 }
 
 void dfk_destroy(dfk_ctx* c)
@@ -1434,6 +1572,7 @@ int dfk_count_device(dfk_ctx* c, const void* d_packed, uint64_t packed_bytes, co
                      const void* d_read_len, const void* d_pq, uint64_t pq_nbytes, const void* d_pq_off,
                      const void* d_bc, uint64_t n_reads)
 {
+    return guarded([&]() -> int {
     if (!c) return fail(DFK_E_ARG, "null context");
     if (n_reads && (!d_packed || !d_base_off || !d_read_len || !d_pq || !d_pq_off)) return fail(DFK_E_ARG, "null input array");
     if (n_reads >= (1ull << 32)) return fail(DFK_E_ARG, "more than 2^32-1 reads in one shard");
@@ -1446,32 +1585,37 @@ int dfk_count_device(dfk_ctx* c, const void* d_packed, uint64_t packed_bytes, co
     int rc = run(c, in);
     if (rc) c->release_all();
     return rc;
+    });
 }
 
 int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const uint32_t* read_len,
               const uint8_t* pq, const uint64_t* pq_off, const int32_t* bc, uint64_t n_reads)
 {
+    return guarded([&]() -> int {
     if (!c) return fail(DFK_E_ARG, "null context");
     if (n_reads && (!packed || !base_off || !read_len || !pq || !pq_off)) return fail(DFK_E_ARG, "null input array");
     HIP_TRY(hipSetDevice(c->device));
     c->release_all();
-    const uint64_t pb = n_reads ? base_off[n_reads] : 0, qb = n_reads ? pq_off[n_reads] : 0;
+    // (the host tables may sit at any address -- e.g. inside a mapped feudal file -- so they are not dereferenced as u64)
+    uint64_t pb = 0, qb = 0;
+    if (n_reads) { memcpy(&pb, (const char*)base_off + 8 * n_reads, 8); memcpy(&qb, (const char*)pq_off + 8 * n_reads, 8); }
     // staging copies live outside the context's run allocations (release_all() at the start of a run)
     void *d_packed = nullptr, *d_boff = nullptr, *d_len = nullptr, *d_pq = nullptr, *d_poff = nullptr, *d_bc = nullptr;
     Timer t(c->stream);
     t.start();
-    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(d, bytes + 64); if (e != hipSuccess) return e;
-        return bytes ? hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, c->stream) : hipSuccess;
-    };
-    hipError_t e = up(&d_packed, packed, pb);
-    if (e == hipSuccess) e = up(&d_boff, base_off, (n_reads + 1) * 8);
-    if (e == hipSuccess) e = up(&d_len, read_len, n_reads * 4);
-    if (e == hipSuccess) e = up(&d_pq, pq, qb);
-    if (e == hipSuccess) e = up(&d_poff, pq_off, (n_reads + 1) * 8);
-    if (e == hipSuccess && bc) e = up(&d_bc, bc, n_reads * 4);
     int rc = 0;
-    if (e != hipSuccess) rc = fail(DFK_E_NOMEM, "uploading inputs: %s", hipGetErrorString(e));
+    auto up = [&](void** d, const void* h, size_t bytes) {
+        if (rc) return;
+        // (64 bytes of slack: the kernels read the 2-bit stream as aligned 32-bit words, up to 3 bytes past its end)
+        if (hipMalloc(d, bytes + 64) != hipSuccess) { (void)hipGetLastError(); rc = fail(DFK_E_NOMEM, "no room on the device for %zu bytes of input", bytes); return; }
+        rc = upload(c, *d, h, bytes);
+    };
+    up(&d_packed, packed, pb);
+    up(&d_boff, base_off, (n_reads + 1) * 8);
+    up(&d_len, read_len, n_reads * 4);
+    up(&d_pq, pq, qb);
+    up(&d_poff, pq_off, (n_reads + 1) * 8);
+    if (bc) up(&d_bc, bc, n_reads * 4);
     float ms_up = t.stop();
     if (!rc) {
         uint64_t staged = pb + qb + (n_reads + 1) * 16 + n_reads * 8 + 6 * 64;
@@ -1483,15 +1627,18 @@ int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const
     }
     (void)hipFree(d_packed); (void)hipFree(d_boff); (void)hipFree(d_len); (void)hipFree(d_pq); (void)hipFree(d_poff); (void)hipFree(d_bc);
     return rc;
+    });
 }
 
 int dfk_good_lens(dfk_ctx* c, uint32_t* out, uint64_t cap)
 {
+    return guarded([&]() -> int {
     if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
     if (cap < c->n_reads) return fail(DFK_E_ARG, "buffer too small");
     HIP_TRY(hipSetDevice(c->device));
     if (c->n_reads) HIP_TRY(hipMemcpy(out, c->good_len.p, c->n_reads * 4, hipMemcpyDeviceToHost));
     return 0;
+    });
 }
 
 int dfk_spectrum(dfk_ctx* c, const int64_t** hist, uint64_t* nbins)
@@ -1503,6 +1650,7 @@ int dfk_spectrum(dfk_ctx* c, const int64_t** hist, uint64_t* nbins)
 
 int dfk_spectrum_json(dfk_ctx* c, char* out, uint64_t cap, uint64_t* need)
 {
+    return guarded([&]() -> int {
     if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
     // WriteHistToJson<int64_t> (10X/MakeHist.cc:67-92) as called from WriteKmerSpectrum
     std::string s = "{\n\t\"description\": \"kmer_count\",\n\t\"stage\": \"DF\",\n\t\"binsize\": 1,\n\t\"min\": 0,\n";
@@ -1513,6 +1661,7 @@ int dfk_spectrum_json(dfk_ctx* c, char* out, uint64_t cap, uint64_t* need)
     if (need) *need = s.size();
     if (out && cap) { size_t n = std::min<size_t>(cap, s.size()); memcpy(out, s.data(), n); if (n < cap) out[n] = 0; }
     return 0;
+    });
 }
 
 int dfk_solid_count(dfk_ctx* c, uint64_t* n)
@@ -1524,6 +1673,7 @@ int dfk_solid_count(dfk_ctx* c, uint64_t* n)
 
 int dfk_solid_fetch(dfk_ctx* c, dfk_entry32* out, uint64_t cap, int pre)
 {
+    return guarded([&]() -> int {
     if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
     if (cap < c->n_solid) return fail(DFK_E_ARG, "buffer too small: %llu < %llu", (unsigned long long)cap, (unsigned long long)c->n_solid);
     HIP_TRY(hipSetDevice(c->device));
@@ -1531,10 +1681,12 @@ int dfk_solid_fetch(dfk_ctx* c, dfk_entry32* out, uint64_t cap, int pre)
     int rc = fetch_sorted(c, pre != 0, &v); if (rc) return rc;
     if (!v->empty()) memcpy(out, v->data(), v->size() * 32);
     return 0;
+    });
 }
 
 int dfk_solid_fetch_unsorted(dfk_ctx* c, dfk_entry32* out, uint64_t cap, int pre)
 {
+    return guarded([&]() -> int {
     if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
     if (cap < c->n_solid) return fail(DFK_E_ARG, "buffer too small: %llu < %llu", (unsigned long long)cap, (unsigned long long)c->n_solid);
     if (pre && !(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
@@ -1546,10 +1698,12 @@ int dfk_solid_fetch_unsorted(dfk_ctx* c, dfk_entry32* out, uint64_t cap, int pre
         at += pt.n;
     }
     return 0;
+    });
 }
 
 int dfk_solid_digest(dfk_ctx* c, int pre, uint64_t* digest)
 {
+    return guarded([&]() -> int {
     if (!c || !digest) return fail(DFK_E_ARG, "null argument");
     if (!c->have) return fail(DFK_E_STATE, "no completed count");
     if (pre && !(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
@@ -1567,12 +1721,30 @@ int dfk_solid_digest(dfk_ctx* c, int pre, uint64_t* digest)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->release(d);
     return 0;
+    });
 }
 
-int dfk_write_kvec(dfk_ctx* c, const char* path, int pre)
+int dfk_write_kvec(dfk_ctx* c, const char* path, int flags)
 {
+    return guarded([&]() -> int {
     if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    if (!path) return fail(DFK_E_ARG, "null path");
+    const int pre = flags & DFK_KVEC_PRE_ADJ;
+    if (pre && !(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
     HIP_TRY(hipSetDevice(c->device));
+    if (!(flags & DFK_KVEC_SORTED)) {
+        // device order, as the reference's own kmers.kvec is in thread-arrival order (BuildReadQGraph48.cc:287-288,
+        // ReadPather.h:406-418): no host copy of the dictionary, no sort
+        const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) return fail(DFK_E_ARG, "cannot open %s", path);
+        const uint64_t n = c->n_solid;
+        char head[16]; memcpy(head, "BINWRITE", 8); memcpy(head + 8, &n, 8);
+        int rc = pwrite(fd, head, 16, 0) == 16 ? 0 : fail(DFK_E_ARG, "short write to %s", path);
+        if (!rc && ftruncate(fd, (off_t)(16 + 32 * n)) != 0) rc = fail(DFK_E_ARG, "cannot size %s", path);
+        if (!rc) rc = write_parts_unsorted(c, fd, pre != 0);
+        if (close(fd) != 0 && !rc) rc = fail(DFK_E_ARG, "short write to %s", path);
+        return rc;
+    }
     std::vector<dfk_entry32>* v = nullptr;
     int rc = fetch_sorted(c, pre != 0, &v); if (rc) return rc;
     FILE* f = fopen(path, "wb");
@@ -1581,6 +1753,7 @@ int dfk_write_kvec(dfk_ctx* c, const char* path, int pre)
     bool ok = fwrite("BINWRITE", 1, 8, f) == 8 && fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v->data(), 32, n, f) == n);
     ok = (fclose(f) == 0) && ok;
     return ok ? 0 : fail(DFK_E_ARG, "short write to %s", path);
+    });
 }
 
 int dfk_get_stats(dfk_ctx* c, dfk_stats* out)

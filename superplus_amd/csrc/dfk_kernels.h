@@ -14,7 +14,8 @@ namespace dfk {
 // flags reads whose PQVec length disagrees with read_len.
 template <int K>
 __global__ void __launch_bounds__(256)
-k_trim(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, const uint32_t* __restrict__ read_len,
+k_trim(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, uint64_t pq_nbytes,
+       const uint64_t* __restrict__ base_off, uint64_t packed_bytes, const uint32_t* __restrict__ read_len,
        uint64_t n_reads, uint32_t min_qual, uint32_t* __restrict__ good_len,
        unsigned long long* __restrict__ n_inst, unsigned int* __restrict__ bad,
        unsigned long long* __restrict__ sum_good)
@@ -27,7 +28,11 @@ k_trim(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, cons
         uint32_t gl = 0;
         uint64_t p = pq_off[r], end = pq_off[r + 1];
         uint32_t idx = 0, run = 0;
-        bool ok = true;
+        // the offset tables are the caller's: nothing is read through them before they have been checked against
+        // the array sizes (a malformed .qualp/.fastb must end as DFK_E_INPUT, not as a stray device read)
+        const uint64_t b0 = base_off[r], b1 = base_off[r + 1];
+        bool ok = p <= end && end <= pq_nbytes && b0 <= b1 && b1 <= packed_bytes && b1 - b0 >= ((uint64_t)read_len[r] + 3) / 4;
+        if (!ok) end = p;
         while (p < end) {
             uint32_t nQs = pq[p];
             if (!nQs) break;
@@ -720,7 +725,11 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
     }
 #endif
     if (state == PS_FOUND) {
-        if ((seen & CNT_MASK) < CNT_NEAR_SAT) atomicAdd(&cnt[slot], 1u);
+        // The plain add is safe while (count seen at probe time) + (lanes that can sit between their probe and their
+        // add) stays below 2^24.  An LDS table sees at most the 1024 lanes of its workgroup; an HBM table is shared by
+        // the whole grid (a hot k-mer sends every resident lane to one slot: up to 256 CUs x 2048 lanes), so its margin
+        // is 2^20 -- beyond it the count would carry into the fingerprint byte and the k-mer would claim a second slot.
+        if ((seen & CNT_MASK) < (LDS_TABLE ? CNT_NEAR_SAT : CNT_NEAR_SAT_GRID)) atomicAdd(&cnt[slot], 1u);
         else {                                                            // saturate exactly at 2^24-1 (KDef::setCount)
             uint32_t cur = tld(&cnt[slot]);
             while ((cur & CNT_MASK) != CNT_MASK &&

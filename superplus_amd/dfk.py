@@ -169,10 +169,27 @@ class Dfk:
         _check(lib().dfk_solid_digest(self._ctx, C.c_int(1 if pre_adjacency else 0), out))
         return int(out[0]), int(out[1])
 
-    def write_kvec(self, path, pre_adjacency=False):
-        _check(lib().dfk_write_kvec(self._ctx, path.encode(), C.c_int(1 if pre_adjacency else 0)))
+    def write_kvec(self, path, pre_adjacency=False, in_order=False):
+        """kmers.kvec image; device order unless in_order (ascending k-mers, sorted on the host)."""
+        _check(lib().dfk_write_kvec(self._ctx, path.encode(), C.c_int((1 if pre_adjacency else 0) | (2 if in_order else 0))))
 
     def stats(self):
         s = Stats()
         _check(lib().dfk_get_stats(self._ctx, C.byref(s)))
         return s.asdict()
+
+
+def _mix(x):
+    x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xBF58476D1CE4E5B9)
+    x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def digest_of(entries):
+    """numpy form of k_digest (dfk_solid_digest) over 32-byte dictionary entries: (sum, xor).  What a CPU-side answer
+    is turned into to be compared with a dictionary that stays on the device."""
+    w = np.ascontiguousarray(entries).view(np.uint64).reshape(-1, 4)
+    with np.errstate(over="ignore"):
+        h = _mix(w[:, 0] ^ _mix(w[:, 1] ^ _mix(w[:, 2] ^ _mix(w[:, 3] + np.uint64(0x9E3779B97F4A7C15)))))
+        x = _mix(h + np.uint64(0xD1B54A32D192ED03))
+        return int(h.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(x)) if len(x) else 0

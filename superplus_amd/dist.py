@@ -22,15 +22,25 @@ from . import dfk as _dfk
 from .dfk import Dfk, _check, lib
 
 
-def exchange_begin(send: torch.Tensor, send_counts, unit: int, comm, recv_alloc=None):
+def exchange_begin(send: torch.Tensor, send_counts, unit: int, comm, recv_alloc=None, agree=None):
     """First half of exchange(): the counts are exchanged (small, waited for), the receive buffer is made and the
     all-to-all of the payload is started.  Returns a token for exchange_end().  With a transport that cannot run
-    the collective in the background the whole exchange happens here."""
+    the collective in the background the whole exchange happens here.
+    agree(err): called with the DfkError recv_alloc raised (or None) before the payload moves; it is expected to
+    make every rank raise if any rank failed (the receive buffer comes out of each rank's own HBM budget)."""
     sc = torch.tensor(list(send_counts), dtype=torch.int64, device=send.device)
     rc = torch.empty_like(sc)
     comm.all_to_all_single(rc, sc, None, None)
     rcl = [int(x) for x in rc.tolist()]
-    recv = recv_alloc(sum(rcl)) if recv_alloc else torch.empty(sum(rcl) * unit, dtype=torch.uint8, device=send.device)
+    err, recv = None, None
+    try:
+        recv = recv_alloc(sum(rcl)) if recv_alloc else torch.empty(sum(rcl) * unit, dtype=torch.uint8, device=send.device)
+    except _dfk.DfkError as e:
+        err = e
+    if agree is not None:
+        agree(err)
+    elif err is not None:
+        raise err
     if send.is_cuda:
         torch.cuda.synchronize(send.device)       # the library filled `send` on its own stream
     start = getattr(comm, "all_to_all_single_async", None)
@@ -264,45 +274,93 @@ class DistDfk(Dfk):
         sent = 0
         t_all = time.perf_counter()
 
+        comm = self.comm or TorchComm()
+        world = comm.world
+        pending = []                                   # a local failure waits here for the next agreement point
+
         def timed(key, f, *a):
             t = time.perf_counter()
-            r = f(*a)
+            r = None
+            try:
+                if not pending:
+                    r = f(*a)
+            except _dfk.DfkError as e:                 # the library's own errors only: they are local to this rank
+                pending.append(e)
             T[key] += 1e3 * (time.perf_counter() - t)
             return r
 
-        comm = self.comm or TorchComm()
-        world = comm.world
+        def agree(what):
+            """A library call can fail on one rank only (its own data, its own HBM budget).  The others would then
+            sit in the next collective until the backend times out, holding their GPUs.  So after every local phase
+            the ranks all-reduce a status word and every rank raises when any of them failed -- before the next
+            exchange is entered."""
+            worst = comm.all_reduce_max(-pending[0].code if pending else 0, packed.device)
+            if pending:
+                raise pending[0]
+            if worst:
+                raise _dfk.DfkError(-worst, f"another rank failed in {what}; this rank stops with it")
+
         n_local = timed("trim", self.begin, packed, base_off, read_len, pq_bytes, pq_off, bc, read_id0)
+        agree("dfk_shard_begin")
         n_global = comm.all_reduce_sum(n_local, packed.device)
         if n_global == 0:
             raise _dfk.DfkError(-7, "Looks like your input data have almost no good bases.")
         self._n_inst_global = n_global
-        log2_passes = comm.all_reduce_max(timed("plan", self.plan, world, n_global), packed.device)   # every rank runs the same passes
+        mine = timed("plan", self.plan, world, n_global)
+        agree("dfk_shard_plan")
+        log2_passes = comm.all_reduce_max(mine, packed.device)   # every rank runs the same passes
         # The k-mer shuffle, one bucket range at a time -- and one range ahead: while pass p is counted, the records
         # of pass p+1 have been cut and are on their way (the library keeps a second receive buffer for them).
         n_pass = 1 << log2_passes
-        send, counts = timed("partition", self.partition, world, n_global, log2_passes, 0)
+        def cut(p):
+            r = timed("partition", self.partition, world, n_global, log2_passes, p)
+            agree("dfk_shard_partition")               # (also covers the count of the pass before: see below)
+            return r
+
+        send, counts = cut(0)
         sent += 32 * (sum(counts) - counts[comm.rank])
-        recv, _ = timed("exchange_wait", lambda: exchange_end(exchange_begin(send, counts, 32, comm, self.recv_buffer)))
+        def agree_recv(err):
+            if err is not None:
+                pending.append(err)
+            agree("dfk_shard_recv_buffer")
+
+        def wait_for(token):                           # (never skipped: a transfer that was started is waited for)
+            t = time.perf_counter()
+            r = exchange_end(token)
+            T["exchange_wait"] += 1e3 * (time.perf_counter() - t)
+            return r
+
+        def start(send, counts):                       # (contains collectives: never skipped, never swallowed)
+            t = time.perf_counter()
+            token = exchange_begin(send, counts, 32, comm, self.recv_buffer, agree_recv)
+            T["exchange_wait"] += 1e3 * (time.perf_counter() - t)
+            return token
+
+        recv, _ = wait_for(start(send, counts))
         for p in range(n_pass):
             token = None
             if p + 1 < n_pass:
-                send, counts = timed("partition", self.partition, world, n_global, log2_passes, p + 1)
+                send, counts = cut(p + 1)
                 sent += 32 * (sum(counts) - counts[comm.rank])
-                token = timed("exchange_wait", exchange_begin, send, counts, 32, comm, self.recv_buffer)
+                token = start(send, counts)
                 if os.environ.get("DFK_SHARD_SERIAL"):                          # debugging aid: no transfer under the count
-                    token = (*exchange_end(token), None, None)
+                    token = (*wait_for(token), None, None)
+            # a failure here is agreed on at the next cut() -- after the exchange that is already in flight has been
+            # waited for, so that no rank is left inside a transfer
             timed("count", self.count_records, recv, p)
             del recv
             if token is not None:
-                recv, _ = timed("exchange_wait", exchange_end, token)
+                recv, _ = wait_for(token)
                 del token
         del send
         t_adj = time.perf_counter()
-        keys, kcounts = self.adj_queries(world)
+        q = timed("adjacency", self.adj_queries, world)
+        agree("dfk_shard_count / dfk_shard_adj_queries")
+        keys, kcounts = q
         sent += 17 * (sum(kcounts) - kcounts[comm.rank])
         rkeys, rcounts = exchange(keys, kcounts, 16, comm)                 # neighbour queries
-        answers = self.adj_answer(rkeys)
+        answers = timed("adjacency", self.adj_answer, rkeys)
+        agree("dfk_shard_adj_answer")
         if getattr(comm, "rehearsal", False):                              # no peers to answer: see ReplicaComm
             back = torch.ones(sum(kcounts), dtype=torch.uint8, device=packed.device)
         else:

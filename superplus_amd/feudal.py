@@ -20,6 +20,11 @@ import numpy as np
 _HDR = struct.Struct("<IBBBBQQ")
 
 
+def header(n, sizeof_fixed, sizeof_x, sizeof_a, var_tab, fixed_off):
+    """The 24-byte control block of a feudal file."""
+    return _HDR.pack(n & 0xFFFFFFFF, 1, sizeof_fixed, sizeof_x, sizeof_a, var_tab, fixed_off)
+
+
 def _write_feudal(path, var_bytes, var_off, fixed_bytes, sizeof_fixed, sizeof_x, sizeof_a):
     n = len(var_off) - 1
     var_len = int(var_off[-1])

@@ -39,37 +39,57 @@ class ReadSet:
         )
 
 
-def make_genome(size, seed, device="cpu", repeat_frac=0.0, family_copies=0, family_len=300, family_div=0.10):
+def make_genome(size, seed, device="cpu", repeat_frac=0.0, family_copies=0, family_len=300, family_div=0.10,
+                low_complexity_frac=0.0):
     """family_copies > 0 plants that many diverged copies (substitution rate family_div) of ONE random
-    family_len-bp element, Alu-like: a few minimizers then own a large share of the k-mers (hot buckets)."""
-    if torch.device(device).type != "cpu" and repeat_frac == 0 and family_copies == 0:
-        g = torch.Generator(device=device).manual_seed(seed)
-        return torch.randint(0, 4, (size,), generator=g, dtype=torch.uint8, device=device)
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    genome = torch.randint(0, 4, (size,), generator=g, dtype=torch.uint8)
+    family_len-bp element, Alu-like: a few minimizers then own a large share of the k-mers (hot buckets).
+    low_complexity_frac > 0 overwrites that share of the genome with 200-bp microsatellite stretches (units of 1-6 bp:
+    poly-A, (AT)n, (CAG)n ...), whose k-mers are few and heavily repeated.  Both are planted on `device`."""
+    dev = torch.device(device)
+    if dev.type != "cpu":
+        g = torch.Generator(device=dev).manual_seed(seed)
+        genome = torch.randint(0, 4, (size,), generator=g, dtype=torch.uint8, device=dev)
+    else:
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        genome = torch.randint(0, 4, (size,), generator=g, dtype=torch.uint8)
     if repeat_frac > 0 and size > 4000:
         # plant copies of a few 1-2 kb segments so some k-mers have high multiplicity
         n_rep = max(1, int(size * repeat_frac / 1500))
-        src = torch.randint(0, size - 2000, (n_rep,), generator=g)
-        dst = torch.randint(0, size - 2000, (n_rep,), generator=g)
-        ln = torch.randint(1000, 2000, (n_rep,), generator=g)
+        src = torch.randint(0, size - 2000, (n_rep,), generator=g, device=dev)
+        dst = torch.randint(0, size - 2000, (n_rep,), generator=g, device=dev)
+        ln = torch.randint(1000, 2000, (n_rep,), generator=g, device=dev)
         for s, d, l in zip(src.tolist(), dst.tolist(), ln.tolist()):
             genome[d : d + l] = genome[s : s + l].clone()
     if family_copies > 0 and size > 4 * family_len:
-        elem = torch.randint(0, 4, (family_len,), generator=g, dtype=torch.uint8)
-        pos = torch.randint(0, size - family_len, (family_copies,), generator=g)
-        copies = elem[None, :].repeat(family_copies, 1)
-        hit = torch.rand(copies.shape, generator=g) < family_div
-        sub = torch.randint(1, 4, copies.shape, generator=g, dtype=torch.uint8)
-        copies = torch.where(hit, (copies + sub) & 3, copies)
-        idx = pos[:, None] + torch.arange(family_len)[None, :]
-        genome[idx.reshape(-1)] = copies.reshape(-1)
-    return genome.to(device)
+        elem = torch.randint(0, 4, (family_len,), generator=g, dtype=torch.uint8, device=dev)
+        ar = torch.arange(family_len, device=dev)
+        for a in range(0, family_copies, 1 << 18):              # in slabs: a million copies are 300 M cells
+            m = min(1 << 18, family_copies - a)
+            pos = torch.randint(0, size - family_len, (m,), generator=g, device=dev)
+            copies = elem[None, :].repeat(m, 1)
+            hit = torch.rand(copies.shape, generator=g, device=dev) < family_div
+            sub = torch.randint(1, 4, copies.shape, generator=g, dtype=torch.uint8, device=dev)
+            copies = torch.where(hit, (copies + sub) & 3, copies)
+            genome[(pos[:, None] + ar[None, :]).reshape(-1)] = copies.reshape(-1)
+            del pos, copies, hit, sub
+    if low_complexity_frac > 0 and size > 4000:
+        span = 200
+        n = max(1, int(size * low_complexity_frac / span))
+        ar = torch.arange(span, device=dev)
+        for a in range(0, n, 1 << 18):
+            m = min(1 << 18, n - a)
+            pos = torch.randint(0, size - span, (m,), generator=g, device=dev)
+            unit_len = torch.randint(1, 7, (m,), generator=g, device=dev)
+            unit = torch.randint(0, 4, (m, 6), generator=g, dtype=torch.uint8, device=dev)
+            cells = torch.gather(unit, 1, ar[None, :] % unit_len[:, None])
+            genome[(pos[:, None] + ar[None, :]).reshape(-1)] = cells.reshape(-1)
+            del pos, unit_len, unit, cells
+    return genome
 
 
 def make_reads(genome, n_pairs, seed, read_len=100, err=0.005, unbar_frac=0.10,
                pairs_per_barcode=20, tails=(0, 0, 0, 5, 15), quals=(30, 35, 37),
-               chunk=1 << 22):
+               chunk=1 << 22, ragged_frac=0.0):
     """-> ReadSet on genome.device.  All random draws happen on that device (a seeded torch.Generator), so a
     30x human-scale set is generated in HBM without touching the host."""
     dev = genome.device
@@ -127,23 +147,45 @@ def make_reads(genome, n_pairs, seed, read_len=100, err=0.005, unbar_frac=0.10,
         packed[2 * a : 2 * b] = c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)
         del both, c
 
-    # PQVec: [L-tail x Q][tail x Q2] as nBits=0 blocks {nQs, minQ<<3 (low byte), minQ>>5} + the 0 terminator
+    # PQVec: [L-tail x Q][tail x Q2] as nBits=0 blocks {nQs, minQ<<3 (low byte), minQ>>5} + the 0 terminator.
+    # ragged_frac of the reads get per-base qualities instead: their body is ONE nBits=2 block (values minQ..minQ+3,
+    # random; 17 header bits then 2 bits per quality, LSB-first -- feudal/PQVec.cc:87-127), minQ mostly 33, for one
+    # such read in sixteen 5: qualities 5..8 straddle MIN_QUAL = 7, so the trim's run rule works base by base.
     tail_choices = torch.tensor(tails, dtype=torch.int64, device=dev)
     qual_choices = torch.tensor(quals, dtype=torch.int64, device=dev)
     tail = tail_choices[ri(0, len(tails), n_reads)]
     qbody = qual_choices[ri(0, len(quals), n_reads)]
     has_tail = tail > 0
+    body_bytes = torch.full((n_reads,), 3, dtype=torch.int64, device=dev)
+    if ragged_frac > 0:
+        ragged = torch.rand(n_reads, generator=g, device=dev) < ragged_frac
+        low = ragged & (ri(0, 16, n_reads) == 0)
+        qbody = torch.where(ragged, torch.where(low, 5, 33), qbody)
+        body_bytes = torch.where(ragged, (2 * (L - tail) + 24) >> 3, body_bytes)
+        del low
     pq_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
-    pq_off[1:] = torch.cumsum(torch.where(has_tail, 7, 4), 0)
-    pq = torch.zeros(int(pq_off[-1]), dtype=torch.uint8, device=dev)
+    pq_off[1:] = torch.cumsum(body_bytes + torch.where(has_tail, 3, 0) + 1, 0)
+    total = int(pq_off[-1])
+    if ragged_frac > 0:                      # payload bits are random; headers, tails and terminators are written over them
+        pq = torch.randint(0, 256, (total,), generator=g, dtype=torch.uint8, device=dev)
+    else:
+        pq = torch.zeros(total, dtype=torch.uint8, device=dev)
     o = pq_off[:-1]
     pq[o] = (L - tail).to(torch.uint8)
-    pq[o + 1] = ((qbody << 3) & 0xFF).to(torch.uint8)
-    pq[o + 2] = (qbody >> 5).to(torch.uint8)
-    ot = o[has_tail]
-    pq[ot + 3] = tail[has_tail].to(torch.uint8)
-    pq[ot + 4] = (2 << 3) & 0xFF
-    del tail, qbody, has_tail, o, ot
+    if ragged_frac > 0:
+        nbits = torch.where(ragged, 2, 0)
+        pq[o + 1] = (((qbody << 3) & 0xFF) | nbits).to(torch.uint8)
+        pq[o + 2] = torch.where(ragged, (pq[o + 2] & 0xFE) | (qbody >> 5).to(torch.uint8), (qbody >> 5).to(torch.uint8))
+        del ragged, nbits
+    else:
+        pq[o + 1] = ((qbody << 3) & 0xFF).to(torch.uint8)
+        pq[o + 2] = (qbody >> 5).to(torch.uint8)
+    ot = (o + body_bytes)[has_tail]
+    pq[ot] = tail[has_tail].to(torch.uint8)
+    pq[ot + 1] = (2 << 3) & 0xFF
+    pq[ot + 2] = 0
+    pq[pq_off[1:] - 1] = 0
+    del tail, qbody, has_tail, o, ot, body_bytes
     bc = torch.repeat_interleave(pair_bc, 2)
     return ReadSet(
         packed=packed.reshape(-1),

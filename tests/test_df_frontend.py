@@ -85,13 +85,89 @@ def test_lr_select_frac_follows_the_reference_random_stream(tmp_path, golden_dir
         assert rd(f"{tmp_path}/w/data/{name}") == rd(f"{golden_dir}/side_frac07/{name}"), name
 
 
+def test_runall_command_line_parses_without_a_gpu(tmp_path, golden_dir):
+    """runall.sh:127 passes MAX_MEM_GB=640 -- a HOST memory cap (system/System.cc:1073-1078), not a device budget --
+    beside PIPELINE/ALIGN/NUM_THREADS; the ingest half must run with exactly those arguments."""
+    r = run_df(f"ROOT={tmp_path}", f"LR={golden_dir}/reads.fastb", "PIPELINE=cs", "ALIGN=False", "NUM_THREADS=8", "MAX_MEM_GB=640",
+               "EXIT_LOAD=True")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.exists(f"{tmp_path}/GapToy/1/data/frag_reads_orig.fastb")
+
+
+def test_malformed_feudal_offsets_are_refused(tmp_path, golden_dir):
+    raw = bytearray(open(f"{golden_dir}/reads.qualp", "rb").read())
+    var_tab = int.from_bytes(raw[8:16], "little")
+    raw[var_tab + 8 * 5: var_tab + 8 * 6] = (var_tab + 1000).to_bytes(8, "little")      # an offset past the var data
+    for ext in ("fastb", "bci"):
+        open(f"{tmp_path}/bad.{ext}", "wb").write(open(f"{golden_dir}/reads.{ext}", "rb").read())
+    open(f"{tmp_path}/bad.qualp", "wb").write(raw)
+    r = run_df(f"LR={tmp_path}/bad.fastb", f"OUT_DIR={tmp_path}/w", "EXIT_LOAD=True")
+    assert r.returncode == 1 and "offset table" in r.stderr
+
+
+def _kvec(path):
+    kv = open(path, "rb").read()
+    assert kv[:8] == b"BINWRITE"
+    n = int.from_bytes(kv[8:16], "little")
+    assert len(kv) == 16 + 32 * n
+    from superplus_amd.dfk import ENTRY_DTYPE
+    return kv, np.frombuffer(kv, ENTRY_DTYPE, count=n, offset=16)
+
+
 @pytest.mark.gpu
 def test_df_end_to_end_on_gpu(tmp_path, golden_dir, oracle):
+    from tests import util
     r = run_df(f"LR={golden_dir}/reads.fastb", f"OUT_DIR={tmp_path}/w", "K=48")
     assert r.returncode == 0, r.stdout + r.stderr
     exp = np.load(f"{golden_dir}/expect_k48.npz")
     assert open(f"{tmp_path}/w/stats/histogram_kmer_count.json").read() == oracle.spectrum_json(exp["spectrum"])
-    kv = open(f"{tmp_path}/w/kmers.kvec", "rb").read()
-    assert kv[:8] == b"BINWRITE" and int.from_bytes(kv[8:16], "little") == len(exp["solid_post"])
-    assert kv[16:] == exp["solid_post"].tobytes()
+    # kmers.kvec holds the dictionary in device order (the reference's is in thread-arrival order): same entries
+    _, e = _kvec(f"{tmp_path}/w/kmers.kvec")
+    util.assert_same_solid(e[np.lexsort((e["w1"], e["w0"]))], exp["solid_post"], "kmers.kvec, sorted here")
     assert f"dictionary covers {len(exp['solid_post']):,}".replace(",", "") in r.stdout.replace(",", "")
+    assert "DF_TIMING {" in r.stdout and '"fast_path": true' in r.stdout
+    # ... and byte for byte the sorted dictionary on request
+    r = run_df(f"LR={golden_dir}/reads.fastb", f"OUT_DIR={tmp_path}/w2", "K=48", "KVEC_SORTED=True")
+    assert r.returncode == 0, r.stdout + r.stderr
+    kv, _ = _kvec(f"{tmp_path}/w2/kmers.kvec")
+    assert kv[16:] == exp["solid_post"].tobytes()
+    rd = lambda p: open(p, "rb").read()
+    for ext in ("fastb", "qualp", "bci"):
+        assert rd(f"{tmp_path}/w/data/frag_reads_orig.{ext}") == rd(f"{golden_dir}/reads.{ext}"), ext
+
+
+@pytest.mark.gpu
+def test_runall_command_line_on_gpu(tmp_path, golden_dir, oracle):
+    """The full command line of runall.sh:127, unchanged: MAX_MEM_GB=640 must not become a 640 GiB HBM plan.  The
+    transfers are forced through the many-chunk staged path (a few KB per chunk, three host threads)."""
+    from tests import util
+    env = dict(os.environ, DFK_XFER_CHUNK="4096", DFK_HOST_THREADS="3")
+    r = subprocess.run([DF, f"ROOT={tmp_path}", f"LR={golden_dir}/reads.fastb", "PIPELINE=cs", "ALIGN=False", "NUM_THREADS=8",
+                        "MAX_MEM_GB=640"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = np.load(f"{golden_dir}/expect_k48.npz")
+    w = f"{tmp_path}/GapToy/1"
+    assert open(f"{w}/stats/histogram_kmer_count.json").read() == oracle.spectrum_json(exp["spectrum"])
+    _, e = _kvec(f"{w}/kmers.kvec")
+    util.assert_same_solid(e[np.lexsort((e["w1"], e["w0"]))], exp["solid_post"], "kmers.kvec through the staged transfers")
+
+
+@pytest.mark.gpu
+def test_df_general_path_on_gpu(tmp_path, golden_dir, oracle):
+    """Two inputs (LoadData reorders): the gathered arrays go through the same count."""
+    from tests import util
+    from oracle import pyoracle
+    r = run_df("LR={" + f"{golden_dir}/reads.fastb,{golden_dir}/reads.fastb" + "}", f"OUT_DIR={tmp_path}/w", "K=48", "HBM_GB=8")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert '"fast_path": false' in r.stdout
+    w = f"{tmp_path}/w/data/frag_reads_orig"
+    packed, boff, rlen = feudal.read_fastb(w + ".fastb")
+    pq, qoff = feudal.read_qualp(w + ".qualp")
+    bci = feudal.read_bci(w + ".bci")
+    bc = np.zeros(len(rlen), np.int32)
+    for b in range(len(bci) - 1):
+        bc[int(bci[b]):int(bci[b + 1])] = b
+    ref = pyoracle.run(packed, boff, rlen, pq, qoff, bc, K=48)
+    _, e = _kvec(f"{tmp_path}/w/kmers.kvec")
+    util.assert_same_solid(e[np.lexsort((e["w1"], e["w0"]))], ref["solid"], "two-input run")
+    assert open(f"{tmp_path}/w/stats/histogram_kmer_count.json").read() == oracle.spectrum_json(ref["hist"])

@@ -116,3 +116,68 @@ def test_single_rank_and_bad_splits():
     res = q.get(timeout=120)
     p.join(timeout=60)
     assert res == "ok", res
+
+
+def _failing_rank(rank, world, port, q, fail_in):
+    """DistDfk.count_device with the library calls replaced by CPU stand-ins; rank 1 fails in `fail_in`."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from superplus_amd import dist as D
+        from superplus_amd.dfk import DfkError
+
+        class Stub(D.DistDfk):
+            def __init__(self):                         # no context: every library call is overridden
+                self.comm = None; self._n_inst_global = 0; self._ctx = None
+
+            def _maybe(self, what):
+                if rank == 1 and what == fail_in:
+                    raise DfkError(-4, f"injected failure in {what}")
+
+            def begin(self, *a, **k): self._maybe("begin"); return 1000
+            def plan(self, world, n): self._maybe("plan"); return 1            # two passes
+            def partition(self, world, n, l, p): self._maybe("partition%d" % p); return torch.zeros(32 * 3 * world, dtype=torch.uint8), [3] * world
+            def recv_buffer(self, n): self._maybe("recv"); return torch.zeros(32 * n, dtype=torch.uint8)
+            def count_records(self, recv, p): self._maybe("count%d" % p)
+            def adj_queries(self, world): self._maybe("adjq"); return torch.zeros(16 * 2 * world, dtype=torch.uint8), [2] * world
+            def adj_answer(self, keys): self._maybe("adja"); return torch.ones(keys.numel() // 16, dtype=torch.uint8)
+            def adj_apply(self, present): pass
+            def close(self): pass
+
+        t = torch.zeros(4, dtype=torch.uint8)
+        try:
+            Stub().count_device(t, t, t, t, t, t)
+            q.put((rank, "completed"))
+        except DfkError as e:
+            q.put((rank, "DfkError %d" % e.code))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_in", ["none", "begin", "plan", "partition0", "recv", "count0", "partition1", "count1", "adjq", "adja"])
+def test_one_rank_failing_stops_every_rank(fail_in):
+    """A library call that fails on one rank only (its own data, its own HBM budget) must end the run on EVERY rank
+    with an error, not leave the others inside the next collective: the driver all-reduces a status
+    word after each local phase."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + int(np.random.default_rng().integers(0, 2000))
+    procs = [ctx.Process(target=_failing_rank, args=(r, 2, port, q, fail_in)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = dict(q.get(timeout=90) for _ in range(2))
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()
+    if fail_in == "none":
+        assert res == {0: "completed", 1: "completed"}, res
+    else:
+        assert res == {0: "DfkError -4", 1: "DfkError -4"}, res

@@ -251,3 +251,74 @@ def test_output_segments_too_small_are_redone(oracle):
     ref, d = util.run_both(oracle, rs, K=48, min_freq=1, min_bc=0)
     st = util.check_parity(ref, d)
     assert st["n_solid"] > 8_000_000
+
+
+def test_budget_above_free_hbm_is_clamped(oracle):
+    """runall.sh hands every binary MAX_MEM_GB=640; a caller that forwards such a figure as the device budget must get
+    90 % of the free HBM, not a plan for room that does not exist (dfk_create clamps)."""
+    import torch
+    rs = util.make_set(91, 200000, 30000)
+    ref, d = util.run_both(oracle, rs, K=48, hbm_budget_bytes=640 << 30)
+    st = util.check_parity(ref, d)
+    assert st["n_passes"] == 1 and st["hbm_bytes_peak"] < torch.cuda.get_device_properties(0).total_memory
+
+
+def test_count_saturates_at_2_pow_24_in_the_hbm_table(oracle):
+    """KDef::setCount saturates at 2^24-1 (ReadPather.h:128-129).  330 k poly-A reads put 17.5 M instances of ONE 48-mer
+    into one fine bucket, which is counted in an HBM table by the whole grid: the count must stop at exactly 2^24-1
+    and must not carry into the slot's fingerprint byte (which would make the k-mer claim a second slot)."""
+    n = 330_000
+    rng = np.random.default_rng(17)
+    extra = rng.integers(0, 4, (3000, 100), dtype=np.uint8)
+    extra[1000:2000] = extra[:1000]; extra[2000:] = extra[:1000]      # some other solid k-mers (three copies, barcodes differ)
+    from superplus_amd import feudal
+    packed = np.concatenate([np.zeros(25 * n, np.uint8), feudal.pack_bases(extra).reshape(-1)])
+    N = n + len(extra)
+    blk = np.array([100, (35 << 3) & 0xFF, 35 >> 5, 0], np.uint8)      # one nBits=0 block of Q35 + terminator
+    rs = dict(packed=packed, base_off=(np.arange(N + 1, dtype=np.uint64) * 25), read_len=np.full(N, 100, np.uint32),
+              pq_bytes=np.tile(blk, N), pq_off=(np.arange(N + 1, dtype=np.uint64) * 4),
+              bc=(1 + np.arange(N) % 7).astype(np.int32), n_reads=N)
+    ref, d = util.run_both(oracle, rs, K=48)
+    st = util.check_parity(ref, d)
+    s = d.solid()
+    top = s[s["w0"] == 0]
+    assert len(top) == 1 and (top["count_ctx"][0] & 0xFFFFFF) == 0xFFFFFF      # poly-A, saturated
+    assert st["n_inst"] > (1 << 24) and len(d.spectrum()) == 1 << 24
+
+
+def test_malformed_offset_tables_are_an_error():
+    """The offset tables are checked on the device before anything is read through them (DFK_E_INPUT, no stray read)."""
+    from superplus_amd.dfk import Dfk, DfkError
+    base = _custom([np.zeros(100, np.uint8)] * 64, [np.full(100, 30, np.uint8)] * 64)
+    def broken(key, idx, val):
+        rs = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in base.items()}
+        rs[key][idx] = val
+        return rs
+    cases = [broken("pq_off", 10, 1 << 40),                      # a quality stream far outside the array
+             broken("pq_off", 10, 0),                            # not ascending
+             broken("base_off", 20, 1 << 40), broken("base_off", 20, 3),
+             broken("read_len", 5, 4000)]                        # more bases than the read has bytes
+    for rs in cases:
+        with pytest.raises(DfkError) as e:
+            Dfk(K=48).count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+        assert e.value.code == -5, e.value
+
+
+def test_kvec_file_device_order_and_sorted(oracle, tmp_path):
+    rs = util.make_set(93, 300000, 50000)
+    ref, d = util.run_both(oracle, rs, K=48, passes=3)
+    from superplus_amd.dfk import ENTRY_DTYPE
+    def load(path):
+        kv = open(path, "rb").read()
+        n = int.from_bytes(kv[8:16], "little")
+        assert kv[:8] == b"BINWRITE" and len(kv) == 16 + 32 * n
+        return np.frombuffer(kv, ENTRY_DTYPE, count=n, offset=16)
+    d.write_kvec(f"{tmp_path}/a.kvec")
+    a = load(f"{tmp_path}/a.kvec")
+    util.assert_same_solid(a[np.lexsort((a["w1"], a["w0"]))], ref["solid"], "device-order kvec")
+    assert np.array_equal(a, d.solid_unsorted())
+    d.write_kvec(f"{tmp_path}/b.kvec", in_order=True)
+    util.assert_same_solid(load(f"{tmp_path}/b.kvec"), ref["solid"], "sorted kvec")
+    d.write_kvec(f"{tmp_path}/c.kvec", pre_adjacency=True)
+    c = load(f"{tmp_path}/c.kvec")
+    util.assert_same_solid(c[np.lexsort((c["w1"], c["w0"]))], ref["solid_pre"], "pre-adjacency kvec")

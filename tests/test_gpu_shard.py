@@ -123,9 +123,13 @@ def test_one_process_per_rank(oracle, world):
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, shards[r], q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=60)
+    try:
+        res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    finally:
+        for p in procs:                                  # a rank that is still there (hung in a collective) must not outlive the test
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
     assert all(r[1] == "ok" for r in res), [r[1] for r in res]
     allk = np.concatenate([r[2] for r in res])
     util.assert_same_solid(allk[np.lexsort((allk["w1"], allk["w0"]))], ref["solid"], "one process per rank")

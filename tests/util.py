@@ -30,19 +30,7 @@ def run_both(oracle, rs, K=48, min_qual=7, min_freq=3, min_bc=2, use_bc=True, ig
     return ref, d
 
 
-def _mix(x):
-    x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xBF58476D1CE4E5B9)
-    x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94D049BB133111EB)
-    return x ^ (x >> np.uint64(31))
-
-
-def digest_of(entries):
-    """numpy form of k_digest (dfk_solid_digest) over 32-byte dictionary entries: (sum, xor)."""
-    w = np.ascontiguousarray(entries).view(np.uint64).reshape(-1, 4)
-    with np.errstate(over="ignore"):
-        h = _mix(w[:, 0] ^ _mix(w[:, 1] ^ _mix(w[:, 2] ^ _mix(w[:, 3] + np.uint64(0x9E3779B97F4A7C15)))))
-        x = _mix(h + np.uint64(0xD1B54A32D192ED03))
-        return int(h.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(x)) if len(x) else 0
+from superplus_amd.dfk import digest_of  # noqa: E402,F401  (the numpy form of k_digest lives beside the binding)
 
 
 def check_parity(ref, d):
