@@ -28,7 +28,7 @@
 //                                        the reference's BaseVec/PQVecEncoder/feudal writer
 //   rdreads  head out.raw                reference reader -> raw reads/quals
 //   side     head outdir                 .lens/.qhist/.dti/subsam.* as DF's ingest writes them (reference BinaryWriter)
-//   dict K head outdir minQual minFreq minBC useBC nThreads
+//   dict K head outdir minQual minFreq minBC useBC nThreads [ignBcBelow]
 //                                        goodlens.u32, kmers.kvec (pre-adjacency, written by
 //                                        the reference's BinaryWriter), solid.bin (post
 //                                        recomputeAdjacencies, sorted), spectrum.txt, times.txt
@@ -158,7 +158,7 @@ struct Rec { uint64_t w0, w1; uint32_t edge, cc; int32_t bc; uint32_t pad; };
 
 template <unsigned K>
 int runDict( std::string const& head, std::string const& outdir, unsigned minQual,
-             unsigned minFreq, unsigned minBC, bool useBC, unsigned nThreads )
+             unsigned minFreq, unsigned minBC, bool useBC, unsigned nThreads, int64_t ignBcBelow )
 {
     typedef RefImpl<K> Impl;
     typedef typename Impl::Entry Entry;
@@ -197,12 +197,12 @@ int runDict( std::string const& head, std::string const& outdir, unsigned minQua
     {
         std::atomic_size_t nSolid(0);
         { Impl impl; impl.reads=&reads; impl.goodLens=&goodLens; impl.bc = useBC?&bc:nullptr;
-          impl.minFreq=minFreq; impl.minBC=minBC; impl.nSolid=&nSolid;
+          impl.minFreq=minFreq; impl.minBC=minBC; impl.nSolid=&nSolid; impl.ignBcBelow=ignBcBelow;
           MapReduceEngine<Impl,Entry,typename Kmer::Hasher> mre(impl);
           if ( !mre.run(nKeys,0ul,reads.size()) ) { fprintf(stderr,"mre run1 failed\n"); return 2; } }
         t2 = now_s();
         { Impl impl; impl.reads=&reads; impl.goodLens=&goodLens; impl.bc = useBC?&bc:nullptr;
-          impl.minFreq=minFreq; impl.minBC=minBC; impl.out=&kv;
+          impl.minFreq=minFreq; impl.minBC=minBC; impl.out=&kv; impl.ignBcBelow=ignBcBelow;
           typedef MapReduceEngine<Impl,Entry,typename Kmer::Hasher> MRE;
           MRE mre(impl);
           if ( !mre.run(nKeys,0ul,reads.size(),MRE::VERBOSITY::NOISY) )
@@ -386,15 +386,16 @@ int main( int argc, char** argv )
     if ( cmd == "rdreads" && argc == 4 ) return rdreads(argv[2],argv[3]);
     if ( cmd == "side" && argc == 4 ) return side(argv[2],argv[3]);
     if ( cmd == "side" && argc == 5 ) return side(argv[2],argv[3],atof(argv[4]));
-    if ( cmd == "dict" && argc == 10 )
+    if ( cmd == "dict" && ( argc == 10 || argc == 11 ) )
     {
+        int64_t ign = argc == 11 ? atoll(argv[10]) : 0;          // createDict's ignBcBelow (= DF's bc_start)
         unsigned K = atoi(argv[2]);
         std::string head = argv[3], outdir = argv[4];
         unsigned minQual = atoi(argv[5]), minFreq = atoi(argv[6]), minBC = atoi(argv[7]);
         bool useBC = atoi(argv[8]) != 0; unsigned nThreads = atoi(argv[9]);
-        if ( K == 48 ) return runDict<48>(head,outdir,minQual,minFreq,minBC,useBC,nThreads);
-        if ( K == 40 ) return runDict<40>(head,outdir,minQual,minFreq,minBC,useBC,nThreads);
-        if ( K == 60 ) return runDict<60>(head,outdir,minQual,minFreq,minBC,useBC,nThreads);
+        if ( K == 48 ) return runDict<48>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign);
+        if ( K == 40 ) return runDict<40>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign);
+        if ( K == 60 ) return runDict<60>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign);
         fprintf(stderr,"K must be 40, 48 or 60\n"); return 1;
     }
     fprintf(stderr,"bad arguments\n");

@@ -726,7 +726,7 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
         tot_inst += inst;
         uint32_t l2 = std::max<uint32_t>(13, ceil_log2(2 * inst + 64));
         items.push_back(BigItem{singles[i].b0, singles[i].b1, words, l2, 0});
-        words += (uint64_t)(KW + 3 + (NBC > 1 ? NBC - 1 : 0)) << l2;
+        words += (uint64_t)(KW + 4 + (NBC > 1 ? NBC - 1 : 0)) << l2;   // keys, state, contexts, counts, barcode words (BigView)
         chunk_pre[i + 1] = chunk_pre[i] + (rec[2 * i + 1] - rec[2 * i] + COUNT_CHUNK - 1) / COUNT_CHUNK;
         slot_pre[i + 1] = slot_pre[i] + (1ull << l2);
     }

@@ -117,6 +117,5 @@ constexpr uint32_t BCW_MULTI = 0x80000000u;   // barcode word: first barcode see
 constexpr uint32_t CNT_LOCK  = 0x00FFFFFFu;
 constexpr uint32_t CNT_MASK  = 0x00FFFFFFu;
 constexpr uint32_t CNT_NEAR_SAT = 0x00FFFF00u;  // above this the count is bumped by compare-and-swap so that it saturates exactly
-constexpr uint32_t CNT_NEAR_SAT_GRID = 0x00F00000u;  // the same for a table the whole grid inserts into (k_big_insert)
 
 } // namespace dfk

@@ -725,16 +725,25 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
     }
 #endif
     if (state == PS_FOUND) {
-        // The plain add is safe while (count seen at probe time) + (lanes that can sit between their probe and their
-        // add) stays below 2^24.  An LDS table sees at most the 1024 lanes of its workgroup; an HBM table is shared by
-        // the whole grid (a hot k-mer sends every resident lane to one slot: up to 256 CUs x 2048 lanes), so its margin
-        // is 2^20 -- beyond it the count would carry into the fingerprint byte and the k-mer would claim a second slot.
-        if ((seen & CNT_MASK) < (LDS_TABLE ? CNT_NEAR_SAT : CNT_NEAR_SAT_GRID)) atomicAdd(&cnt[slot], 1u);
-        else {                                                            // saturate exactly at 2^24-1 (KDef::setCount)
-            uint32_t cur = tld(&cnt[slot]);
-            while ((cur & CNT_MASK) != CNT_MASK &&
-                   !__hip_atomic_compare_exchange_strong(&cnt[slot], &cur, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT)) {}
+        if (LDS_TABLE) {
+            // an LDS table sees at most its item's instances (a few thousand; a sub-pass 256 x 1024): the plain add is
+            // safe below CNT_NEAR_SAT, above it the count is bumped by compare-and-swap so that it saturates exactly
+            if ((seen & CNT_MASK) < CNT_NEAR_SAT) atomicAdd(&cnt[slot], 1u);
+            else {                                                        // saturate exactly at 2^24-1 (KDef::setCount)
+                uint32_t cur = tld(&cnt[slot]);
+                while ((cur & CNT_MASK) != CNT_MASK &&
+                       !__hip_atomic_compare_exchange_strong(&cnt[slot], &cur, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)) {}
+            }
+        } else {
+            // An HBM table is shared by the whole grid, and a hot k-mer (poly-A: 10^7 instances of ONE key) sends every
+            // resident lane to one slot.  No margin on the 24-bit field is safe there: between a lane's probe and its add
+            // any number of other lanes can finish theirs, and a carry into the fingerprint byte makes the k-mer claim a
+            // second slot (seen: 330 k poly-A reads gave one distinct k-mer too many).  So the count of an HBM table is a
+            // word of its own (after the context words), clamped by undoing an add that finds it at 2^31; the readers
+            // (k_big_flags, k_big_emit) take min(count, 2^24-1).
+            uint32_t* wide = ctxs + S;
+            if (atomicAdd(&wide[slot], 1u) >= 0x7FFFFFFFu) atomicSub(&wide[slot], 1u);
         }
         atomicOr(&ctxs[slot], A.ctx);
         if (NBC > 0) {
@@ -1235,14 +1244,18 @@ k_big_insert(const uint4* __restrict__ records, const BigItem* __restrict__ item
             uint32_t* keys = tab_pool + I.tab_off;
             uint32_t* cnt = keys + (size_t)KW * S;
             const uint64_t rb = rec_base[I.b0] + (t - chunk_pre[it]) * COUNT_CHUNK;
-            wave_count_chunk<K, NBC, false>(records, rb, rec_base[I.b1], &stages[wave], lane, keys, cnt, cnt + S, cnt + 2 * (size_t)S, S, &fill, &ovf);
+            wave_count_chunk<K, NBC, false>(records, rb, rec_base[I.b1], &stages[wave], lane, keys, cnt, cnt + S, cnt + 3 * (size_t)S, S, &fill, &ovf);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0 && ovf) atomicOr(failed, 1u);
 }
 
-template <int K> struct BigView { uint32_t* keys; uint32_t* cnt; uint32_t* ctxs; uint32_t* bcw; uint32_t S, slot; };
+// words of an HBM table: [KW][S] keys, [S] state (fingerprint << 24, see table_insert), [S] contexts, [S] counts, then the barcode words
+template <int K> struct BigView {
+    uint32_t* keys; uint32_t* cnt; uint32_t* ctxs; uint32_t* wide; uint32_t* bcw; uint32_t S, slot;
+    __device__ __forceinline__ uint32_t count() const { const uint32_t c = tld(&wide[slot]); return c < CNT_MASK ? c : CNT_MASK; }   // KDef::setCount saturates at 2^24-1
+};
 template <int K>
 __device__ __forceinline__ BigView<K> big_view(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_pre, uint32_t n_items,
                                                uint32_t* __restrict__ tab_pool, uint64_t x)
@@ -1252,7 +1265,7 @@ __device__ __forceinline__ BigView<K> big_view(const BigItem* __restrict__ items
     const uint32_t S = 1u << I.log2s;
     uint32_t* keys = tab_pool + I.tab_off;
     uint32_t* cnt = keys + (size_t)KTraits<K>::KW * S;
-    return BigView<K>{keys, cnt, cnt + S, cnt + 2 * (size_t)S, S, (uint32_t)(x - slot_pre[it])};
+    return BigView<K>{keys, cnt, cnt + S, cnt + 2 * (size_t)S, cnt + 3 * (size_t)S, S, (uint32_t)(x - slot_pre[it])};
 }
 
 template <int K, int NBC>
@@ -1267,7 +1280,7 @@ k_big_flags(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot
         const uint32_t c = tld(&v.cnt[v.slot]);
         if (!c) continue;
         ++occ;
-        const bool solid = (c & CNT_MASK) >= cp.min_freq && bc_pass<(NBC > 0)>(NBC > 0 ? tld(&v.bcw[v.slot]) : 0u, cp.min_bc);
+        const bool solid = v.count() >= cp.min_freq && bc_pass<(NBC > 0)>(NBC > 0 ? tld(&v.bcw[v.slot]) : 0u, cp.min_bc);
         if (solid && cp.do_adj && cp.keep_pre) { const uint32_t ctx = tld(&v.ctxs[v.slot]) & 0xFFu; tst(&v.ctxs[v.slot], ctx | (ctx << 8)); }
         tst(&v.bcw[v.slot], solid ? FLAG_SOLID : 0u);
     }
@@ -1330,7 +1343,7 @@ k_big_emit(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_
         if (lane == 0) wbase = atomicAdd(&g->big_cursor, (unsigned long long)__popcll(mk));
         wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
         if (!solid) continue;
-        const uint32_t S = v.S, slot = v.slot, count = c & CNT_MASK;
+        const uint32_t S = v.S, slot = v.slot, count = v.count();
         const uint32_t cw = tld(&v.ctxs[slot]);
         const uint32_t pending = flags & 0xFFu & cw;
         boundary += pending != 0;

@@ -56,6 +56,55 @@ def make_raw(seed, G, n_pairs):
     return reads, quals, bci
 
 
+def make_hot(seed, n_reads):
+    """Reads that all contain AGTACGGTATGCTCAC -- the one 16-mer whose minimizer rank is 0 in libdfk (dfk_device.h) --
+    so that thousands of distinct k-mers share ONE fine bucket, plus a diverged repeat family and exact duplicates
+    (so that solid k-mers exist): the input of the sub-pass and HBM-table paths."""
+    rng = np.random.default_rng(seed)
+    hot = np.array(["ACGT".index(ch) for ch in "AGTACGGTATGCTCAC"], np.uint8)
+    elem = rng.integers(0, 4, 100, dtype=np.uint8)
+    reads, quals = [], []
+    for i in range(n_reads):
+        if i % 5 == 4:                                   # a copy of the family element, 5 % diverged
+            r = elem.copy(); hit = rng.random(100) < 0.05
+            r[hit] = (r[hit] + rng.integers(1, 4, int(hit.sum()))) & 3
+        else:
+            r = rng.integers(0, 4, 100, dtype=np.uint8)
+            r[42:58] = hot
+        if i % 3 == 0 and reads:
+            r = reads[-1].copy()
+        if rng.random() < 0.3:
+            r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r); quals.append(np.full(100, 30, np.uint8))
+    n_unbar = 2 * (n_reads // 16)
+    bcs = np.sort(np.concatenate([np.zeros(n_unbar // 2, int), rng.integers(1, 9, (n_reads - n_unbar) // 2)]))
+    bci = np.concatenate([[0], np.cumsum(np.bincount(bcs, minlength=9) * 2)]).astype(np.int64)
+    return reads, quals, bci
+
+
+def run_dict(head, out, K, use_bc, min_bc, min_freq=3, ign=0):
+    os.makedirs(out, exist_ok=True)
+    subprocess.check_call([REFDRV, "dict", str(K), head, out, "7", str(min_freq), str(min_bc), str(use_bc), "4", str(ign)],
+                          stdout=subprocess.DEVNULL)
+    post = np.fromfile(out + "/solid.bin", ENTRY)
+    kv = open(out + "/kmers.kvec", "rb").read()
+    assert kv[:8] == b"BINWRITE"
+    n = struct.unpack("<Q", kv[8:16])[0]
+    pre = np.frombuffer(kv, ENTRY, count=n, offset=16).copy()
+    pre["bc"] = -1; pre["pad"] = 0                       # tempBC / pad are arbitrary in the reference
+    pre = pre[np.lexsort((pre["w1"], pre["w0"]))]
+    good = np.fromfile(out + "/goodlens.u32", np.uint32)
+    spec = np.loadtxt(out + "/spectrum.txt", dtype=np.int64, ndmin=1)
+    subprocess.check_call(["rm", "-rf", out])
+    return good, pre, post, spec
+
+
+# filter variants of createDict (BuildReadQGraph48.cc:104-132,167-174,313) on the golden reads: (tag, min_freq, min_bc, use_bc, ign_bc_below)
+VARIANTS = [("minbc0", 3, 0, 1, 0), ("minbc3", 3, 3, 1, 0), ("minbc4", 3, 4, 1, 0), ("minfreq1", 1, 2, 1, 0),
+            ("minfreq2", 2, 2, 1, 0), ("minfreq5", 5, 2, 1, 0), ("ign600", 3, 2, 1, 600), ("ign600_minbc3_minfreq2", 2, 3, 1, 600),
+            ("ign_all", 5, 2, 1, 10 ** 9), ("minfreq1_nobc", 1, 0, 0, 0)]
+
+
 def write_raw(path, reads, quals):
     with open(path, "wb") as f:
         f.write(struct.pack("<Q", len(reads)))
@@ -82,23 +131,33 @@ def main():
     os.makedirs(side07, exist_ok=True)
     subprocess.check_call([REFDRV, "side", head, side07, "0.7"])   # the same with LR_SELECT_FRAC = 0.7 (+ the selected reads themselves)
     for K, use_bc, min_bc, tag in ((48, 1, 2, "k48"), (48, 1, 1, "k48_minbc1"), (40, 0, 0, "k40_nobc"), (60, 0, 0, "k60_nobc")):
-        out = os.path.join(HERE, "tmp_" + tag)
-        os.makedirs(out, exist_ok=True)
-        subprocess.check_call([REFDRV, "dict", str(K), head, out, "7", "3", str(min_bc), str(use_bc), "4"],
-                              stdout=subprocess.DEVNULL)
-        post = np.fromfile(out + "/solid.bin", ENTRY)
-        kv = open(out + "/kmers.kvec", "rb").read()
-        assert kv[:8] == b"BINWRITE"
-        n = struct.unpack("<Q", kv[8:16])[0]
-        pre = np.frombuffer(kv, ENTRY, count=n, offset=16).copy()
-        pre["bc"] = -1; pre["pad"] = 0                       # tempBC / pad are arbitrary in the reference
-        pre = pre[np.lexsort((pre["w1"], pre["w0"]))]
-        np.savez_compressed(os.path.join(HERE, f"expect_{tag}.npz"),
-                            good_len=np.fromfile(out + "/goodlens.u32", np.uint32),
-                            solid_post=post, solid_pre=pre,
-                            spectrum=np.loadtxt(out + "/spectrum.txt", dtype=np.int64, ndmin=1))
+        good, pre, post, spec = run_dict(head, os.path.join(HERE, "tmp_" + tag), K, use_bc, min_bc)
+        np.savez_compressed(os.path.join(HERE, f"expect_{tag}.npz"), good_len=good, solid_post=post, solid_pre=pre, spectrum=spec)
         print(tag, "solid", len(post), "ctx rewritten by adjacency", int((post["count_ctx"] != pre["count_ctx"]).sum()))
-        subprocess.check_call(["rm", "-rf", out])
+    # The filter variants: what is kept is small -- the solid count, the spectrum and the order-independent digest of
+    # the entries before and after recomputeAdjacencies (superplus_amd.dfk.digest_of; every parity test ties that
+    # digest to the entries themselves).
+    import json
+    from superplus_amd.dfk import digest_of
+    var = {}
+    for tag, min_freq, min_bc, use_bc, ign in VARIANTS:
+        good, pre, post, spec = run_dict(head, os.path.join(HERE, "tmp_" + tag), 48, use_bc, min_bc, min_freq, ign)
+        var[tag] = dict(K=48, min_freq=min_freq, min_bc=min_bc, use_bc=use_bc, ign_bc_below=ign, n_solid=len(post),
+                        digest_pre=[str(x) for x in digest_of(pre)], digest_post=[str(x) for x in digest_of(post)],
+                        spectrum=[int(x) for x in spec])
+        print(tag, "solid", len(post))
+    json.dump(var, open(os.path.join(HERE, "variants.json"), "w"), indent=1)
+    # one hot-minimizer input, full entries
+    reads, quals, bci = make_hot(777, 1500)
+    raw = os.path.join(HERE, "hot.raw")
+    write_raw(raw, reads, quals)
+    hot = os.path.join(HERE, "hot")
+    subprocess.check_call([REFDRV, "mkreads", raw, hot], stdout=subprocess.DEVNULL)
+    os.remove(raw)
+    feudal.write_bci(hot + ".bci", bci)
+    good, pre, post, spec = run_dict(hot, os.path.join(HERE, "tmp_hot"), 48, 1, 2, 2)
+    np.savez_compressed(os.path.join(HERE, "expect_hot_k48_minfreq2.npz"), good_len=good, solid_post=post, solid_pre=pre, spectrum=spec)
+    print("hot solid", len(post))
 
 
 if __name__ == "__main__":

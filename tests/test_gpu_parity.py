@@ -45,6 +45,39 @@ def test_golden_fixtures_through_abi(oracle, golden_dir):
         d.close()
 
 
+def test_golden_filter_variants_through_abi(golden_dir):
+    """Every filter parameter the tests below vary, against fixtures the reference's classes produced
+    (tests/golden/variants.json: refdrv dict with MIN_FREQ 1/2/5, MIN_BC 0/3/4, ignBcBelow > 0, no barcodes)."""
+    from superplus_amd.dfk import Dfk
+    from tests.test_oracle_golden import check_variant, load_inputs, load_variants
+    rs = load_inputs(golden_dir)
+    for tag, v in load_variants(golden_dir).items():
+        d = Dfk(K=v["K"], min_freq=v["min_freq"], min_bc=v["min_bc"], ign_bc_below=v["ign_bc_below"], keep_pre_adjacency=True)
+        d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"] if v["use_bc"] else None)
+        check_variant(v, d.solid_count(), d.digest(pre_adjacency=True), d.digest(), d.spectrum(), tag)
+        check_variant(v, d.solid_count(), util.digest_of(d.solid(pre_adjacency=True)), util.digest_of(d.solid()), d.spectrum(), tag + " (fetched)")
+        d.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(inst_per_item=1000), dict(passes=3)])
+def test_golden_hot_minimizer_through_abi(golden_dir, kw):
+    """One fine bucket holding thousands of distinct k-mers (every read carries the rank-0 minimizer) beside a diverged
+    repeat family: expected entries from the reference's classes.  Goes through the sub-pass / HBM-table paths."""
+    from superplus_amd.dfk import Dfk
+    from tests.test_oracle_golden import load_hot
+    import os
+    rs = load_hot(golden_dir)
+    exp = np.load(os.path.join(golden_dir, "expect_hot_k48_minfreq2.npz"))
+    d = Dfk(K=48, min_freq=2, keep_pre_adjacency=True, **kw)
+    d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    assert np.array_equal(d.good_lens(), exp["good_len"])
+    util.assert_same_solid(d.solid(pre_adjacency=True), exp["solid_pre"], "hot: kvec view")
+    util.assert_same_solid(d.solid(), exp["solid_post"], "hot: Dict view")
+    assert np.array_equal(d.spectrum(), exp["spectrum"])
+    assert d.stats()["n_overflow_items"] > 0
+    d.close()
+
+
 @pytest.mark.parametrize("min_freq,min_bc,use_bc,ign", [(1, 2, True, 0), (2, 0, True, 0), (3, 1, True, 0), (3, 2, False, 0),
                                                        (3, 2, True, 2000), (5, 2, True, 10**9),
                                                        (3, 3, True, 0), (3, 4, True, 0), (2, 3, True, 2000)])

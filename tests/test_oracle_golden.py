@@ -98,6 +98,47 @@ def test_oracle_matches_golden(oracle, golden_dir, tag, K, use_bc, min_bc):
     assert np.array_equal(r["hist"], exp["spectrum"])
 
 
+def load_variants(golden_dir):
+    import json
+    return json.load(open(os.path.join(golden_dir, "variants.json")))
+
+
+def check_variant(v, n_solid, digest_pre, digest_post, hist, tag):
+    assert n_solid == v["n_solid"], (tag, n_solid, v["n_solid"])
+    assert [str(x) for x in digest_pre] == v["digest_pre"], tag + ": kmers.kvec view"
+    assert [str(x) for x in digest_post] == v["digest_post"], tag + ": Dict view after recomputeAdjacencies"
+    assert [int(x) for x in hist] == v["spectrum"], tag + ": spectrum"
+
+
+def test_oracle_matches_golden_filter_variants(oracle, golden_dir):
+    """MIN_FREQ 1/2/5, MIN_BC 0/3/4, ignBcBelow > 0 (areIgnoredBarcodes) and the no-barcode form, each run by the
+    reference's classes (refdrv dict ... ignBcBelow): solid count, spectrum and the digests of both views."""
+    rs = load_inputs(golden_dir)
+    for tag, v in load_variants(golden_dir).items():
+        r = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"],
+                       rs["bc"] if v["use_bc"] else None, K=v["K"], min_qual=7, min_freq=v["min_freq"], min_bc=v["min_bc"],
+                       ign_bc_below=v["ign_bc_below"])
+        check_variant(v, r["n_solid"], util.digest_of(r["solid_pre"]), util.digest_of(r["solid"]), r["hist"], tag)
+
+
+def load_hot(golden_dir):
+    packed, base_off, read_len = feudal.read_fastb(os.path.join(golden_dir, "hot.fastb"))
+    pq, pq_off = feudal.read_qualp(os.path.join(golden_dir, "hot.qualp"))
+    bci = feudal.read_bci(os.path.join(golden_dir, "hot.bci"))
+    return dict(packed=packed, base_off=base_off, read_len=read_len, pq_bytes=pq, pq_off=pq_off,
+                bc=feudal.bci_to_bc(bci, len(read_len)), n_reads=len(read_len))
+
+
+def test_oracle_matches_golden_hot_minimizer(oracle, golden_dir):
+    rs = load_hot(golden_dir)
+    exp = np.load(os.path.join(golden_dir, "expect_hot_k48_minfreq2.npz"))
+    r = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48, min_freq=2)
+    assert np.array_equal(r["good_len"], exp["good_len"])
+    util.assert_same_solid(r["solid_pre"], exp["solid_pre"], "hot: kmers.kvec view")
+    util.assert_same_solid(r["solid"], exp["solid_post"], "hot: Dict view")
+    assert np.array_equal(r["hist"], exp["spectrum"])
+
+
 def test_good_len_rule(oracle):
     K = 48
     q = np.full(100, 30, np.uint8)
