@@ -15,7 +15,7 @@ mkdir -p "$OUT/obj"
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 COMMON="-std=gnu++11 -O2 -w -fno-access-control -fopenmp -ffunction-sections -fdata-sections -include $HERE/ref_compat.h -I$REF"
 cd "$REF"
-LIST=$(ls system/*.cc system/file/*.cc feudal/*.cc dna/*.cc kmers/KMerContext.cc 10X/Martian.cc \
+LIST=$(ls system/*.cc system/file/*.cc feudal/*.cc dna/*.cc kmers/KMerContext.cc kmers/ReadPather.cc 10X/Martian.cc \
           random/RNGen.cc math/PowerOf2.cc *.cc | grep -v -e MakeDepend.cc \
           -e '^Alignment.cc' -e BlockAlign.cc -e Fastavector.cc -e IndexedAlignmentPlusVector.cc \
           -e PackAlign.cc -e PrintAlignment.cc -e ScoreAlignment.cc -e VecAlignmentPlus.cc -e '^Vec.cc')
@@ -28,5 +28,7 @@ echo "$LIST" | xargs -P "${DFK_JOBS:-8}" -I{} sh -c '
 o="$OUT/obj/Vec.cc.o"
 if [ ! -f "$o" ]; then $CLANG $COMMON -fdelayed-template-parsing -c Vec.cc -o "$o"; fi
 cd "$HERE"
-g++ -no-pie $COMMON -fpermissive ref_driver.cc "$OUT"/obj/*.o -o "$OUT/refdrv" -Wl,--gc-sections -lz -lpthread
+# the graph half (digraphE<basevector>: graph/Digraph.h needs clang's delayed template parsing, like Vec.cc)
+$CLANG $COMMON -fdelayed-template-parsing -c ref_graph.cc -o "$OUT/ref_graph.o"
+g++ -no-pie $COMMON -fpermissive ref_driver.cc "$OUT/ref_graph.o" "$OUT"/obj/*.o -o "$OUT/refdrv" -Wl,--gc-sections -lz -lpthread
 echo "build_ref: built $OUT/refdrv"

@@ -28,6 +28,8 @@
 //                                        the reference's BaseVec/PQVecEncoder/feudal writer
 //   rdreads  head out.raw                reference reader -> raw reads/quals
 //   side     head outdir                 .lens/.qhist/.dti/subsam.* as DF's ingest writes them (reference BinaryWriter)
+//   graph ... (same arguments as dict)   dict, then the unipath edges (edges.fastb) and outdir/a.<K>/{a.fastb,a.hbv,a.hbx,
+//                                        a.kmers,a.inv,a.to_left,a.to_right,a.k} -- see oracle/ref_graph.cc
 //   dict K head outdir minQual minFreq minBC useBC nThreads [ignBcBelow]
 //                                        goodlens.u32, kmers.kvec (pre-adjacency, written by
 //                                        the reference's BinaryWriter), solid.bin (post
@@ -51,6 +53,8 @@
 #include <fstream>
 #include <string>
 #include <vector>
+
+int graph_main( unsigned K, std::string const& edgesFile, std::string const& dir );   // ref_graph.cc
 
 namespace {
 
@@ -154,11 +158,97 @@ struct RefImpl
     { if ( last-first > 1 ) merge(first,last); return first+1; }
 };
 
+// ---- glue restated from BuildReadQGraph48.cc:320-530 (EdgeBuilder, buildEdges) ----
+// Unipath edges over the real KmerDict after recomputeAdjacencies: the real KMer (toSuccessor / toPredecessor / rc /
+// isRev / isPalindrome), KMerContext, KDef::set and bvec::getCanonicalForm do the arithmetic; the walk is restated.
+// Single-threaded (the reference's thread order only permutes the edges; buildHBVFromEdges sorts them).
+template <unsigned K>
+struct EdgeGlue
+{
+    typedef KMer<K> Kmer;
+    typedef KmerDictEntry<K> Entry;
+    typedef KmerDict<K> Dict;
+    Dict const& dict; vecbvec& edges;
+    bvec seq; std::vector<Entry const*> on;
+
+    EdgeGlue( Dict const& d, vecbvec* e ) : dict(d), edges(*e) {}
+
+    Entry const* find( Kmer const& k, KMerContext* ctx )
+    { Entry const* r;
+      if ( k.isRev() ) { r = dict.findEntryCanonical(Kmer(k).rc()); ForceAssert(r); *ctx = r->getKDef().getContext().rc(); }
+      else { r = dict.findEntryCanonical(k); ForceAssert(r); *ctx = r->getKDef().getContext(); }
+      return r; }
+
+    bool canGoUp( Entry const& e )
+    { KMerContext c = e.getKDef().getContext();
+      if ( c.getPredecessorCount() != 1 ) return false;
+      Kmer p(e); p.toPredecessor(c.getSinglePredecessor());
+      if ( p.isPalindrome() ) return false;
+      find(p,&c); return c.getSuccessorCount() == 1; }
+
+    bool canGoDown( Entry const& e )
+    { KMerContext c = e.getKDef().getContext();
+      if ( c.getSuccessorCount() != 1 ) return false;
+      Kmer n(e); n.toSuccessor(c.getSingleSuccessor());
+      if ( n.isPalindrome() ) return false;
+      find(n,&c); return c.getPredecessorCount() == 1; }
+
+    void emit()
+    { if ( seq.getCanonicalForm() == CanonicalForm::REV ) { seq.ReverseComplement(); std::reverse(on.begin(),on.end()); }
+      EdgeID id; id.setVal(edges.size()); edges.push_back(seq);
+      unsigned off = 0;
+      for ( Entry const* p : on ) { ForceAssert(p->getKDef().isNull()); const_cast<KDef&>(p->getKDef()).set(id,off++); }
+      seq.clear(); on.clear(); }
+
+    void walk( Kmer const& start, KMerContext c )
+    { Kmer next(start);
+      while ( c.getSuccessorCount() == 1 )
+      { unsigned char b = c.getSingleSuccessor(); next.toSuccessor(b);
+        if ( next.isPalindrome() ) break;
+        Entry const* p = find(next,&c);
+        if ( c.getPredecessorCount() != 1 ) break;
+        seq.push_back(b); on.push_back(p); }
+      if ( seq.getCanonicalForm() == CanonicalForm::REV ) { seq.clear(); on.clear(); }    // its mirror image is built from the other end
+      else emit(); }
+
+    void fromEntry( Entry const& e )
+    { bool up = false;
+      if ( Kmer(e).isPalindrome() ) { seq.assign(e.begin(),e.end()); on.push_back(&e); emit(); return; }
+      if ( (up = canGoUp(e)) && canGoDown(e) ) return;                                   // interior k-mer
+      if ( up ) { seq.assign(e.rcbegin(),e.rcend()); on.push_back(&e); walk(Kmer(e).rc(),e.getKDef().getContext().rc()); }
+      else if ( canGoDown(e) ) { seq.assign(e.begin(),e.end()); on.push_back(&e); walk(e,e.getKDef().getContext()); }
+      else { seq.assign(e.begin(),e.end()); on.push_back(&e); emit(); } }
+
+    // a k-mer still unplaced lies on a cycle without branches: the edge starts at the cycle's smallest canonical
+    // k-mer, in its canonical orientation (canonicalizeCircle, :367-392)
+    void circle( Entry const& first )
+    { seq.assign(first.begin(),first.end()); on.push_back(&first);
+      KMerContext c = first.getKDef().getContext(); Kmer k(first);
+      for (;;)
+      { unsigned char b = c.getSingleSuccessor(); k.toSuccessor(b);
+        Entry const* p = find(k,&c);
+        if ( p == &first ) break;
+        ForceAssert(p->getKDef().isNull());
+        seq.push_back(b); on.push_back(p); }
+      size_t idx = 0;
+      for ( size_t i = 1; i < on.size(); ++i ) if ( static_cast<Kmer const&>(*on[i]) < static_cast<Kmer const&>(*on[idx]) ) idx = i;
+      if ( CF<K>::getForm(seq.begin(idx)) == CanonicalForm::REV )
+      { seq.ReverseComplement(); std::reverse(on.begin(),on.end()); idx = seq.size()-idx-K; }
+      if ( idx )
+      { bvec bv; bv.assign(seq.begin(idx),seq.end()); bv.append(seq.begin(K-1),seq.begin(K+idx-1)); seq = bv;
+        std::rotate(on.begin(),on.begin()+idx,on.end()); }
+      emit(); }
+
+    void run()
+    { for ( auto const& hhs : dict ) for ( Entry const& e : hhs ) if ( e.getKDef().isNull() ) fromEntry(e);
+      for ( auto const& hhs : dict ) for ( Entry const& e : hhs ) if ( e.getKDef().isNull() ) circle(e); }
+};
+
 struct Rec { uint64_t w0, w1; uint32_t edge, cc; int32_t bc; uint32_t pad; };
 
 template <unsigned K>
 int runDict( std::string const& head, std::string const& outdir, unsigned minQual,
-             unsigned minFreq, unsigned minBC, bool useBC, unsigned nThreads, int64_t ignBcBelow )
+             unsigned minFreq, unsigned minBC, bool useBC, unsigned nThreads, int64_t ignBcBelow, bool graph = false )
 {
     typedef RefImpl<K> Impl;
     typedef typename Impl::Entry Entry;
@@ -241,6 +331,18 @@ int runDict( std::string const& head, std::string const& outdir, unsigned minQua
     fprintf(f,"reads %zu\ninstances %zu\nsolid %zu\nthreads %u\ngoodlens_s %.6f\nmr1_s %.6f\nmr2_s %.6f\ndict_s %.6f\nadj_s %.6f\n",
             reads.size(),nInst,recs.size(),nt,t1-t0,t2-t1,t3-t2,t4-t3,t5-t4);
     fclose(f);
+    if ( graph )
+    {   // buildEdges + buildHBVFromEdges + WriteAssemblyFiles' graph files (BuildReadQGraph48.cc:1636,1664; WriteFiles.cc:69-101)
+        double t6 = now_s();
+        vecbvec edges;
+        EdgeGlue<K> eg(dict,&edges); eg.run();
+        edges.WriteAll((outdir+"/edges.fastb").c_str());
+        double t7 = now_s();
+        int rc = graph_main(K,outdir+"/edges.fastb",outdir+"/a."+std::to_string(K));
+        f = fopen((outdir+"/times.txt").c_str(),"a");
+        fprintf(f,"edges_s %.6f\nhbv_s %.6f\n",t7-t6,now_s()-t7); fclose(f);
+        return rc;
+    }
     return 0;
 }
 
@@ -386,16 +488,18 @@ int main( int argc, char** argv )
     if ( cmd == "rdreads" && argc == 4 ) return rdreads(argv[2],argv[3]);
     if ( cmd == "side" && argc == 4 ) return side(argv[2],argv[3]);
     if ( cmd == "side" && argc == 5 ) return side(argv[2],argv[3],atof(argv[4]));
-    if ( cmd == "dict" && ( argc == 10 || argc == 11 ) )
+    if ( cmd == "hbv" && argc == 5 ) return graph_main(atoi(argv[2]),argv[3],argv[4]);   // hbv K edges.fastb outdir
+    if ( ( cmd == "dict" || cmd == "graph" ) && ( argc == 10 || argc == 11 ) )
     {
+        bool graph = cmd == "graph";                             // graph: dict + edges.fastb + a.<K>/{a.fastb,a.hbv,a.kmers,a.inv,...}
         int64_t ign = argc == 11 ? atoll(argv[10]) : 0;          // createDict's ignBcBelow (= DF's bc_start)
         unsigned K = atoi(argv[2]);
         std::string head = argv[3], outdir = argv[4];
         unsigned minQual = atoi(argv[5]), minFreq = atoi(argv[6]), minBC = atoi(argv[7]);
         bool useBC = atoi(argv[8]) != 0; unsigned nThreads = atoi(argv[9]);
-        if ( K == 48 ) return runDict<48>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign);
-        if ( K == 40 ) return runDict<40>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign);
-        if ( K == 60 ) return runDict<60>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign);
+        if ( K == 48 ) return runDict<48>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign,graph);
+        if ( K == 40 ) return runDict<40>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign,graph);
+        if ( K == 60 ) return runDict<60>(head,outdir,minQual,minFreq,minBC,useBC,nThreads,ign,graph);
         fprintf(stderr,"K must be 40, 48 or 60\n"); return 1;
     }
     fprintf(stderr,"bad arguments\n");

@@ -733,11 +733,13 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     DevBuf pool, d_items, d_fail, d_pre;
     R.big_cap = tot_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;   // every solid k-mer has >= min_freq instances
     rc = c->alloc(R.big, R.big_cap * 32, "fallback solid entries"); if (rc) return rc;
-    rc = c->alloc(pool, words * 4, "HBM fallback tables"); if (rc) return rc;
+    rc = c->alloc(pool, words * 4 + 8, "HBM fallback tables"); if (rc) return rc;
     rc = c->alloc(d_items, items.size() * sizeof(BigItem), "fallback items"); if (rc) return rc;
     rc = c->alloc(d_pre, 16ull * (n + 1), "fallback prefixes"); if (rc) return rc;
     rc = c->alloc(d_fail, 16, "fallback flag"); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(pool.p, 0, words * 4, c->stream));
+    // (zeroed by our own grid-stride kernel: the pool of a pass with a 10^8-instance bucket is past 4 GiB)
+    hipLaunchKernelGGL(k_fill_u64, dim3(4096), dim3(256), 0, c->stream, (uint64_t*)pool.p, words / 2 + (words & 1), 0ull);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(d_fail.p, 0, 16, c->stream));
     HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice, c->stream));
     uint64_t* d_chunk_pre = (uint64_t*)d_pre.p; uint64_t* d_slot_pre = d_chunk_pre + (n + 1);
