@@ -168,10 +168,10 @@ struct EdgeGlue
     typedef KMer<K> Kmer;
     typedef KmerDictEntry<K> Entry;
     typedef KmerDict<K> Dict;
-    Dict const& dict; vecbvec& edges;
+    Dict const& dict; std::vector<bvec>& edges;
     bvec seq; std::vector<Entry const*> on;
 
-    EdgeGlue( Dict const& d, vecbvec* e ) : dict(d), edges(*e) {}
+    EdgeGlue( Dict const& d, std::vector<bvec>* e ) : dict(d), edges(*e) {}
 
     Entry const* find( Kmer const& k, KMerContext* ctx )
     { Entry const* r;
@@ -334,9 +334,11 @@ int runDict( std::string const& head, std::string const& outdir, unsigned minQua
     if ( graph )
     {   // buildEdges + buildHBVFromEdges + WriteAssemblyFiles' graph files (BuildReadQGraph48.cc:1636,1664; WriteFiles.cc:69-101)
         double t6 = now_s();
-        vecbvec edges;
-        EdgeGlue<K> eg(dict,&edges); eg.run();
-        edges.WriteAll((outdir+"/edges.fastb").c_str());
+        { std::vector<bvec> found;
+          { EdgeGlue<K> eg(dict,&found); eg.run(); }
+          vecbvec edges; edges.reserve(found.size());            // (a MasterVec that grows by push_back corrupts its heap under g++ 11)
+          for ( bvec const& b : found ) edges.push_back(b);
+          edges.WriteAll((outdir+"/edges.fastb").c_str()); }
         double t7 = now_s();
         int rc = graph_main(K,outdir+"/edges.fastb",outdir+"/a."+std::to_string(K));
         f = fopen((outdir+"/times.txt").c_str(),"a");

@@ -14,6 +14,7 @@
 #include <functional>
 #include <new>
 #include <string>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <mutex>
 #include <thread>
@@ -765,7 +766,13 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     HIP_TRY(hipMemcpyAsync(&failed, d_fail.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->release(pool); c->release(d_items); c->release(d_fail); c->release(d_pre);
-    if (failed) return fail(DFK_E_HIP, "HBM fallback table overflowed (should be impossible at load <= 0.5)");
+    if (failed) {
+        unsigned int info[4] = {};
+        (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(g_big_fail), sizeof info);
+        return fail(DFK_E_HIP, "an insert into an HBM fallback table gave up after %u probe steps and %u waits on a locked slot "
+                               "(table of 2^%u slots; %u tables, %llu instances in this pass's fallback)", info[1], info[2], info[3], n,
+                    (unsigned long long)tot_inst);
+    }
     return 0;
 }
 
@@ -1462,19 +1469,25 @@ int write_parts_unsorted(dfk_ctx* c, int fd, bool pre)
     }
     struct Pending { uint64_t bytes = 0, file_off = 0; bool live = false; };
     std::vector<Pending> pend(2 * (size_t)xfer_threads());
+    // The lanes store through a shared mapping of the file: concurrent pwrite()s to ONE file serialise on its inode
+    // lock (measured on tmpfs: 3.7 GB/s with 16 lanes, 50 GB in 13 s), page faults on a mapping do not.
+    char* map = at > 16 ? (char*)mmap(nullptr, at, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : nullptr;
+    if (map == (char*)MAP_FAILED) map = nullptr;                   // (a file system without shared mappings: pwrite)
     auto flush = [&](XferLane& l, unsigned t, int k) -> int {      // the chunk sitting in buffer k goes to the file
         Pending& p = pend[2 * t + k];
         if (!p.live) return 0;
         HIP_TRY(hipEventSynchronize(l.ev[k]));
-        for (uint64_t done = 0; done < p.bytes;) {
-            const ssize_t w = pwrite(fd, (const char*)l.pin[k] + done, p.bytes - done, (off_t)(p.file_off + done));
-            if (w <= 0) return fail(DFK_E_ARG, "short write to the k-mer file");
-            done += (uint64_t)w;
-        }
+        if (map) memcpy(map + p.file_off, l.pin[k], p.bytes);
+        else
+            for (uint64_t done = 0; done < p.bytes;) {
+                const ssize_t w = pwrite(fd, (const char*)l.pin[k] + done, p.bytes - done, (off_t)(p.file_off + done));
+                if (w <= 0) return fail(DFK_E_ARG, "short write to the k-mer file");
+                done += (uint64_t)w;
+            }
         p.live = false;
         return 0;
     };
-    return xfer_run(c, pieces.size(),
+    const int rc = xfer_run(c, pieces.size(),
         [&](unsigned t, XferLane& l, uint64_t i) -> int {
             const int k = l.turn++ & 1;
             int r = flush(l, t, k); if (r) return r;
@@ -1485,6 +1498,8 @@ int write_parts_unsorted(dfk_ctx* c, int fd, bool pre)
             return flush(l, t, k ^ 1);                              // the other buffer's chunk is written while this one is in flight
         },
         [&](unsigned t, XferLane& l) -> int { int r = flush(l, t, 0); return r ? r : flush(l, t, 1); });
+    if (map && munmap(map, at) != 0 && !rc) return fail(DFK_E_ARG, "cannot unmap the k-mer file");
+    return rc;
 }
 
 int fetch_sorted(dfk_ctx* c, bool pre, std::vector<dfk_entry32>** out)

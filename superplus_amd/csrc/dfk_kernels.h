@@ -661,6 +661,9 @@ __device__ __forceinline__ Probe probe_begin(u128 c, uint32_t ctx, int32_t tag, 
 __device__ unsigned long long g_probe_stats[4];
 #endif
 
+// what the first insert that gave up in an HBM table looked like: {set, probe steps, waits on a locked slot, log2 slots}
+__device__ unsigned int g_big_fail[4];
+
 // lane state in the probe loop
 enum : uint32_t { PS_PROBING = 0, PS_FOUND = 1, PS_FAILED = 2, PS_IDLE = 3 };
 // one counter bounds both the probe sequence (COUNT_MAX_PROBE steps) and the waits on a locked slot
@@ -671,7 +674,7 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
                                              uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw,
                                              uint32_t S, const Probe& A, uint32_t& n_claimed)
 {
-    uint32_t state = A.active ? PS_PROBING : PS_IDLE, slot = A.slot, seen = 0, cost = 0;
+    uint32_t state = A.active ? PS_PROBING : PS_IDLE, slot = A.slot, seen = 0, cost = 0, waits = 0;
 #ifdef DFK_PROBE_STATS
     uint32_t dbg_iter = 0;
 #endif
@@ -710,6 +713,7 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
             n_claimed += (uint32_t)won;
             seen |= e & (0u - match);                                    // 0 for the claimer
             cost += PROBE_COST - (PROBE_COST - 1u) * locked;
+            if (!LDS_TABLE) waits += locked;                             // (diagnostics of a failure only)
             slot = (slot + (A.step & ((fin | locked) - 1u))) & (S - 1);  // stay on a found or locked slot
             state = fin | ((uint32_t)(cost >= PROBE_LIMIT) << 1);        // PS_FOUND, PS_FAILED or PS_PROBING
         }
@@ -724,6 +728,9 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
         }
     }
 #endif
+    if (!LDS_TABLE && state == PS_FAILED && atomicCAS(&g_big_fail[0], 0u, 1u) == 0u) {
+        g_big_fail[1] = (cost - waits) / PROBE_COST; g_big_fail[2] = waits; g_big_fail[3] = 31u - (uint32_t)__clz(S);
+    }
     if (state == PS_FOUND) {
         if (LDS_TABLE) {
             // an LDS table sees at most its item's instances (a few thousand; a sub-pass 256 x 1024): the plain add is

@@ -82,6 +82,52 @@ def make_hot(seed, n_reads):
     return reads, quals, bci
 
 
+GRAPH_FILES = ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right")
+
+
+def make_special(seed):
+    """Error-free reads over three small sequences that exercise the corners of the edge builder: a circular
+    chromosome (a cycle without branches: simpleCircle / canonicalizeCircle, BuildReadQGraph48.cc:338-392), a sequence
+    with a reverse-complement-palindromic 48-mer in its middle (a one-k-mer edge that stops the walks on both sides),
+    and two sequences sharing a 120-base stretch (branch vertices)."""
+    rng = np.random.default_rng(seed)
+    seqs = []
+    circle = rng.integers(0, 4, 400, dtype=np.uint8)
+    seqs.append(np.concatenate([circle, circle, circle[:100]]))            # reads wrap around twice
+    half = rng.integers(0, 4, 24, dtype=np.uint8)
+    pal = np.concatenate([half, (3 - half[::-1]).astype(np.uint8)])
+    seqs.append(np.concatenate([rng.integers(0, 4, 150, dtype=np.uint8), pal, rng.integers(0, 4, 150, dtype=np.uint8)]))
+    shared = rng.integers(0, 4, 120, dtype=np.uint8)
+    for _ in range(2):
+        seqs.append(np.concatenate([rng.integers(0, 4, 130, dtype=np.uint8), shared, rng.integers(0, 4, 130, dtype=np.uint8)]))
+    reads, quals = [], []
+    for s in seqs:
+        for pos in range(0, len(s) - 100 + 1, 7):
+            for rep in range(3):
+                r = s[pos:pos + 100].copy()
+                if (pos + rep) % 2:
+                    r = (3 - r[::-1]).astype(np.uint8)
+                reads.append(r); quals.append(np.full(100, 30, np.uint8))
+    if len(reads) % 2:
+        reads.append(reads[-1].copy()); quals.append(quals[-1].copy())
+    bci = np.array([0, 0, len(reads)], np.int64)                           # one barcode; run without the barcode test
+    return reads, quals, bci
+
+
+def run_graph(head, out, K, use_bc, min_bc, min_freq, dest):
+    """refdrv graph: dict, then the unipath edges through the real KmerDict and a.<K>/ through the real digraphE."""
+    os.makedirs(out, exist_ok=True)
+    subprocess.check_call([REFDRV, "graph", str(K), head, out, "7", str(min_freq), str(min_bc), str(use_bc), "4", "0"],
+                          stdout=subprocess.DEVNULL)
+    os.makedirs(dest, exist_ok=True)
+    for f in GRAPH_FILES:
+        open(os.path.join(dest, f), "wb").write(open(os.path.join(out, f"a.{K}", f), "rb").read())
+    post = np.fromfile(out + "/solid.bin", ENTRY)
+    n_edges = int(np.frombuffer(open(os.path.join(dest, "a.kmers"), "rb").read()[8:16], "<u8")[0])
+    subprocess.check_call(["rm", "-rf", out])
+    return post, n_edges
+
+
 def run_dict(head, out, K, use_bc, min_bc, min_freq=3, ign=0):
     os.makedirs(out, exist_ok=True)
     subprocess.check_call([REFDRV, "dict", str(K), head, out, "7", str(min_freq), str(min_bc), str(use_bc), "4", str(ign)],
@@ -158,6 +204,23 @@ def main():
     good, pre, post, spec = run_dict(hot, os.path.join(HERE, "tmp_hot"), 48, 1, 2, 2)
     np.savez_compressed(os.path.join(HERE, "expect_hot_k48_minfreq2.npz"), good_len=good, solid_post=post, solid_pre=pre, spectrum=spec)
     print("hot solid", len(post))
+    # The graph half (row f-1): a.<K>/ files for the golden reads at K = 48/40/60, the hot-minimizer input, and a
+    # special input with a cycle, a palindromic k-mer and branches.
+    for tag, K, use_bc, min_bc in (("k48", 48, 1, 2), ("k40_nobc", 40, 0, 0), ("k60_nobc", 60, 0, 0)):
+        post, ne = run_graph(head, os.path.join(HERE, "tmp_g" + tag), K, use_bc, min_bc, 3, os.path.join(HERE, "graph_" + tag))
+        print("graph", tag, "solid", len(post), "HBV edges", ne)
+    post, ne = run_graph(hot, os.path.join(HERE, "tmp_ghot"), 48, 1, 2, 2, os.path.join(HERE, "graph_hot_k48_minfreq2"))
+    print("graph hot: solid", len(post), "HBV edges", ne)
+    reads, quals, bci = make_special(99)
+    raw = os.path.join(HERE, "special.raw")
+    write_raw(raw, reads, quals)
+    sp = os.path.join(HERE, "special")
+    subprocess.check_call([REFDRV, "mkreads", raw, sp], stdout=subprocess.DEVNULL)
+    os.remove(raw)
+    feudal.write_bci(sp + ".bci", bci)
+    post, ne = run_graph(sp, os.path.join(HERE, "tmp_gsp"), 48, 0, 0, 3, os.path.join(HERE, "graph_special_k48"))
+    np.savez_compressed(os.path.join(HERE, "expect_special_k48_nobc.npz"), solid_post=post)
+    print("graph special: solid", len(post), "HBV edges", ne)
 
 
 if __name__ == "__main__":
