@@ -215,7 +215,7 @@ def df_stage_wall(args, dev, local):
         del rs
         torch.cuda.synchronize(); torch.cuda.empty_cache()
         cmd = [os.path.join(ROOT, "superplus_amd", "DF"), f"ROOT={root}", f"LR={root}/reads.fastb", "PIPELINE=cs", "ALIGN=False",
-               f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}"]
+               f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}", "GRAPH=False"]   # (ingest + count)
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, DFK_HOST_THREADS=str(min(args.df_threads, 16))))
         wall = time.perf_counter() - t0

@@ -163,6 +163,23 @@ int dfk_write_kvec(dfk_ctx* ctx, const char* path, int flags);
 
 int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
 
+/* ---- the graph of the solid k-mers (single-GPU counts) ----
+ * dfk_graph_build replaces, on the dictionary of the last dfk_count*:
+ *   buildEdges         (paths/long/BuildReadQGraph48.cc:505-530, EdgeBuilder :320-503): the unipath edges, each once
+ *                      in canonical form -- on the device; as in the reference every dictionary entry then carries
+ *                      (edge id, offset on the edge) in place of (null, count) (KDef::set, kmers/ReadPather.h:122-127),
+ *                      so dfk_solid_fetch afterwards returns offsets where it returned counts;
+ *   buildHBVFromEdges  (paths/long/HBVFromEdges.cc:244-296): vertices = the (K-1)-mers at the edge ends, edges numbered
+ *                      in the reference's canonical traversal order, both orientations of every edge -- on the host
+ *                      (the numbering IS a sequential traversal).
+ * dfk_graph_write writes what WriteAssemblyFiles (10X/WriteFiles.cc:69-101) writes of a.<K>/ for the graph itself:
+ * a.k, a.hbv (K | digraphE<basevector>), a.hbx (HyperBasevectorX), a.to_left, a.to_right, a.inv
+ * (HyperBasevector::Involution), a.fastb (the edges), a.kmers -- byte for byte; the paths files need the read pather
+ * (SURVEY 8(f)-2).  dfk_stats.reserved[1] / [2]: microseconds spent on the edges (device) / the numbering (host). */
+int dfk_graph_build(dfk_ctx* ctx);
+int dfk_graph_stats(dfk_ctx* ctx, uint64_t* n_canonical_edges, uint64_t* n_vertices, uint64_t* n_edges);
+int dfk_graph_write(dfk_ctx* ctx, const char* dir);
+
 /* ---- multi-GPU pieces (one process per GPU; the caller owns the RCCL exchange) ----
  * The reference's only exchange is MapReduceEngine's thread all-to-all ("swizzle",
  * MapReduceEngine.h:345-388): every key goes to the thread that owns hash % T.  Here every

@@ -9,6 +9,7 @@
 //          work_dir/stats/histogram_kmer_count.json          WriteKmerSpectrum (BuildReadQGraph48.cc:283-285)
 //          work_dir/kmers.kvec                               the dictionary  (BuildReadQGraph48.cc:287-288)
 //          work_dir/data/frag_reads_orig.1000.{fastb,qualp}  WriteSubSample  (10X/DfTools.cc:32-67)
+//          work_dir/a.<K>/{a.k,a.hbv,a.hbx,a.to_left,a.to_right,a.inv,a.fastb,a.kmers}  WriteAssemblyFiles (10X/WriteFiles.cc:69-101)
 //
 // The hot path itself runs in libdfk (HIP); this file is host plumbing only -- but plumbing for 1.8 G reads:
 // the inputs are mapped, not copied; the one-input LR_SELECT_FRAC=1 case (what runall.sh:127 runs) re-emits
@@ -18,7 +19,8 @@
 //
 // Arguments beyond the reference's: HBM_GB= (device memory the library may use; 0 = 90 % of what is free --
 // MAX_MEM_GB keeps its reference meaning, a HOST memory cap (system/System.cc:1073-1078), and is not a device
-// budget), DEVICE=, KVEC= / KVEC_SORTED= (write kmers.kvec; in ascending k-mer order), MINIMIZER=.
+// budget), DEVICE=, KVEC= / KVEC_SORTED= (write kmers.kvec; in ascending k-mer order), GRAPH= (build the graph and
+// write a.<K>/: on by default, as in the reference), MINIMIZER=.
 #include "../../include/dfk.h"
 #include "feudal_io.h"
 
@@ -242,7 +244,7 @@ int main(int argc, char** argv)
     std::map<std::string, std::string> a = {
         {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
         {"OUT_DIR", ""}, {"LR", ""}, {"LR_SELECT_FRAC", "1.0"}, {"EXIT_LOAD", "False"}, {"DEVICE", "0"}, {"MAX_MEM_GB", "0"},
-        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "True"}, {"KVEC_SORTED", "False"}};
+        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "True"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}};
     std::string command = "DF";
     for (int i = 1; i < argc; ++i) {
         std::string s = argv[i]; command += " " + s;
@@ -471,6 +473,21 @@ int main(int argc, char** argv)
             if (dfk_write_kvec(ctx, (work_dir + "/kmers.kvec").c_str(), truthy(a["KVEC_SORTED"]) ? DFK_KVEC_SORTED : 0)) throw std::runtime_error(dfk_last_error());
         }
         T.fetch_write = now_s() - t0;
+        // ---- buildEdges + buildHBVFromEdges + the graph files of WriteAssemblyFiles (BuildReadQGraph48.cc:1636,1664;
+        //      10X/WriteFiles.cc:69-101): a.<K>/{a.k,a.hbv,a.hbx,a.to_left,a.to_right,a.inv,a.fastb,a.kmers}
+        double t_graph = 0;
+        uint64_t g_ce = 0, g_v = 0, g_e = 0;
+        if (truthy(a["GRAPH"])) {
+            t0 = now_s();
+            printf("%s: finding edge sequences.\n", date().c_str());
+            if (dfk_graph_build(ctx)) throw std::runtime_error(dfk_last_error());
+            const std::string dir = work_dir + "/a." + std::to_string(K);
+            mkpath(dir);
+            printf("%s: writing files\n", date().c_str());
+            if (dfk_graph_write(ctx, dir.c_str())) throw std::runtime_error(dfk_last_error());
+            dfk_graph_stats(ctx, &g_ce, &g_v, &g_e);
+            t_graph = now_s() - t0;
+        }
         dfk_destroy(ctx);
         join_background();
         T.total = now_s() - t_start;
@@ -479,10 +496,10 @@ int main(int argc, char** argv)
                (unsigned long long)st.n_inst, st.ms_total, st.ms_count, T.total);
         // one machine-readable line (bench.py reads it): where the stage's wall time went
         printf("DF_TIMING {\"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"threads\": %u, \"open_validate_s\": %.3f, "
-               "\"ingest_outputs_s\": %.3f, \"upload_s\": %.3f, \"count_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, \"total_s\": %.3f, "
-               "\"fast_path\": %s}\n",
+               "\"ingest_outputs_s\": %.3f, \"upload_s\": %.3f, \"count_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, \"graph_s\": %.3f, "
+               "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"total_s\": %.3f, \"fast_path\": %s}\n",
                (unsigned long long)n_reads, (unsigned long long)st.n_inst, (unsigned long long)nk, g_threads, T.read, T.ingest_out,
-               T.upload, T.count, T.fetch_write, T.total, fast ? "true" : "false");
+               T.upload, T.count, T.fetch_write, t_graph, (unsigned long long)g_e, (unsigned long long)g_v, T.total, fast ? "true" : "false");
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());
         return 1;

@@ -115,6 +115,8 @@ struct dfk_ctx {
     uint32_t shard_world = 1, shard_log2_nb = 0;
     void* shard_state = nullptr;              // bucket table + count state kept between the passes of a sharded run
     void (*shard_state_free)(void*) = nullptr;
+    void* graph_state = nullptr;              // the graph built from the last count (dfk_graph.inc)
+    void (*graph_state_free)(void*) = nullptr;
 
     // Device memory comes from a few large chunks that are kept for the life of the context and managed
     // by first-fit free lists with coalescing.  hipMalloc/hipFree of multi-GB blocks cost milliseconds to
@@ -255,6 +257,7 @@ struct dfk_ctx {
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
         n_solid = 0; adj_n = 0; shard_open = false;
         if (shard_state) { shard_state_free(shard_state); shard_state = nullptr; }
+        if (graph_state) { graph_state_free(graph_state); graph_state = nullptr; }
     }
 };
 
@@ -1783,3 +1786,4 @@ int dfk_get_stats(dfk_ctx* c, dfk_stats* out)
 } // extern "C"
 
 #include "dfk_shard.inc"
+#include "dfk_graph.inc"

@@ -73,11 +73,16 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 constexpr uint32_t MMER_SALT = 0x2C6B39D1u;
 __device__ __forceinline__ uint32_t mmer_hash(uint32_t canon) { return mix32(canon ^ MMER_SALT); }
 
-// slot hash of a canonical k-mer (2K-bit value) for the LDS / HBM tables
+// slot hash of a canonical k-mer (2K-bit value) for the LDS / HBM tables.  Every key word goes through its own odd
+// multiplier BEFORE the words are combined.  (The first version xor-folded rotated words and mixed afterwards: a linear
+// fold, under which substitutions in different words cancel.  The k-mers of a diverged repeat family -- one minimizer,
+// the other 32 bases a few substitutions away from each other -- then collapsed onto few hash values: 1.67 M distinct
+// keys gave 1.25 M hashes, up to 69 keys per value, and at human scale an HBM table of 2^29 slots ran out of its 96
+// probe steps at load < 0.5.)
 __device__ __forceinline__ uint32_t key_hash(u128 c)
 {
     uint32_t a = (uint32_t)c.lo, b = (uint32_t)(c.lo >> 32), d = (uint32_t)c.hi, e = (uint32_t)(c.hi >> 32);
-    uint32_t h = a ^ __builtin_rotateleft32(b, 11) ^ __builtin_rotateleft32(d, 22) ^ __builtin_rotateleft32(e, 5);
+    uint32_t h = (a * 0x9E3779B1u) ^ __builtin_rotateleft32(b * 0x85EBCA77u, 13) ^ __builtin_rotateleft32(d * 0xC2B2AE3Du, 26) ^ (e * 0x27D4EB2Fu);
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
     return h;
 }

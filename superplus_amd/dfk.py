@@ -23,7 +23,7 @@ EXPORTS = [
     "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_device",
     "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
     "dfk_write_kvec", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
-    "dfk_shard_adj_answer", "dfk_shard_adj_apply",
+    "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
 ]
 
 
@@ -172,6 +172,17 @@ class Dfk:
     def write_kvec(self, path, pre_adjacency=False, in_order=False):
         """kmers.kvec image; device order unless in_order (ascending k-mers, sorted on the host)."""
         _check(lib().dfk_write_kvec(self._ctx, path.encode(), C.c_int((1 if pre_adjacency else 0) | (2 if in_order else 0))))
+
+    def graph_build(self):
+        """Unipath edges (device) + canonical HyperBasevector (host) of the last count's dictionary."""
+        _check(lib().dfk_graph_build(self._ctx))
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().dfk_graph_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_canonical_edges=a.value, n_vertices=b.value, n_edges=c.value)
+
+    def graph_write(self, directory):
+        """a.k, a.hbv, a.hbx, a.to_left, a.to_right, a.inv, a.fastb, a.kmers into `directory` (which must exist)."""
+        _check(lib().dfk_graph_write(self._ctx, directory.encode()))
 
     def stats(self):
         s = Stats()

@@ -134,6 +134,9 @@ def test_df_end_to_end_on_gpu(tmp_path, golden_dir, oracle):
     rd = lambda p: open(p, "rb").read()
     for ext in ("fastb", "qualp", "bci"):
         assert rd(f"{tmp_path}/w/data/frag_reads_orig.{ext}") == rd(f"{golden_dir}/reads.{ext}"), ext
+    # a.48/: the graph files WriteAssemblyFiles writes, against the reference-written fixture
+    for f in ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right"):
+        assert rd(f"{tmp_path}/w/a.48/{f}") == rd(f"{golden_dir}/graph_k48/{f}"), f
 
 
 @pytest.mark.gpu

@@ -1,0 +1,36 @@
+// tools/fs_write_scaling.cc -- how fast can N threads fill ONE file (pwrite / shared mapping / after fallocate)?
+//   g++ -O2 -pthread -o /tmp/fsw tools/fs_write_scaling.cc && /tmp/fsw <threads> <0 pwrite|1 mmap|2 fallocate+pwrite> <GiB> <chunk MiB> [path]
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+int main(int argc, char** argv)
+{
+    const int T = atoi(argv[1]); const int mode = atoi(argv[2]); const size_t total = (size_t)atoll(argv[3]) << 30; const size_t chunk = (size_t)atoi(argv[4]) << 20;
+    const char* path = argc > 5 ? argv[5] : "/dev/shm/wtest.bin";
+    int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
+    if (mode != 3) ftruncate(fd, total);
+    char* map = mode == 1 ? (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : nullptr;
+    std::atomic<size_t> next{0};
+    auto t0 = std::chrono::steady_clock::now();
+    if (mode == 2) { posix_fallocate(fd, 0, total); printf("fallocate %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+        char* buf = (char*)malloc(chunk); memset(buf, t + 1, chunk);
+        for (size_t i; (i = next.fetch_add(1)) * chunk < total;) {
+            if (mode == 1) memcpy(map + i * chunk, buf, chunk);
+            else pwrite(fd, buf, chunk, i * chunk);
+        }
+        free(buf);
+    });
+    for (auto& x : th) x.join();
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("T=%d mode=%d chunk=%zuMB: %.2f s, %.2f GB/s\n", T, mode, chunk >> 20, s, total / s / 1e9);
+    close(fd); unlink(path);
+}
