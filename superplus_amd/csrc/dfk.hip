@@ -726,56 +726,83 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
         c->release(d_i2); c->release(d_v2);
     }
     for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t inst = val[2 * i + 1] - val[2 * i];
-        tot_inst += inst;
-        uint32_t l2 = std::max<uint32_t>(13, ceil_log2(2 * inst + 64));
-        items.push_back(BigItem{singles[i].b0, singles[i].b1, words, l2, 0});
-        words += (uint64_t)(KW + 4 + (NBC > 1 ? NBC - 1 : 0)) << l2;   // keys, state, contexts, counts, barcode words (BigView)
+        tot_inst += val[2 * i + 1] - val[2 * i];
         chunk_pre[i + 1] = chunk_pre[i] + (rec[2 * i + 1] - rec[2 * i] + COUNT_CHUNK - 1) / COUNT_CHUNK;
-        slot_pre[i + 1] = slot_pre[i] + (1ull << l2);
     }
-    DevBuf pool, d_items, d_fail, d_pre;
+    // A table is sized for the distinct k-mers its bucket is expected to hold -- instances x (distinct k-mers per
+    // instance seen so far, with a margin) -- at load <= 0.5; 2 x instances is the certain bound and costs 56 bytes
+    // per instance (42 GB for the hot buckets of one pass of a human-scale set with a 10 % repeat family).  An insert
+    // that runs out of probe steps says the guess was too low: every table is then rebuilt twice as large.
+    double per_inst = c->distinct_per_inst > 0.0 ? std::min(1.0, std::max(0.05, 1.5 * c->distinct_per_inst)) : 1.0;
+    DevBuf d_items, d_fail, d_pre;
     R.big_cap = tot_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;   // every solid k-mer has >= min_freq instances
     rc = c->alloc(R.big, R.big_cap * 32, "fallback solid entries"); if (rc) return rc;
-    rc = c->alloc(pool, words * 4 + 8, "HBM fallback tables"); if (rc) return rc;
-    rc = c->alloc(d_items, items.size() * sizeof(BigItem), "fallback items"); if (rc) return rc;
+    rc = c->alloc(d_items, (uint64_t)n * sizeof(BigItem), "fallback items"); if (rc) return rc;
     rc = c->alloc(d_pre, 16ull * (n + 1), "fallback prefixes"); if (rc) return rc;
     rc = c->alloc(d_fail, 16, "fallback flag"); if (rc) return rc;
-    // (zeroed by our own grid-stride kernel: the pool of a pass with a 10^8-instance bucket is past 4 GiB)
-    hipLaunchKernelGGL(k_fill_u64, dim3(4096), dim3(256), 0, c->stream, (uint64_t*)pool.p, words / 2 + (words & 1), 0ull);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(d_fail.p, 0, 16, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice, c->stream));
     uint64_t* d_chunk_pre = (uint64_t*)d_pre.p; uint64_t* d_slot_pre = d_chunk_pre + (n + 1);
     HIP_TRY(hipMemcpyAsync(d_chunk_pre, chunk_pre.data(), 8ull * (n + 1), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_slot_pre, slot_pre.data(), 8ull * (n + 1), hipMemcpyHostToDevice, c->stream));
     CountParams cpb = R.cp; cpb.seg_cap = R.big_cap;                       // the fallback writes to its own buffer
-    // the whole grid works on the fallback tables together (d_fail + 8: the chunk ticket)
     const unsigned cus = (unsigned)c->prop.multiProcessorCount;
-    const unsigned g_ins = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + NW * BIG_TICKET_CHUNKS - 1) / (NW * BIG_TICKET_CHUNKS), 4ull * cus));
-    const unsigned g_slot = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((slot_pre[n] + 255) / 256, 16ull * cus));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_insert<K, NW, NBC>), dim3(g_ins), dim3(NW * 64), 0, c->stream,
-                       (const uint4*)P.records.p, (const BigItem*)d_items.p, (const uint64_t*)P.base.p, (const uint64_t*)d_chunk_pre, n,
-                       (uint32_t*)pool.p, (unsigned long long*)d_fail.p + 1, (uint32_t*)d_fail.p);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_flags<K, NBC>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
-                       (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p, cpb, R.g);
-    if (cpb.do_adj)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_resolve<K>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
-                           (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_emit<K>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
-                       (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p, cpb, R.g, (uint4*)R.big.p, R.hist);
-    HIP_TRY(hipGetLastError());
-    uint32_t failed = 0;
-    HIP_TRY(hipMemcpyAsync(&failed, d_fail.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->release(pool); c->release(d_items); c->release(d_fail); c->release(d_pre);
-    if (failed) {
-        unsigned int info[4] = {};
-        (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(g_big_fail), sizeof info);
-        return fail(DFK_E_HIP, "an insert into an HBM fallback table gave up after %u probe steps and %u waits on a locked slot "
-                               "(table of 2^%u slots; %u tables, %llu instances in this pass's fallback)", info[1], info[2], info[3], n,
-                    (unsigned long long)tot_inst);
+    for (;;) {
+        items.clear(); words = 0;
+        bool certain = true;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t inst = val[2 * i + 1] - val[2 * i];
+            const uint64_t guess = std::min<uint64_t>(inst, (uint64_t)((double)inst * per_inst) + 256);
+            certain = certain && guess == inst;
+            const uint32_t l2 = std::max<uint32_t>(13, ceil_log2(2 * guess + 64));
+            items.push_back(BigItem{singles[i].b0, singles[i].b1, words, l2, 0});
+            words += (uint64_t)(KW + 4 + (NBC > 1 ? NBC - 1 : 0)) << l2;   // keys, state, contexts, counts, barcode words (BigView)
+            slot_pre[i + 1] = slot_pre[i] + (1ull << l2);
+        }
+        DevBuf pool;
+        rc = c->alloc(pool, words * 4 + 8, "HBM fallback tables"); if (rc) return rc;
+        // (zeroed by our own grid-stride kernel: the pool of a pass with a 10^8-instance bucket is past 4 GiB)
+        hipLaunchKernelGGL(k_fill_u64, dim3(4096), dim3(256), 0, c->stream, (uint64_t*)pool.p, words / 2 + (words & 1), 0ull);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(d_fail.p, 0, 16, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BigItem), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_slot_pre, slot_pre.data(), 8ull * (n + 1), hipMemcpyHostToDevice, c->stream));
+        // the whole grid works on the fallback tables together (d_fail + 8: the chunk ticket)
+        const unsigned g_ins = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + NW * BIG_TICKET_CHUNKS - 1) / (NW * BIG_TICKET_CHUNKS), 4ull * cus));
+        const unsigned g_slot = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((slot_pre[n] + 255) / 256, 16ull * cus));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_insert<K, NW, NBC>), dim3(g_ins), dim3(NW * 64), 0, c->stream,
+                           (const uint4*)P.records.p, (const BigItem*)d_items.p, (const uint64_t*)P.base.p, (const uint64_t*)d_chunk_pre, n,
+                           (uint32_t*)pool.p, (unsigned long long*)d_fail.p + 1, (uint32_t*)d_fail.p);
+        HIP_TRY(hipGetLastError());
+        uint32_t failed = 0;
+        HIP_TRY(hipMemcpyAsync(&failed, d_fail.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (failed) {
+            unsigned int info[4] = {};
+            (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(g_big_fail), sizeof info);
+            const unsigned int zero[4] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_big_fail), zero, sizeof zero);
+            c->release(pool);
+            if (certain) {
+                c->release(d_items); c->release(d_fail); c->release(d_pre);
+                return fail(DFK_E_HIP, "an insert into an HBM fallback table gave up after %u probe steps and %u waits on a locked slot "
+                                       "(table of 2^%u slots at load <= 0.5; %u tables, %llu instances in this pass's fallback)", info[1], info[2], info[3], n,
+                            (unsigned long long)tot_inst);
+            }
+            per_inst = std::min(1.0, 2.0 * per_inst);
+            TRACE("fallback: an HBM table filled up (2^%u slots): rebuilding the tables for %.2f distinct k-mers per instance", info[3], per_inst);
+            continue;
+        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_flags<K, NBC>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
+                           (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p, cpb, R.g);
+        if (cpb.do_adj)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_resolve<K>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
+                               (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_big_emit<K>), dim3(g_slot), dim3(256), 0, c->stream, (const BigItem*)d_items.p,
+                           (const uint64_t*)d_slot_pre, n, (uint32_t*)pool.p, cpb, R.g, (uint4*)R.big.p, R.hist);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->release(pool);
+        break;
     }
+    c->release(d_items); c->release(d_fail); c->release(d_pre);
     return 0;
 }
 
@@ -882,6 +909,7 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
         std::vector<ItemRange> sub_items, huge; std::vector<uint32_t> sub_words;
         constexpr uint64_t PER_SUB = (1ull << CountCfg<K>::LOG2S) / 2;
         constexpr uint32_t MAX_P = 8;                                    // selector bits (wave_count_chunk)
+        static const uint32_t max_lds_p = getenv("DFK_MAX_SUBPASS_LOG2") ? (uint32_t)atoi(getenv("DFK_MAX_SUBPASS_LOG2")) : 2;
         // p is first guessed from the distinct k-mers per instance seen so far (a repeat-rich bucket has far fewer
         // distinct k-mers than instances); a sub-pass that overflows anyway is cut in two by one more selector bit
         // and counted again -- its siblings are done and stay -- until p = MAX_P, where 1024 *instances* per sub-pass
@@ -893,6 +921,10 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
             if (ceil_log2((inst + PER_SUB - 1) / PER_SUB) > MAX_P) { huge.push_back(singles[i]); continue; }
             const uint64_t guess = (uint64_t)((double)inst * dpi) + 1;
             const uint32_t p = std::max<uint32_t>(1, ceil_log2((guess + PER_SUB - 1) / PER_SUB));
+            // every sub-pass reads and extracts ALL of the bucket's instances again: 2^p-fold work, quadratic in the
+            // bucket's size.  An HBM table costs one (slow: ~15 G/s) insert per instance, so beyond four sub-passes
+            // it is the cheaper way -- at human scale with a 10 % repeat family the sub-passes took 6 s of a 9.5 s step.
+            if (p > max_lds_p) { huge.push_back(singles[i]); continue; }
             for (uint32_t k = 0; k < (1u << p); ++k) { sub_items.push_back(singles[i]); sub_words.push_back((p << 8) | k); }
         }
         TRACE("fallback: %zu sub-passes over %zu buckets in LDS tables, %zu buckets in HBM tables", sub_items.size(), singles.size() - huge.size(), huge.size());
@@ -1474,19 +1506,25 @@ int write_parts_unsorted(dfk_ctx* c, int fd, bool pre)
     std::vector<Pending> pend(2 * (size_t)xfer_threads());
     // The lanes store through a shared mapping of the file: concurrent pwrite()s to ONE file serialise on its inode
     // lock (measured on tmpfs: 3.7 GB/s with 16 lanes, 50 GB in 13 s), page faults on a mapping do not.
-    char* map = at > 16 ? (char*)mmap(nullptr, at, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : nullptr;
-    if (map == (char*)MAP_FAILED) map = nullptr;                   // (a file system without shared mappings: pwrite)
+    // Measured on the GPU box's tmpfs (tools/fs_write_scaling.cc, 16 GB into one file): ONE thread pwrite()s 8.6 GB/s,
+    // 16 threads 6.6 GB/s (they serialise on the file's page-cache lock), a shared mapping 3.7-5.2 GB/s.  So the lanes
+    // keep the device copies in flight in parallel and take turns at the file: one writer at a time.
+    char* map = nullptr;
+    if (getenv("DFK_KVEC_MMAP") && at > 16) { map = (char*)mmap(nullptr, at, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); if (map == (char*)MAP_FAILED) map = nullptr; }
+    std::mutex file_turn;
     auto flush = [&](XferLane& l, unsigned t, int k) -> int {      // the chunk sitting in buffer k goes to the file
         Pending& p = pend[2 * t + k];
         if (!p.live) return 0;
         HIP_TRY(hipEventSynchronize(l.ev[k]));
         if (map) memcpy(map + p.file_off, l.pin[k], p.bytes);
-        else
+        else {
+            std::lock_guard<std::mutex> turn(file_turn);
             for (uint64_t done = 0; done < p.bytes;) {
                 const ssize_t w = pwrite(fd, (const char*)l.pin[k] + done, p.bytes - done, (off_t)(p.file_off + done));
                 if (w <= 0) return fail(DFK_E_ARG, "short write to the k-mer file");
                 done += (uint64_t)w;
             }
+        }
         p.live = false;
         return 0;
     };
