@@ -32,3 +32,13 @@ cd "$HERE"
 $CLANG $COMMON -fdelayed-template-parsing -c ref_graph.cc -o "$OUT/ref_graph.o"
 g++ -no-pie $COMMON -fpermissive ref_driver.cc "$OUT/ref_graph.o" "$OUT"/obj/*.o -o "$OUT/refdrv" -Wl,--gc-sections -lz -lpthread
 echo "build_ref: built $OUT/refdrv"
+# The reference's own ParseBarcodedFastqs, from its own sources where they lie: 10X/ParseBarcodedFastqs.cc
+# needs clang's delayed template parsing (kmers/KmerShape.h:566 under g++ 11) and is compiled WITHOUT -fopenmp: its
+# only OpenMP loop appends the buckets' temporary files in the order the threads finish them, so the barcode order
+# of a threaded run is not reproducible; single-threaded it is bucket 0, 1, 2, ...
+cd "$REF"
+$CLANG -std=gnu++11 -O2 -w -fno-access-control -include "$HERE/ref_compat.h" -I"$REF" -fdelayed-template-parsing -c 10X/ParseBarcodedFastqs.cc -o "$OUT/ParseBarcodedFastqs.o"
+g++ $COMMON -fpermissive -c 10X/Barcode.cc -o "$OUT/Barcode.o"
+cd "$HERE"
+g++ -no-pie -fopenmp "$OUT/ParseBarcodedFastqs.o" "$OUT/Barcode.o" "$OUT"/obj/*.o -o "$OUT/ParseBarcodedFastqs" -Wl,--gc-sections -lz -lpthread
+echo "build_ref: built $OUT/ParseBarcodedFastqs"

@@ -121,6 +121,6 @@ constexpr uint32_t BCW_MULTI = 0x80000000u;   // barcode word: first barcode see
 // CNT_LOCK (fingerprint 0, count all ones: not a reachable state) = slot being initialised.
 constexpr uint32_t CNT_LOCK  = 0x00FFFFFFu;
 constexpr uint32_t CNT_MASK  = 0x00FFFFFFu;
-constexpr uint32_t CNT_NEAR_SAT = 0x00FFFF00u;  // above this the count is bumped by compare-and-swap so that it saturates exactly
+constexpr uint32_t CNT_HALF = 0x00800000u;      // from here on the count is bumped by (wave-aggregated) compare-and-swap so that it saturates exactly
 
 } // namespace dfk

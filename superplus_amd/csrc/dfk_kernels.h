@@ -733,14 +733,32 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
     }
     if (state == PS_FOUND) {
         if (LDS_TABLE) {
-            // an LDS table sees at most its item's instances (a few thousand; a sub-pass 256 x 1024): the plain add is
-            // safe below CNT_NEAR_SAT, above it the count is bumped by compare-and-swap so that it saturates exactly
-            if ((seen & CNT_MASK) < CNT_NEAR_SAT) atomicAdd(&cnt[slot], 1u);
-            else {                                                        // saturate exactly at 2^24-1 (KDef::setCount)
-                uint32_t cur = tld(&cnt[slot]);
-                while ((cur & CNT_MASK) != CNT_MASK &&
-                       !__hip_atomic_compare_exchange_strong(&cnt[slot], &cur, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT)) {}
+            // Counts saturate at exactly 2^24-1 (KDef::setCount).  The count shares its word with the fingerprint, so an
+            // add must never carry.  Below 2^23 (as seen at probe time) a plain add is safe: between a lane's probe and
+            // its add the other waves of the workgroup can add at most a few hundred thousand -- the probe loop is
+            // bounded by PROBE_LIMIT iterations.  (The margin used to be 255 and "an item holds a few thousand
+            // instances" the argument; but ONE fine bucket is one item however large: 330 k poly-A reads put 1.76x10^7
+            // instances of one k-mer through one table, the count carried into the fingerprint and the k-mer claimed a
+            // second slot -- in two runs of six.)  From 2^23 on the lanes of a wave that hit the same slot are added
+            // as ONE compare-and-swap by their leader, which saturates exactly.
+            const bool high = (seen & CNT_MASK) >= CNT_HALF;
+            if (!high) atomicAdd(&cnt[slot], 1u);
+            unsigned long long todo = __ballot(high);
+            while (todo) {                                                    // (wave-uniform: `todo` is a ballot)
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t lslot = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
+                const unsigned long long same = __ballot(high && slot == lslot) & todo;
+                if ((threadIdx.x & 63) == leader) {
+                    const uint32_t k = (uint32_t)__popcll(same);
+                    uint32_t cur = tld(&cnt[slot]);
+                    for (;;) {
+                        const uint32_t c0 = cur & CNT_MASK, c1 = c0 + k < CNT_MASK ? c0 + k : CNT_MASK;
+                        if (c1 == c0) break;
+                        if (__hip_atomic_compare_exchange_strong(&cnt[slot], &cur, (cur & ~CNT_MASK) | c1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    }
+                }
+                todo &= ~same;
             }
         } else {
             // An HBM table is shared by the whole grid, and a hot k-mer (poly-A: 10^7 instances of ONE key) sends every

@@ -296,10 +296,11 @@ def test_budget_above_free_hbm_is_clamped(oracle):
     assert st["n_passes"] == 1 and st["hbm_bytes_peak"] < torch.cuda.get_device_properties(0).total_memory
 
 
-def test_count_saturates_at_2_pow_24_in_the_hbm_table(oracle):
+def test_count_saturates_at_2_pow_24_in_an_lds_table(oracle):
     """KDef::setCount saturates at 2^24-1 (ReadPather.h:128-129).  330 k poly-A reads put 17.5 M instances of ONE 48-mer
-    into one fine bucket, which is counted in an HBM table by the whole grid: the count must stop at exactly 2^24-1
-    and must not carry into the slot's fingerprint byte (which would make the k-mer claim a second slot)."""
+    into one fine bucket -- one work item, one LDS table, however many instances: the count must stop at exactly 2^24-1
+    and must not carry into the slot's fingerprint byte (which makes the k-mer claim a second slot: seen in two runs
+    of six before the adds near saturation were made exact)."""
     n = 330_000
     rng = np.random.default_rng(17)
     extra = rng.integers(0, 4, (3000, 100), dtype=np.uint8)
@@ -355,3 +356,53 @@ def test_kvec_file_device_order_and_sorted(oracle, tmp_path):
     d.write_kvec(f"{tmp_path}/c.kvec", pre_adjacency=True)
     c = load(f"{tmp_path}/c.kvec")
     util.assert_same_solid(c[np.lexsort((c["w1"], c["w0"]))], ref["solid_pre"], "pre-adjacency kvec")
+
+
+def test_counts_beyond_2_pow_24_in_an_hbm_table(oracle):
+    """The same limit where the whole grid shares a table.  4.3 M copies of one read made of the 16-mer whose minimizer
+    rank is 0, repeated: 16 distinct 48-mers (the rotations), five of them with 4 x 4.3 M = 1.72x10^7 instances
+    (saturated: exactly 2^24-1), eleven with 3 x 4.3 M = 1.29x10^7 (exact); 3000 random reads around the same 16-mer
+    put enough distinct k-mers into the SAME fine bucket that it goes to the HBM-table path.  Expected values are
+    analytic for the periodic k-mers and the oracle's for the rest (the two sets of k-mers are disjoint)."""
+    from superplus_amd import feudal
+    from superplus_amd.dfk import Dfk
+    N = 4_300_000
+    hot = np.array(["ACGT".index(ch) for ch in "AGTACGGTATGCTCAC"], np.uint8)
+    periodic = np.tile(hot, 7)[:100]
+    rng = np.random.default_rng(23)
+    rnd = rng.integers(0, 4, (3000, 100), dtype=np.uint8)
+    rnd[:, 42:58] = hot
+    rnd[1000:2000] = rnd[:1000]; rnd[2000:] = rnd[:1000]
+    blk = np.array([100, (35 << 3) & 0xFF, 35 >> 5, 0], np.uint8)
+    def as_set(bases, first_bc):
+        n = len(bases)
+        return dict(packed=feudal.pack_bases(bases).reshape(-1), base_off=np.arange(n + 1, dtype=np.uint64) * 25,
+                    read_len=np.full(n, 100, np.uint32), pq_bytes=np.tile(blk, n), pq_off=np.arange(n + 1, dtype=np.uint64) * 4,
+                    bc=(first_bc + np.arange(n) % 7).astype(np.int32))
+    small = as_set(rnd, 1)
+    ref = oracle.run(small["packed"], small["base_off"], small["read_len"], small["pq_bytes"], small["pq_off"], small["bc"], K=48)
+    one = feudal.pack_bases(periodic[None, :]).reshape(-1)
+    M = N + len(rnd)
+    packed = np.concatenate([np.tile(one, N), small["packed"]])
+    bc = np.concatenate([(1 + np.arange(N) % 7).astype(np.int32), small["bc"]])
+    d = Dfk(K=48)
+    d.count(packed, np.arange(M + 1, dtype=np.uint64) * 25, np.full(M, 100, np.uint32), np.tile(blk, M), np.arange(M + 1, dtype=np.uint64) * 4, bc)
+    st = d.stats()
+    assert st["n_overflow_items"] > 0                                  # the bucket left the LDS path
+    assert st["n_distinct"] == ref["n_distinct"] + 16 and st["n_solid"] == ref["n_solid"] + 16
+    s = d.solid()
+    per = {}
+    for r in range(16):
+        w0, w1 = oracle.kmer_from_codes(np.tile(hot, 5)[r:r + 48], 48)
+        if oracle.is_rev(w0, w1, 48):
+            w0, w1 = oracle.rc(w0, w1, 48)
+        per[(w0, w1)] = min(N * (4 if r <= 4 else 3), (1 << 24) - 1)
+    assert len(per) == 16
+    keys = list(zip(s["w0"].tolist(), s["w1"].tolist()))
+    assert len(set(keys)) == len(keys)                                  # no k-mer twice
+    got = {k: int(c) & 0xFFFFFF for k, c in zip(keys, s["count_ctx"]) if k in per}
+    assert got == per
+    rest = s[[k not in per for k in keys]]
+    assert np.array_equal(rest["w0"], ref["solid"]["w0"]) and np.array_equal(rest["w1"], ref["solid"]["w1"])
+    assert np.array_equal(rest["count_ctx"] & 0xFFFFFF, ref["solid"]["count_ctx"] & 0xFFFFFF)
+    d.close()
