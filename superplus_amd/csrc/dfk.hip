@@ -909,7 +909,7 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
         std::vector<ItemRange> sub_items, huge; std::vector<uint32_t> sub_words;
         constexpr uint64_t PER_SUB = (1ull << CountCfg<K>::LOG2S) / 2;
         constexpr uint32_t MAX_P = 8;                                    // selector bits (wave_count_chunk)
-        static const uint32_t max_lds_p = getenv("DFK_MAX_SUBPASS_LOG2") ? (uint32_t)atoi(getenv("DFK_MAX_SUBPASS_LOG2")) : 2;
+        static const uint32_t max_lds_p = getenv("DFK_MAX_SUBPASS_LOG2") ? (uint32_t)atoi(getenv("DFK_MAX_SUBPASS_LOG2")) : 8;
         // p is first guessed from the distinct k-mers per instance seen so far (a repeat-rich bucket has far fewer
         // distinct k-mers than instances); a sub-pass that overflows anyway is cut in two by one more selector bit
         // and counted again -- its siblings are done and stay -- until p = MAX_P, where 1024 *instances* per sub-pass
@@ -921,9 +921,12 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
             if (ceil_log2((inst + PER_SUB - 1) / PER_SUB) > MAX_P) { huge.push_back(singles[i]); continue; }
             const uint64_t guess = (uint64_t)((double)inst * dpi) + 1;
             const uint32_t p = std::max<uint32_t>(1, ceil_log2((guess + PER_SUB - 1) / PER_SUB));
-            // every sub-pass reads and extracts ALL of the bucket's instances again: 2^p-fold work, quadratic in the
-            // bucket's size.  An HBM table costs one (slow: ~15 G/s) insert per instance, so beyond four sub-passes
-            // it is the cheaper way -- at human scale with a 10 % repeat family the sub-passes took 6 s of a 9.5 s step.
+            // Every sub-pass reads and extracts ALL of the bucket's instances again: 2^p-fold work, quadratic in the
+            // bucket's size -- at human scale with a 10 % repeat family the sub-passes take 6 s of a 9.5 s step.  The
+            // HBM tables are no way out as they stand: k_big_insert runs at 1.8 G instances/s there (four dependent
+            // agent-scope atomics per instance, acquire/release fences per probe: 245 ms per pass), 8.7 s per step when
+            // every bucket beyond four sub-passes goes to them (DFK_MAX_SUBPASS_LOG2=2).  What such buckets want is a
+            // second-level partition by k-mer hash into buckets that fit LDS tables.
             if (p > max_lds_p) { huge.push_back(singles[i]); continue; }
             for (uint32_t k = 0; k < (1u << p); ++k) { sub_items.push_back(singles[i]); sub_words.push_back((p << 8) | k); }
         }

@@ -211,6 +211,14 @@ def main():
         print("graph", tag, "solid", len(post), "HBV edges", ne)
     post, ne = run_graph(hot, os.path.join(HERE, "tmp_ghot"), 48, 1, 2, 2, os.path.join(HERE, "graph_hot_k48_minfreq2"))
     print("graph hot: solid", len(post), "HBV edges", ne)
+    # ParseBarcodedFastqs (row f-3): a small fastq.gz pair through the reference's OWN binary (oracle/_ref/ParseBarcodedFastqs,
+    # built from 10X/ParseBarcodedFastqs.cc where it lies; single-threaded, see oracle/build_ref.sh)
+    from tests.fastq_synth import make_fastq
+    pbf = os.path.join(HERE, "pbf")
+    os.makedirs(pbf, exist_ok=True)
+    make_fastq(pbf + "/r_1.fq.gz", pbf + "/r_2.fq.gz", 300, 7, n_bc=12, ragged=True)
+    subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "ParseBarcodedFastqs"), "FASTQS={" + pbf + "/r_1.fq.gz," + pbf + "/r_2.fq.gz}",
+                           "OUT_HEAD=" + pbf + "/reads", "NUM_THREADS=1", "NUM_BUCKETS=4"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     reads, quals, bci = make_special(99)
     raw = os.path.join(HERE, "special.raw")
     write_raw(raw, reads, quals)
