@@ -160,6 +160,10 @@ int dfk_solid_digest(dfk_ctx* ctx, int pre_adjacency, uint64_t* digest /* [2] */
 #define DFK_KVEC_PRE_ADJ 1
 #define DFK_KVEC_SORTED  2
 int dfk_write_kvec(dfk_ctx* ctx, const char* path, int flags);
+/* The same file written by several ranks (multi-GPU runs: solid sets are disjoint): every rank writes its share at
+ * entry first_entry of a file of total_entries entries (the caller derives first_entry from the ranks' solid counts);
+ * the rank with first_entry == 0 writes the header.  Device order only. */
+int dfk_write_kvec_part(dfk_ctx* ctx, const char* path, int flags, uint64_t first_entry, uint64_t total_entries);
 
 int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
 
@@ -209,6 +213,13 @@ int dfk_shard_begin(dfk_ctx* ctx,
               const void* d_pq_off, const void* d_bc, uint64_t n_reads,
               int64_t global_read_offset /* index of this shard's first read (ign_bc_below is global) */,
               uint64_t* n_inst_local);
+/* The same from host memory, for a host that maps the read files (DF NUM_GPUS=N): the tables are this rank's SLICE of
+ * the whole set's tables -- base_off / pq_off keep the whole set's offsets and packed_bases / pq_bytes are the whole
+ * set's arrays -- and only the bytes of this rank's reads are uploaded.  The device copies live until the next run. */
+int dfk_shard_begin_host(dfk_ctx* ctx,
+              const uint8_t* packed_bases, const uint64_t* base_off /* n+1 */, const uint32_t* read_len,
+              const uint8_t* pq_bytes, const uint64_t* pq_off /* n+1 */, const int32_t* bc, uint64_t n_reads,
+              int64_t global_read_offset, uint64_t* n_inst_local);
 int dfk_shard_plan(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t* log2_passes);
 int dfk_shard_partition(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t log2_passes, uint32_t pass,
               const void** d_records, uint64_t* send_counts /* [world], in 32-byte records */);

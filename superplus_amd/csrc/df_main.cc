@@ -22,6 +22,7 @@
 // budget), DEVICE=, KVEC= / KVEC_SORTED= (write kmers.kvec; in ascending k-mer order), GRAPH= (build the graph and
 // write a.<K>/: on by default, as in the reference), MINIMIZER=.
 #include "../../include/dfk.h"
+#include "df_shard.h"
 #include "feudal_io.h"
 
 #include <algorithm>
@@ -38,6 +39,8 @@
 #include <string>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <signal.h>
+#include <sys/wait.h>
 #include <thread>
 #include <unistd.h>
 
@@ -238,6 +241,101 @@ struct QualHist {
 
 struct Timing { double read = 0, ingest_out = 0, upload = 0, count = 0, fetch_write = 0, total = 0; };
 
+// WriteHistToJson<int64_t> as WriteKmerSpectrum calls it (10X/MakeHist.cc:67-92): the text dfk_spectrum_json produces,
+// here for a spectrum summed over ranks
+std::string spectrum_json(const std::vector<uint64_t>& hist)
+{
+    std::string s = "{\n\t\"description\": \"kmer_count\",\n\t\"stage\": \"DF\",\n\t\"binsize\": 1,\n\t\"min\": 0,\n";
+    s += "\t\"max\": " + std::to_string((long long)hist.size() - 1) + ",\n";
+    s += "\t\"numbins\": " + std::to_string(hist.size()) + ",\n\t\"vals\": [";
+    for (size_t i = 0; i < hist.size(); ++i) { s += std::to_string(hist[i]); if (i + 1 != hist.size()) s += ","; }
+    return s + "]\n}\n";
+}
+
+// One rank of `DF NUM_GPUS=N`: its pair range of the (single, already LoadData-ordered) input, the sharded createDict
+// over the transport, its share of kmers.kvec; rank 0 writes the spectrum summed over the ranks.
+int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::string& work_dir, const std::string& head, int rank, int world,
+              dfkx::LoopbackHub* hub)
+{
+    const double t_start = now_s();
+    try {
+        FeudalMap fb, qp;
+        fb.open(head + ".fastb"); qp.open(head + ".qualp");
+        const std::vector<int64_t> bci = feudal::read_bci(head + ".bci");
+        if (qp.n != fb.n || bci.size() < 2 || bci[0] != 0 || (uint64_t)bci.back() != fb.n || fb.n % 2) throw std::runtime_error(head + ": not a LoadData-ordered pair set");
+        const uint64_t n_pairs = fb.n / 2, lo = 2 * (n_pairs * (uint64_t)rank / (uint64_t)world), hi = 2 * (n_pairs * (uint64_t)(rank + 1) / (uint64_t)world), n = hi - lo;
+        std::vector<int32_t> bc(n, 0);                                                       // DF.cc:447-452 for this rank's reads
+        parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t b0, uint64_t b1) {
+            for (uint64_t b = b0; b < b1; ++b)
+                for (int64_t r = std::max<int64_t>(bci[b], (int64_t)lo); r < std::min<int64_t>(bci[b + 1], (int64_t)hi); ++r) bc[r - lo] = (int32_t)b;
+        }, 1024);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device");
+        dfk_config cfg{};
+        cfg.abi_version = DFK_ABI_VERSION; cfg.K = K; cfg.min_qual = (uint32_t)atoi(a["MIN_QUAL"].c_str());
+        cfg.min_freq = (uint32_t)atoi(a["MIN_FREQ"].c_str()); cfg.min_bc = (uint32_t)atoi(a["MIN_BC"].c_str());
+        cfg.device = hub ? atoi(a["DEVICE"].c_str()) : rank % ndev; cfg.ign_bc_below = 0;
+        cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
+        cfg.hbm_budget_bytes = (uint64_t)(atof(a["HBM_GB"].c_str()) * 1073741824.0);
+        if (hub && !cfg.hbm_budget_bytes) { size_t fr = 0, tot = 0; (void)hipSetDevice(cfg.device); (void)hipMemGetInfo(&fr, &tot); cfg.hbm_budget_bytes = (uint64_t)(0.8 * (double)fr / world); }   // ranks sharing one GPU
+        dfk_ctx* ctx = nullptr;
+        if (dfk_create(&cfg, &ctx)) throw std::runtime_error(dfk_last_error());
+        std::unique_ptr<dfkx::Transport> T;
+        if (hub) T.reset(new dfkx::LoopbackTransport(*hub, rank));
+        else T.reset(new dfkx::RcclTransport(rank, world, cfg.device, work_dir + "/.dfk_rccl_id"));
+        uint64_t n_local = 0;
+        double t0 = now_s();
+        int rc = dfk_shard_begin_host(ctx, fb.m.p, (const uint64_t*)(fb.off_table() + 8 * lo), (const uint32_t*)(fb.fixed() + 4 * lo), qp.m.p,
+                                      (const uint64_t*)(qp.off_table() + 8 * lo), bc.data(), n, (int64_t)lo, &n_local);
+        // (a rank whose own data fail still has to meet the others in the first collective: the status travels with the count)
+        uint64_t st0[2] = {rc ? (uint64_t)(-rc) : 0, 0};
+        const std::string begin_err = rc ? dfk_last_error() : "";
+        T->all_reduce(st0, 1, true);
+        if (rc) throw dfkx::ShardError(rc, begin_err);
+        if (st0[0]) throw dfkx::ShardError(-(int)st0[0], "another rank failed in dfk_shard_begin; this rank stops with it");
+        const double t_begin = now_s() - t0;
+        dfkx::ShardTimes tm;
+        const uint64_t piece = getenv("DFK_A2A_PIECE_BYTES") ? (uint64_t)atoll(getenv("DFK_A2A_PIECE_BYTES")) : (uint64_t)1 << 30;
+        dfkx::shard_create_dict(ctx, *T, n_local, piece, &tm);
+        // ---- results: spectrum summed over the ranks (rank 0 writes it), every rank its share of kmers.kvec
+        t0 = now_s();
+        const int64_t* h = nullptr; uint64_t nb = 0;
+        dfk_spectrum(ctx, &h, &nb);
+        uint64_t nb_all = nb; T->all_reduce(&nb_all, 1, true);
+        std::vector<uint64_t> hist(nb_all, 0);
+        for (uint64_t i = 0; i < nb; ++i) hist[i] = (uint64_t)h[i];
+        if (nb_all) T->all_reduce(hist.data(), (int)nb_all, false);
+        if (rank == 0) { const std::string js = spectrum_json(hist); FILE* f = fopen((work_dir + "/stats/histogram_kmer_count.json").c_str(), "wb"); if (!f) throw std::runtime_error("cannot write spectrum"); fwrite(js.data(), 1, js.size(), f); fclose(f); }
+        uint64_t mine[2] = {0, n_local}; dfk_solid_count(ctx, &mine[0]);
+        std::vector<uint64_t> all(2 * (size_t)world);
+        T->all_gather(mine, 2, all.data());
+        uint64_t first = 0, total = 0, inst = 0;
+        for (int r = 0; r < world; ++r) { if (r < rank) first += all[2 * r]; total += all[2 * r]; inst += all[2 * r + 1]; }
+        if (truthy(a["KVEC"]) && dfk_write_kvec_part(ctx, (work_dir + "/kmers.kvec").c_str(), 0, first, total)) throw std::runtime_error(dfk_last_error());
+        const double t_write = now_s() - t0;
+        uint64_t done = 1; T->all_reduce(&done, 1, false);                                   // every share is in the file
+        dfk_stats st{}; dfk_get_stats(ctx, &st);
+        T.reset();
+        dfk_destroy(ctx);
+        if (rank == 0) {
+            printf("%s: dictionary covers %llu kmers\n", date().c_str(), (unsigned long long)total);
+            printf("DF_TIMING {\"ranks\": %d, \"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"rank0\": {\"upload_trim_s\": %.3f, \"plan_s\": %.3f, "
+                   "\"partition_s\": %.3f, \"exchange_wait_s\": %.3f, \"count_s\": %.3f, \"adjacency_s\": %.3f, \"create_dict_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, "
+                   "\"bytes_sent_to_peers\": %llu, \"passes\": %u, \"rank_total_s\": %.3f}}\n", world, (unsigned long long)fb.n, (unsigned long long)inst,
+                   (unsigned long long)total, t_begin, tm.plan, tm.partition, tm.exchange_wait, tm.count, tm.adjacency, tm.total, t_write,
+                   (unsigned long long)tm.bytes_sent, tm.n_passes, now_s() - t_start);
+        }
+        return 0;
+    } catch (const dfkx::ShardError& e) {
+        if (e.code == DFK_E_NOGOOD) { if (rank == 0) printf("\nLooks like your input data have almost no good bases.\nGiving up.\n\n"); return 1; }
+        fprintf(stderr, "DF[rank %d]: %s\n", rank, e.what());
+        return e.code == DFK_E_NOMEM ? 185 : 1;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "DF[rank %d]: %s\n", rank, e.what());
+        return 1;
+    }
+}
+
 } // namespace
 
 int main(int argc, char** argv)
@@ -246,7 +344,7 @@ int main(int argc, char** argv)
     std::map<std::string, std::string> a = {
         {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
         {"OUT_DIR", ""}, {"LR", ""}, {"LR_SELECT_FRAC", "1.0"}, {"EXIT_LOAD", "False"}, {"DEVICE", "0"}, {"MAX_MEM_GB", "0"},
-        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "True"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}};
+        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "True"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}, {"NUM_GPUS", "1"}};
     std::string command = "DF";
     for (int i = 1; i < argc; ++i) {
         std::string s = argv[i]; command += " " + s;
@@ -278,6 +376,39 @@ int main(int argc, char** argv)
             give_up("Can't file your LR input files " + head + ".*.");                             // DF.cc:251-258
         heads.push_back(head);
     }
+    // ---- NUM_GPUS > 1: one process per GPU, spawned HERE, before this process has made a single HIP call (a process that
+    //      has initialised the GPU must not be replaced or forked).  The children (DF_RANK set) run the sharded createDict
+    //      and write the spectrum and kmers.kvec; this process does the ingest and its output files meanwhile, then waits.
+    //      DF_TRANSPORT=loopback: all ranks as threads of this process on ONE GPU, records moved by device copies -- the way
+    //      the multi-rank driver is exercised where there is one GPU (RCCL refuses two ranks on one device).
+    const int num_gpus = std::max(1, atoi(a["NUM_GPUS"].c_str()));
+    const bool loopback = getenv("DF_TRANSPORT") && std::string(getenv("DF_TRANSPORT")) == "loopback";
+    if ((num_gpus & (num_gpus - 1)) || num_gpus > 64) give_up("NUM_GPUS must be a power of two (the owner of a minimizer bucket is its low bits)");
+    if (getenv("DF_RANK")) return rank_main(a, K, work_dir, heads[0], atoi(getenv("DF_RANK")), atoi(getenv("DF_WORLD")), nullptr);
+    std::vector<pid_t> children;
+    if (num_gpus > 1 || getenv("DF_FORCE_SHARDED")) {
+        if (heads.size() != 1) give_up("NUM_GPUS > 1 takes one LR input");
+        if (!loopback) {
+            unlink((work_dir + "/.dfk_rccl_id").c_str());
+            for (int r = 0; r < num_gpus; ++r) {
+                const pid_t pid = fork();
+                if (pid < 0) give_up("cannot fork");
+                if (pid == 0) {
+                    setenv("DF_RANK", std::to_string(r).c_str(), 1); setenv("DF_WORLD", std::to_string(num_gpus).c_str(), 1);
+                    execv("/proc/self/exe", argv);
+                    _exit(127);
+                }
+                children.push_back(pid);
+            }
+        }
+    }
+    const bool sharded = num_gpus > 1 || getenv("DF_FORCE_SHARDED");
+    auto wait_children = [&]() -> int {
+        int worst = 0;
+        for (pid_t pid : children) { int st = 0; if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st)) worst = std::max(worst, 1); else worst = std::max(worst, WEXITSTATUS(st)); }
+        children.clear();
+        return worst;
+    };
     Timing T;
     try {
         // ---- LoadData (10X/DfTools.cc:69-170): unbarcoded pairs of every input first, then barcoded pairs
@@ -443,7 +574,24 @@ int main(int argc, char** argv)
             background.clear();
             if (bg_failed) std::rethrow_exception(bg_err);
         };
-        if (truthy(a["EXIT_LOAD"])) { join_background(); return 0; }            // DF.cc:483
+        if (truthy(a["EXIT_LOAD"]) && !sharded) { join_background(); return 0; } // DF.cc:483
+        if (sharded) {
+            // the ranks are counting (or, loopback, start now); this process has done the ingest
+            int rc = 0;
+            if (loopback) {
+                if (!fast) throw std::runtime_error("NUM_GPUS > 1 needs one LR input with LR_SELECT_FRAC = 1");
+                dfkx::LoopbackHub hub(num_gpus, [](void* d, const void* s_, uint64_t nbytes) { if (hipMemcpy(d, s_, nbytes, hipMemcpyDeviceToDevice) != hipSuccess) throw std::runtime_error("device copy failed"); });
+                std::vector<int> rcs(num_gpus, 0);
+                std::vector<std::thread> th;
+                for (int r = 0; r < num_gpus; ++r) th.emplace_back([&, r] { rcs[r] = rank_main(a, K, work_dir, heads[0], r, num_gpus, &hub); });
+                for (auto& x : th) x.join();
+                for (int r : rcs) rc = std::max(rc, r);
+            } else rc = wait_children();
+            join_background();
+            T.total = now_s() - t_start;
+            printf("%s: ingest + sharded count stage %.2f s wall on %d GPUs\n", date().c_str(), T.total, num_gpus);
+            return rc;
+        }
 
         // ---- barcode expansion (DF.cc:447-452) and createDict on the GPU
         std::vector<int32_t> bc(n_reads, 0);
@@ -505,6 +653,8 @@ int main(int argc, char** argv)
                T.upload, T.count, T.fetch_write, t_graph, (unsigned long long)g_e, (unsigned long long)g_v, T.total, fast ? "true" : "false");
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());
+        for (pid_t pid : children) kill(pid, SIGTERM);
+        (void)wait_children();
         return 1;
     }
     return 0;

@@ -1,0 +1,163 @@
+// superplus_amd/csrc/df_shard.h -- the sharded createDict of `DF NUM_GPUS=N`, host side in C++: one rank per GPU drives
+// libdfk's dfk_shard_* entry points and moves the records itself, over RCCL (rccl.h) directly.
+//
+//   reference: MapReduceEngine::Client (MapReduceEngine.h:345-388): map -> thread all-to-all -> sort/reduce, per pass
+//   here:      dfk_shard_partition -> all_to_all_v of 32-byte records by owner rank (dfk_exchange.h) -> dfk_shard_count,
+//              per bucket-range pass, the exchange of pass p+1 in flight under the count of pass p; then the
+//              neighbour-query round trip of recomputeAdjacencies (two small all-to-alls).
+// superplus_amd/dist.py is the same driver over torch.distributed and stays the test harness of the library's shard
+// API; this file is what a C++ host links.
+#pragma once
+#include "../../include/dfk.h"
+#include "dfk_exchange.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <string>
+#include <thread>
+#include <unistd.h>
+
+namespace dfkx {
+
+#define DFKX_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define DFKX_NCCL(expr) do { ncclResult_t e_ = (expr); if (e_ != ncclSuccess) throw std::runtime_error(std::string(#expr) + ": " + ncclGetErrorString(e_)); } while (0)
+
+// RCCL over xGMI: point-to-point pieces in groups, on a stream of its own (the library counts on its own streams
+// meanwhile).  The communicator's id travels through a file both sides can see (rank 0 writes it, the others wait).
+struct RcclTransport : Transport {
+    ncclComm_t comm = nullptr; hipStream_t st = nullptr; uint64_t* d_small = nullptr; size_t small_cap = 0;
+    RcclTransport(int r, int w, int device, const std::string& id_file)
+    {
+        rank = r; world = w;
+        DFKX_HIP(hipSetDevice(device));
+        ncclUniqueId id;
+        const std::string tmp = id_file + ".tmp";
+        if (r == 0) {
+            DFKX_NCCL(ncclGetUniqueId(&id));
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(&id, sizeof id, 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+            fclose(f);
+            if (rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file);
+        } else {
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = fopen(id_file.c_str(), "rb")); ++tries) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            if (!f || fread(&id, sizeof id, 1, f) != 1) throw std::runtime_error("rank 0 never published " + id_file);
+            fclose(f);
+        }
+        DFKX_NCCL(ncclCommInitRank(&comm, w, id, r));
+        DFKX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    }
+    ~RcclTransport() override { if (d_small) (void)hipFree(d_small); if (comm) (void)ncclCommDestroy(comm); if (st) (void)hipStreamDestroy(st); }
+    void group_begin() override { DFKX_NCCL(ncclGroupStart()); }
+    void send(const void* p, uint64_t bytes, int peer) override { DFKX_NCCL(ncclSend(p, bytes, ncclUint8, peer, comm, st)); }
+    void recv(void* p, uint64_t bytes, int peer) override { DFKX_NCCL(ncclRecv(p, bytes, ncclUint8, peer, comm, st)); }
+    void group_end() override { DFKX_NCCL(ncclGroupEnd()); }
+    void wait() override { DFKX_HIP(hipStreamSynchronize(st)); }
+    void copy_local(void* dst, const void* src, uint64_t bytes) override { DFKX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st)); }
+    uint64_t* small(size_t n) { if (n > small_cap) { if (d_small) (void)hipFree(d_small); DFKX_HIP(hipMalloc(&d_small, 8 * n)); small_cap = n; } return d_small; }
+    void all_reduce(uint64_t* v, int n, bool max_not_sum) override
+    {
+        uint64_t* d = small((size_t)n);
+        DFKX_HIP(hipMemcpyAsync(d, v, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        DFKX_NCCL(ncclAllReduce(d, d, (size_t)n, ncclUint64, max_not_sum ? ncclMax : ncclSum, comm, st));
+        DFKX_HIP(hipMemcpyAsync(v, d, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+        DFKX_HIP(hipStreamSynchronize(st));
+    }
+    void all_gather(const uint64_t* mine, int n, uint64_t* all) override
+    {
+        uint64_t* d = small((size_t)n * (world + 1));
+        DFKX_HIP(hipMemcpyAsync(d, mine, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        DFKX_NCCL(ncclAllGather(d, d + n, (size_t)n, ncclUint64, comm, st));
+        DFKX_HIP(hipMemcpyAsync(all, d + n, 8 * (size_t)n * world, hipMemcpyDeviceToHost, st));
+        DFKX_HIP(hipStreamSynchronize(st));
+    }
+};
+
+struct ShardError : std::runtime_error { int code; ShardError(int c, const std::string& m) : std::runtime_error(m), code(c) {} };
+
+struct ShardTimes { double trim = 0, plan = 0, partition = 0, exchange_wait = 0, count = 0, adjacency = 0, total = 0; uint64_t bytes_sent = 0; uint32_t n_passes = 0; };
+
+// The sharded createDict on this rank, after dfk_shard_begin* has put the rank's reads on the device.  Afterwards the
+// context holds this rank's share of the dictionary (solid sets are disjoint, spectra add).
+// A library call can fail on one rank only (its own data, its own HBM budget): after every local phase the ranks
+// agree on a status word, and every rank throws when any of them failed -- before the next exchange is entered.
+inline void shard_create_dict(dfk_ctx* ctx, Transport& T, uint64_t n_inst_local, uint64_t piece, ShardTimes* times)
+{
+    using clock = std::chrono::steady_clock;
+    auto secs = [](clock::time_point a) { return std::chrono::duration<double>(clock::now() - a).count(); };
+    const auto t_all = clock::now();
+    const int w = T.world, r = T.rank;
+    int pending = 0; std::string pending_msg;
+    auto note = [&](int rc) { if (rc && !pending) { pending = rc; pending_msg = dfk_last_error(); } };
+    auto agree = [&](const char* what) {
+        uint64_t worst = pending ? (uint64_t)(-pending) : 0;
+        T.all_reduce(&worst, 1, true);
+        if (pending) throw ShardError(pending, pending_msg);
+        if (worst) throw ShardError(-(int)worst, std::string("another rank failed in ") + what + "; this rank stops with it");
+    };
+    uint64_t n_global = n_inst_local;
+    T.all_reduce(&n_global, 1, false);
+    if (n_global == 0) throw ShardError(DFK_E_NOGOOD, "Looks like your input data have almost no good bases.");
+    auto t0 = clock::now();
+    uint32_t lp = 0;
+    note(dfk_shard_plan(ctx, (uint32_t)w, n_global, &lp));
+    times->plan += secs(t0);
+    agree("dfk_shard_plan");
+    { uint64_t v = lp; T.all_reduce(&v, 1, true); lp = (uint32_t)v; }                 // every rank runs the same passes
+    const uint32_t n_pass = 1u << lp;
+    times->n_passes = n_pass;
+    std::vector<uint64_t> sc(w), rc(w), all((size_t)w * w);
+    struct Cut { const void* send = nullptr; void* recv = nullptr; uint64_t n_recv = 0; };
+    auto cut = [&](uint32_t p) -> Cut {                                               // partition pass p, size and start its exchange
+        Cut c;
+        auto t1 = clock::now();
+        if (!pending) note(dfk_shard_partition(ctx, (uint32_t)w, n_global, lp, p, &c.send, sc.data()));
+        times->partition += secs(t1);
+        agree("dfk_shard_partition");                                                 // (also covers the count of the pass before)
+        t1 = clock::now();
+        T.all_gather(sc.data(), w, all.data());
+        for (int s = 0; s < w; ++s) { rc[s] = all[(size_t)s * w + r]; c.n_recv += rc[s]; if (s != r) times->bytes_sent += 32 * sc[s]; }
+        note(dfk_shard_recv_buffer(ctx, c.n_recv, &c.recv));
+        agree("dfk_shard_recv_buffer");
+        all_to_all_v(T, c.send, sc.data(), c.recv, rc.data(), 32, piece, /*wait=*/false);
+        times->exchange_wait += secs(t1);
+        return c;
+    };
+    auto wait = [&] { auto t1 = clock::now(); T.wait(); times->exchange_wait += secs(t1); };
+    Cut cur = cut(0);
+    wait();
+    for (uint32_t p = 0; p < n_pass; ++p) {
+        Cut nxt;
+        if (p + 1 < n_pass) nxt = cut(p + 1);                                         // its records travel while this pass is counted
+        auto t1 = clock::now();
+        if (!pending) note(dfk_shard_count(ctx, cur.recv, cur.n_recv, p));            // a failure is agreed on at the next cut / after the loop
+        times->count += secs(t1);
+        if (p + 1 < n_pass) { wait(); cur = nxt; }
+    }
+    // recomputeAdjacencies across ranks: queries to the owners, answers back in query order
+    t0 = clock::now();
+    const void* keys = nullptr;
+    if (!pending) note(dfk_shard_adj_queries(ctx, &keys, sc.data()));
+    agree("dfk_shard_count / dfk_shard_adj_queries");
+    T.all_gather(sc.data(), w, all.data());
+    uint64_t n_q = 0, n_in = 0;
+    for (int s = 0; s < w; ++s) { rc[s] = all[(size_t)s * w + r]; n_in += rc[s]; n_q += sc[s]; if (s != r) times->bytes_sent += 17 * sc[s]; }
+    void *d_in = nullptr, *d_ans = nullptr, *d_back = nullptr;
+    DFKX_HIP(hipMalloc(&d_in, 16 * n_in + 16)); DFKX_HIP(hipMalloc(&d_ans, n_in + 16)); DFKX_HIP(hipMalloc(&d_back, n_q + 16));
+    try {
+        all_to_all_v(T, keys, sc.data(), d_in, rc.data(), 16, piece);
+        note(dfk_shard_adj_answer(ctx, d_in, n_in, d_ans));
+        agree("dfk_shard_adj_answer");
+        all_to_all_v(T, d_ans, rc.data(), d_back, sc.data(), 1, piece);
+        note(dfk_shard_adj_apply(ctx, d_back, n_q));
+        agree("dfk_shard_adj_apply");
+    } catch (...) { (void)hipFree(d_in); (void)hipFree(d_ans); (void)hipFree(d_back); throw; }
+    (void)hipFree(d_in); (void)hipFree(d_ans); (void)hipFree(d_back);
+    times->adjacency += secs(t0);
+    times->total = secs(t_all);
+}
+
+} // namespace dfkx

@@ -110,6 +110,8 @@ struct dfk_ctx {
     uint32_t shard_send_pass = 0;             //   ... and which pass that is
     DevBuf shard_recv[2];                     // receive buffers handed to the caller by dfk_shard_recv_buffer: the pass being
     unsigned shard_recv_seq = 0;              //   counted and the one being received under it alternate between the two
+    uint64_t budget_taken = 0;                //   ... and the part of the budget they stand for
+    void* sh_staged[6] = {};                  // dfk_shard_begin_host: this rank's inputs on the device (hipMalloc, outside the arena)
     DevBuf adj_keys, adj_src; uint64_t adj_n = 0;
     DevBuf set; uint64_t set_mask = 0;
     uint32_t shard_world = 1, shard_log2_nb = 0;
@@ -257,6 +259,8 @@ struct dfk_ctx {
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
         n_solid = 0; adj_n = 0; shard_open = false;
         if (shard_state) { shard_state_free(shard_state); shard_state = nullptr; }
+        for (void*& p : sh_staged) if (p) { (void)hipFree(p); p = nullptr; }
+        budget += budget_taken; budget_taken = 0;
         if (graph_state) { graph_state_free(graph_state); graph_state = nullptr; }
     }
 };
@@ -1495,11 +1499,11 @@ int upload(dfk_ctx* c, void* d, const void* h, uint64_t bytes)
 
 // The dictionary as the device holds it (pass after pass, no order inside a pass), streamed into a kmers.kvec image:
 // every chunk has its place in the file, so the lanes write independently (pwrite).
-int write_parts_unsorted(dfk_ctx* c, int fd, bool pre)
+int write_parts_unsorted(dfk_ctx* c, int fd, bool pre, uint64_t first_byte = 16)
 {
     struct Piece { const char* src; uint64_t bytes, file_off; };
     std::vector<Piece> pieces;
-    uint64_t at = 16;
+    uint64_t at = first_byte;
     for (const dfk_ctx::Part& pt : c->parts) {
         const DevBuf& src = pre ? pt.pre : pt.buf;
         for (uint64_t o = 0; o < pt.n * 32; o += XFER_CHUNK) pieces.push_back(Piece{(const char*)src.p + o, std::min<uint64_t>(XFER_CHUNK, pt.n * 32 - o), at + o});
@@ -1814,6 +1818,31 @@ int dfk_write_kvec(dfk_ctx* c, const char* path, int flags)
     bool ok = fwrite("BINWRITE", 1, 8, f) == 8 && fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v->data(), 32, n, f) == n);
     ok = (fclose(f) == 0) && ok;
     return ok ? 0 : fail(DFK_E_ARG, "short write to %s", path);
+    });
+}
+
+int dfk_write_kvec_part(dfk_ctx* c, const char* path, int flags, uint64_t first_entry, uint64_t total_entries)
+{
+    return guarded([&]() -> int {
+    if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
+    if (!path) return fail(DFK_E_ARG, "null path");
+    if (flags & DFK_KVEC_SORTED) return fail(DFK_E_ARG, "the shares of several ranks are written in device order");
+    const int pre = flags & DFK_KVEC_PRE_ADJ;
+    if (pre && !(c->cfg.flags & DFK_F_KEEP_PRE_ADJ)) return fail(DFK_E_STATE, "pre-adjacency view needs DFK_F_KEEP_PRE_ADJ");
+    if (first_entry + c->n_solid > total_entries) return fail(DFK_E_ARG, "this rank's %llu entries from %llu on do not fit %llu", (unsigned long long)c->n_solid,
+                                                              (unsigned long long)first_entry, (unsigned long long)total_entries);
+    HIP_TRY(hipSetDevice(c->device));
+    const int fd = open(path, O_WRONLY | O_CREAT, 0666);
+    if (fd < 0) return fail(DFK_E_ARG, "cannot open %s", path);
+    int rc = 0;
+    if (first_entry == 0) {
+        char head[16]; memcpy(head, "BINWRITE", 8); memcpy(head + 8, &total_entries, 8);
+        if (pwrite(fd, head, 16, 0) != 16) rc = fail(DFK_E_ARG, "short write to %s", path);
+    }
+    if (!rc && ftruncate(fd, (off_t)(16 + 32 * total_entries)) != 0) rc = fail(DFK_E_ARG, "cannot size %s", path);   // every rank: the same size
+    if (!rc) rc = write_parts_unsorted(c, fd, pre != 0, 16 + 32 * first_entry);
+    if (close(fd) != 0 && !rc) rc = fail(DFK_E_ARG, "short write to %s", path);
+    return rc;
     });
 }
 

@@ -174,3 +174,55 @@ def test_df_general_path_on_gpu(tmp_path, golden_dir, oracle):
     _, e = _kvec(f"{tmp_path}/w/kmers.kvec")
     util.assert_same_solid(e[np.lexsort((e["w1"], e["w0"]))], ref["solid"], "two-input run")
     assert open(f"{tmp_path}/w/stats/histogram_kmer_count.json").read() == oracle.spectrum_json(ref["hist"])
+
+
+def _sorted_kvec(path):
+    _, e = _kvec(path)
+    return e[np.lexsort((e["w1"], e["w0"]))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rccl1", "loopback2", "loopback4"])
+def test_df_num_gpus_cpp_host(tmp_path, golden_dir, oracle, mode):
+    """`DF NUM_GPUS=N`: the C++ host (df_shard.h) -- one rank per GPU over RCCL, spawned before any HIP call; on this
+    one-GPU box: a single RCCL rank through the sharded path, and two / four ranks as threads sharing the GPU over
+    the loopback transport (RCCL refuses two ranks on one device).  Same dictionary and spectrum as the oracle."""
+    from tests import util
+    env = dict(os.environ)
+    if mode == "rccl1":
+        args, env["DF_FORCE_SHARDED"] = ["NUM_GPUS=1"], "1"
+    else:
+        args, env["DF_TRANSPORT"] = [f"NUM_GPUS={mode[-1]}"], "loopback"
+        env["DFK_A2A_PIECE_BYTES"] = "4096"                               # several rounds per pair of ranks
+    r = subprocess.run([DF, f"ROOT={tmp_path}", f"LR={golden_dir}/reads.fastb", "PIPELINE=cs", "ALIGN=False", "NUM_THREADS=8", "MAX_MEM_GB=640",
+                        "HBM_GB=8", *args], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exp = np.load(f"{golden_dir}/expect_k48.npz")
+    w = f"{tmp_path}/GapToy/1"
+    assert open(f"{w}/stats/histogram_kmer_count.json").read() == oracle.spectrum_json(exp["spectrum"])
+    util.assert_same_solid(_sorted_kvec(f"{w}/kmers.kvec"), exp["solid_post"], "kmers.kvec written by the ranks")
+    rd = lambda p: open(p, "rb").read()
+    for ext in ("fastb", "qualp", "bci"):
+        assert rd(f"{w}/data/frag_reads_orig.{ext}") == rd(f"{golden_dir}/reads.{ext}"), ext
+    assert "DF_TIMING {" in r.stdout and f"dictionary covers {len(exp['solid_post'])}" in r.stdout.replace(",", "")
+
+
+@pytest.mark.gpu
+def test_df_num_gpus_larger_set_equals_single_gpu(tmp_path, oracle):
+    """80 k pairs, four ranks (loopback) against one GPU through the same binary: same spectrum text, same entries."""
+    from superplus_amd import synth
+    from tests import util
+    g = synth.make_genome(400000, 41)
+    rs = synth.make_reads(g, 80000, 42).numpy()
+    feudal.write_fastb(f"{tmp_path}/r.fastb", rs["packed"], rs["base_off"], rs["read_len"])
+    feudal.write_qualp(f"{tmp_path}/r.qualp", rs["pq_bytes"], rs["pq_off"])
+    feudal.write_bci(f"{tmp_path}/r.bci", rs["bci"])
+    a = subprocess.run([DF, f"OUT_DIR={tmp_path}/one", f"LR={tmp_path}/r.fastb", "GRAPH=False", "HBM_GB=16"], capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run([DF, f"OUT_DIR={tmp_path}/four", f"LR={tmp_path}/r.fastb", "NUM_GPUS=4", "HBM_GB=4"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DF_TRANSPORT="loopback"))
+    assert b.returncode == 0, b.stdout + b.stderr
+    assert open(f"{tmp_path}/one/stats/histogram_kmer_count.json").read() == open(f"{tmp_path}/four/stats/histogram_kmer_count.json").read()
+    util.assert_same_solid(_sorted_kvec(f"{tmp_path}/four/kmers.kvec"), _sorted_kvec(f"{tmp_path}/one/kmers.kvec"), "four ranks against one GPU")
+    ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
+    util.assert_same_solid(_sorted_kvec(f"{tmp_path}/four/kmers.kvec"), ref["solid"], "four ranks against the oracle")

@@ -181,3 +181,14 @@ def test_one_rank_failing_stops_every_rank(fail_in):
         assert res == {0: "completed", 1: "completed"}, res
     else:
         assert res == {0: "DfkError -4", 1: "DfkError -4"}, res
+
+
+def test_cpp_exchange_schedule(tmp_path):
+    """The C++ host's all-to-all schedule (superplus_amd/csrc/dfk_exchange.h: pieces in rounds, rank r to r+d while it
+    receives from r-d) over a loopback transport, every rank a thread: tests/cpp/test_exchange.cc."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_exchange")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-Wall", "-o", exe, os.path.join(root, "tests", "cpp", "test_exchange.cc")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "FAILED" not in out.stdout and out.stdout.count(": ok") >= 20, out.stdout + out.stderr
