@@ -28,6 +28,7 @@ extern "C" {
 #endif
 
 #define DFK_ABI_VERSION 1
+#define DFK_MAX_MIN_BC 8u
 
 enum {
     DFK_OK            = 0,
@@ -47,7 +48,7 @@ typedef struct dfk_config {
     uint32_t K;                 /* 40, 48 or 60 */
     uint32_t min_qual;          /* MIN_QUAL, default 7   (10X/DF.cc:129-132) */
     uint32_t min_freq;          /* MIN_FREQ, default 3 */
-    uint32_t min_bc;            /* MIN_BC,   default 2; 0..4 */
+    uint32_t min_bc;            /* MIN_BC,   default 2; 0..DFK_MAX_MIN_BC (a table slot remembers MIN_BC-1 distinct barcodes) */
     int32_t  device;            /* HIP device ordinal */
     int64_t  ign_bc_below;      /* createDict ignBcBelow (= bc_start, DF.cc:344-349) */
     uint64_t hbm_budget_bytes;  /* 0 = 90 % of free HBM (mem_frac analogue, GRAPHMEM=0.9); larger requests are clamped to that */

@@ -92,6 +92,7 @@ struct dfk_ctx {
     struct Part { DevBuf buf, pre; uint64_t n = 0; uint64_t blist = 0, n_blist = 0; bool listed = false; };   // listed: n_blist is all of them
     bool want_blist = false;                  // single-GPU runs: list each part's boundary entries while the next pass is counted
     int pending_blist = -1;                   // part whose list is still to be launched (see launch_boundary_list)
+    std::function<int()> after_count_launch;  // the next range's sweep, when it is to start behind k_count rather than ahead of it (run_typed)
     std::vector<Part> parts;
     uint64_t n_solid = 0, n_boundary = 0;
     unsigned seg_attempt = 0;                 // the room for a pass's solid k-mers is (estimate << seg_attempt)
@@ -499,8 +500,24 @@ template <int K> uint64_t item_budget(const dfk_ctx* c)
 struct ScatterJob { Partition P; DevBuf cur, d_bad; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; uint32_t lo = 0, n = 0; };
 
 template <int K>
+int scatter_launch(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0, ScatterJob* J)
+{
+    const PartParams pp = part_params<K>(c, T.log2_nb, log2_world, read_id0, J->lo, J->n);
+    HIP_TRY(hipEventRecord(J->e0, J->st));
+    if (in.n_reads)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 256ull * sweep_reads<K>() - 1) / (256ull * sweep_reads<K>()))),
+                           dim3(256), 0, J->st,
+                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
+                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p, (const uint32_t*)T.classes.p,
+                           (unsigned long long*)J->cur.p, J->P.n_records, (uint4*)J->P.records.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(J->e1, J->st));
+    return 0;
+}
+
+template <int K>
 int scatter_begin(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log2_world, int64_t read_id0,
-                  uint32_t sub_lo, uint32_t sub_n, ScatterJob* J)
+                  uint32_t sub_lo, uint32_t sub_n, ScatterJob* J, bool launch_now = true)
 {
     Partition* P = &J->P;
     J->st = c->stream; J->lo = sub_lo; J->n = sub_n;
@@ -514,15 +531,8 @@ int scatter_begin(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t l
     HIP_TRY(hipMemcpyAsync(J->cur.p, P->base.p, nb * 8, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(J->d_bad.p, 0, 16, c->stream));
     if (!J->e0) { HIP_TRY(hipEventCreate(&J->e0)); HIP_TRY(hipEventCreate(&J->e1)); }
-    HIP_TRY(hipEventRecord(J->e0, c->stream));
-    if (in.n_reads)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_runs<K>), dim3((unsigned)((in.n_reads + 256ull * sweep_reads<K>() - 1) / (256ull * sweep_reads<K>()))),
-                           dim3(256), 0, c->stream,
-                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
-                           (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (const uint4*)T.summ.p, (const uint32_t*)T.classes.p,
-                           (unsigned long long*)J->cur.p, P->n_records, (uint4*)P->records.p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(J->e1, c->stream));
+    (void)pp;
+    if (launch_now) return scatter_launch<K>(c, in, T, log2_world, read_id0, J);
     return 0;
 }
 
@@ -637,7 +647,7 @@ int count_run_end(dfk_ctx* c, CountRun* R)
 template <int K> unsigned count_grid(const dfk_ctx* c, int nbc = 1)      // persistent workgroups of k_count: as many as fit the LDS
 {
     constexpr int LOG2S = CountCfg<K>::LOG2S, NW = CountCfg<K>::NWAVES;
-    const size_t lds = nbc <= 1 ? count_lds_bytes<K, LOG2S, NW, 1>() : nbc == 2 ? count_lds_bytes<K, LOG2S, NW, 2>() : count_lds_bytes<K, LOG2S, NW, 3>();
+    const size_t lds = count_lds_bytes<K, LOG2S, NW, 1>() + (size_t)(nbc > 1 ? nbc - 1 : 0) * sizeof(uint32_t) * (1u << LOG2S);   // one more word per slot and barcode beyond the first
     const unsigned per_cu = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / lds);
     return (unsigned)c->prop.multiProcessorCount * per_cu;
 }
@@ -680,6 +690,7 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
                        (const uint4*)P.records.p, d_items, (const uint64_t*)P.base.p, cp, R.g, R.seg, (WgOut*)R.d_wg.p, R.hist,
                        (ItemRange*)d_ovf.p, d_sub);
     HIP_TRY(hipGetLastError());
+    if (c->after_count_launch) { std::function<int()> f; f.swap(c->after_count_launch); rc = f(); if (rc) return rc; }
     rc = launch_boundary_list(c); if (rc) return rc;
     *kernel_ms += tk.stop();
     CountGlobals g{};
@@ -814,7 +825,7 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
 // k-mers into a dense part.
 // barcodes a table slot remembers: max(1, MIN_BC - 1); 0 without barcodes
 int barcode_words(const dfk_ctx* c, bool have_bc)
-{ return !have_bc ? 0 : (int)std::max<uint32_t>(1, std::min<uint32_t>(c->cfg.min_bc, 4) - (c->cfg.min_bc > 1 ? 1 : 0)); }
+{ return !have_bc ? 0 : (int)std::max<uint32_t>(1, std::min<uint32_t>(c->cfg.min_bc, DFK_MAX_MIN_BC) - (c->cfg.min_bc > 1 ? 1 : 0)); }
 
 // solid k-mers a pass of n_inst instances is expected to emit at most (what its part's reservation is sized for)
 uint64_t solid_cap(const dfk_ctx* c, const CountRun& R, uint64_t n_inst)
@@ -1038,7 +1049,11 @@ int stage_count(dfk_ctx* c, const Partition& P, CountRun& R, bool have_bc)
     case 0: return count_run<K, 0>(c, P, R);
     case 1: return count_run<K, 1>(c, P, R);
     case 2: return count_run<K, 2>(c, P, R);
-    default: return count_run<K, 3>(c, P, R);
+    case 3: return count_run<K, 3>(c, P, R);
+    case 4: return count_run<K, 4>(c, P, R);
+    case 5: return count_run<K, 5>(c, P, R);
+    case 6: return count_run<K, 6>(c, P, R);
+    default: return count_run<K, 7>(c, P, R);
     }
 }
 
@@ -1287,8 +1302,19 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     Job cur, nxt;
     auto drop_events = [&](Job& j) { if (j.sj.e0) { (void)hipEventDestroy(j.sj.e0); (void)hipEventDestroy(j.sj.e1); j.sj.e0 = j.sj.e1 = nullptr; } };
     // start the scatter of [lo, lo + n) on the second stream; NOMEM leaves nothing behind
-    auto start = [&](Job& j, uint32_t lo, uint32_t n) -> int {
+    // A range that is scattered beside a running count normally starts AHEAD of it (a sweep that starts after the
+    // persistent workgroups have filled the CUs runs 30 % longer, and for the large ranges of the first passes it would
+    // outlast the count).  For a SMALL range that order is the 2.5x cliff of DESIGN.md section 9: k_count launched into
+    // a chip full of short-lived sweep blocks (4 KB of LDS each) gets its 71-KB workgroups placed between them, and a
+    // workgroup that lands in the middle of a CU's 160 KB leaves no contiguous 71 KB for the second one as long as it
+    // lives -- it is persistent, so for the whole launch: half the workgroups, 30 G instead of 74 G instances/s, also
+    // after the sweep has ended (timeline: profiles/r02_cliff_timeline.txt; with the kernels serialised under --pmc
+    // every pass runs at the same 0.254 cycles per instance).  A small range's sweep is short, so it is launched
+    // BEHIND k_count instead: into what k_count leaves free.
+    static const double defer_below = getenv("DFK_DEFER_SWEEP_BELOW") ? atof(getenv("DFK_DEFER_SWEEP_BELOW")) : 0.045;
+    auto start = [&](Job& j, uint32_t lo, uint32_t n, bool may_defer = false) -> int {
         j.sj = ScatterJob{}; j.mark = c->alloc_seq; j.valid = false;
+        const bool defer = may_defer && (double)n < defer_below * (double)sub_nb;
         TRACE("pass range [%u, %u) of %u (%.1f %%), %.2f GB held of %.2f", lo, lo + n, sub_nb, 100.0 * n / sub_nb, c->held / 1e9, c->budget / 1e9);
         // the pass's block: tables (80 B per bucket with their scratch) and records (an estimate: what does not
         // fit the block falls back to the open arena)
@@ -1298,10 +1324,11 @@ int run_typed(dfk_ctx* c, const Inputs& in)
         int r = c->alloc(j.blk.block, blk_bytes, "pass block");
         if (!r) {
             c->sub = &j.blk;
-            { StreamSwap sw(c, c->stream2); r = scatter_begin<K>(c, in, T, 0, 0, lo, n, &j.sj); }
+            { StreamSwap sw(c, c->stream2); r = scatter_begin<K>(c, in, T, 0, 0, lo, n, &j.sj, !defer); }
             c->sub = nullptr;
         }
         if (r) { (void)hipStreamSynchronize(c->stream2); c->release_since(j.mark); drop_events(j); return r; }
+        if (defer) { ScatterJob* sj = &j.sj; c->after_count_launch = [c, &in, &T, sj]() { return scatter_launch<K>(c, in, T, 0, 0, sj); }; TRACE("  (its sweep starts behind k_count)"); }
         j.valid = true;
         return 0;
     };
@@ -1335,7 +1362,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
             const RunningPass rp{cur.blk.block.bytes, cur.sj.P.n_inst, n, (uint64_t)((char*)cur.blk.block.p - c->chunks[0].p)};
             const uint32_t n2 = forced ? std::min(per_forced, sub_nb - nlo) : plan_range(c, T, R, sub_nb, nlo, &rp, overlap);
             if (n2) {
-                const int r2 = start(nxt, nlo, n2);
+                const int r2 = start(nxt, nlo, n2, true);
                 if (r2 && r2 != DFK_E_NOMEM) return r2;                // NOMEM: this range is scattered after the count instead
             }
         }
@@ -1344,8 +1371,16 @@ int run_typed(dfk_ctx* c, const Inputs& in)
             case 0: rc = count_run<K, 0>(c, cur.sj.P, R); break;
             case 1: rc = count_run<K, 1>(c, cur.sj.P, R); break;
             case 2: rc = count_run<K, 2>(c, cur.sj.P, R); break;
-            default: rc = count_run<K, 3>(c, cur.sj.P, R); break;
+            case 3: rc = count_run<K, 3>(c, cur.sj.P, R); break;
+            case 4: rc = count_run<K, 4>(c, cur.sj.P, R); break;
+            case 5: rc = count_run<K, 5>(c, cur.sj.P, R); break;
+            case 6: rc = count_run<K, 6>(c, cur.sj.P, R); break;
+            default: rc = count_run<K, 7>(c, cur.sj.P, R); break;
             }
+        }
+        if (c->after_count_launch) {                                     // (no k_count was launched: an error on the way there)
+            std::function<int()> f; f.swap(c->after_count_launch);
+            if (!rc) { const int r3 = f(); if (r3) return r3; } else nxt.valid = false;
         }
         if (rc == DFK_E_NOMEM || rc == E_SEGMENT_FULL) {
             HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipStreamSynchronize(c->stream2));
@@ -1585,7 +1620,7 @@ int dfk_create(const dfk_config* cfg, dfk_ctx** out)
     *out = nullptr;
     if (cfg->abi_version != DFK_ABI_VERSION) return fail(DFK_E_ARG, "dfk_config.abi_version %u != %d", cfg->abi_version, DFK_ABI_VERSION);
     if (cfg->K != 40 && cfg->K != 48 && cfg->K != 60) return fail(DFK_E_ARG, "K=%u: the reference instantiates 40, 48 and 60 only", cfg->K);
-    if (cfg->min_bc > 4) return fail(DFK_E_ARG, "MIN_BC=%u: a table slot remembers at most 3 distinct barcodes (MIN_BC <= 4)", cfg->min_bc);
+    if (cfg->min_bc > DFK_MAX_MIN_BC) return fail(DFK_E_ARG, "MIN_BC=%u: a table slot remembers at most %u distinct barcodes (MIN_BC <= %u)", cfg->min_bc, DFK_MAX_MIN_BC - 1, DFK_MAX_MIN_BC);
     if (cfg->min_freq == 0 || cfg->min_freq > 0xFFFFFFu) return fail(DFK_E_ARG, "MIN_FREQ out of range");
     uint32_t M = cfg->minimizer_len ? cfg->minimizer_len : 16;
     if (M < 8 || M > 16 || M >= cfg->K) return fail(DFK_E_ARG, "minimizer_len must be in 8..16");

@@ -146,7 +146,8 @@ def run_dict(head, out, K, use_bc, min_bc, min_freq=3, ign=0):
 
 
 # filter variants of createDict (BuildReadQGraph48.cc:104-132,167-174,313) on the golden reads: (tag, min_freq, min_bc, use_bc, ign_bc_below)
-VARIANTS = [("minbc0", 3, 0, 1, 0), ("minbc3", 3, 3, 1, 0), ("minbc4", 3, 4, 1, 0), ("minfreq1", 1, 2, 1, 0),
+VARIANTS = [("minbc0", 3, 0, 1, 0), ("minbc3", 3, 3, 1, 0), ("minbc4", 3, 4, 1, 0), ("minbc5", 3, 5, 1, 0), ("minbc6_minfreq2", 2, 6, 1, 0),
+            ("minbc8", 3, 8, 1, 0), ("minfreq1", 1, 2, 1, 0),
             ("minfreq2", 2, 2, 1, 0), ("minfreq5", 5, 2, 1, 0), ("ign600", 3, 2, 1, 600), ("ign600_minbc3_minfreq2", 2, 3, 1, 600),
             ("ign_all", 5, 2, 1, 10 ** 9), ("minfreq1_nobc", 1, 0, 0, 0)]
 

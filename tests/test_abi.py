@@ -46,6 +46,6 @@ def test_create_fails_loudly_without_gpu():
 
 def test_create_rejects_bad_config():
     import pytest
-    for kw in (dict(K=47), dict(K=48, min_bc=5), dict(K=48, min_freq=0), dict(K=48, minimizer_len=20)):
+    for kw in (dict(K=47), dict(K=48, min_bc=9), dict(K=48, min_freq=0), dict(K=48, minimizer_len=20)):
         with pytest.raises(dfk.DfkError):
             dfk.Dfk(**kw)

@@ -89,6 +89,18 @@ def test_filter_variants(oracle, min_freq, min_bc, use_bc, ign):
     util.check_parity(ref, d)
 
 
+@pytest.mark.parametrize("K,min_bc", [(48, 5), (48, 8), (60, 6), (40, 7)])
+def test_min_bc_up_to_eight(oracle, K, min_bc):
+    """MIN_BC 5..8: a table slot remembers MIN_BC-1 distinct barcodes, one word each (up to 7 extra words per slot:
+    one workgroup per CU at K=60); many barcodes per locus so that the filter bites without emptying the set."""
+    rs = util.make_set(29, 60000, 9000, pairs_per_barcode=3)
+    ref, d = util.run_both(oracle, rs, K=K, min_bc=min_bc)
+    st = util.check_parity(ref, d)
+    assert 0 < st["n_solid"] < util.run_both(oracle, rs, K=K, min_bc=2)[0]["n_solid"]
+    ref, d = util.run_both(oracle, rs, K=K, min_bc=min_bc, inst_per_item=100000, passes=2)
+    assert util.check_parity(ref, d)["n_overflow_items"] > 0
+
+
 @pytest.mark.parametrize("K,min_bc", [(40, 3), (60, 4)])
 def test_min_bc_above_two_other_k(oracle, K, min_bc):
     """MIN_BC 3 and 4 (a table slot remembers MIN_BC-1 barcodes) with 3 and 4 key words per slot; also through the
