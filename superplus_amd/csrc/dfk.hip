@@ -574,6 +574,7 @@ int scatter_end(dfk_ctx* c, const Inputs& in, const BucketTable& T, uint32_t log
 }
 
 // ------------------------------------------------------------------ stage: count (a2 second half, a3, a4, a5)
+constexpr int E_SPLIT_NO_ROOM = -101;  // internal: count_split could not even start (no room for the expanded records): sub-passes instead
 constexpr int E_SEGMENT_FULL = -100;   // internal: the room reserved for a pass's solid k-mers was too small; redo the pass with more
 
 struct CountRun {                     // device state shared by the count launches of one run
@@ -750,8 +751,21 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
     // that runs out of probe steps says the guess was too low: every table is then rebuilt twice as large.
     double per_inst = c->distinct_per_inst > 0.0 ? std::min(1.0, std::max(0.05, 1.5 * c->distinct_per_inst)) : 1.0;
     DevBuf d_items, d_fail, d_pre;
-    R.big_cap = tot_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;   // every solid k-mer has >= min_freq instances
-    rc = c->alloc(R.big, R.big_cap * 32, "fallback solid entries"); if (rc) return rc;
+    {
+        // the fallback's own output buffer; a pass can come here more than once (the sub-buckets of split hot buckets,
+        // then the pass's other buckets): what an earlier call emitted stays in front
+        const uint64_t more = tot_inst / std::max<uint32_t>(1, c->cfg.min_freq) + 1;   // every solid k-mer has >= min_freq instances
+        if (!R.big.p) { R.big_cap = more; rc = c->alloc(R.big, R.big_cap * 32, "fallback solid entries"); if (rc) return rc; }
+        else {
+            CountGlobals g0{};
+            HIP_TRY(hipMemcpy(&g0, R.d_g.p, sizeof g0, hipMemcpyDeviceToHost));
+            DevBuf grown;
+            rc = c->alloc(grown, (g0.big_cursor + more) * 32, "fallback solid entries"); if (rc) return rc;
+            if (g0.big_cursor) HIP_TRY(hipMemcpy(grown.p, R.big.p, g0.big_cursor * 32, hipMemcpyDeviceToDevice));
+            c->release(R.big);
+            R.big = grown; R.big_cap = g0.big_cursor + more;
+        }
+    }
     rc = c->alloc(d_items, (uint64_t)n * sizeof(BigItem), "fallback items"); if (rc) return rc;
     rc = c->alloc(d_pre, 16ull * (n + 1), "fallback prefixes"); if (rc) return rc;
     rc = c->alloc(d_fail, 16, "fallback flag"); if (rc) return rc;
@@ -818,6 +832,97 @@ int launch_count_big(dfk_ctx* c, const Partition& P, const std::vector<ItemRange
         break;
     }
     c->release(d_items); c->release(d_fail); c->release(d_pre);
+    return 0;
+}
+
+// Fine buckets too rich for one LDS table, the linear way: one pass over their records writes every instance out as
+// a record of one k-mer, grouped by a second hash of the canonical k-mer into sub-buckets of ~700 distinct k-mers
+// (k_hot_split: count, scan, scatter); the sub-buckets are then an ordinary small pass for k_count.  What still does
+// not fit (a guess too low) goes to the HBM tables.  Returns DFK_E_NOMEM untouched when the expanded records do not
+// fit: the caller then falls back to sub-passes.
+template <int K, int NBC>
+int count_split(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& buckets, const std::vector<uint64_t>& inst,
+                const std::vector<uint32_t>& log2p, CountRun& R)
+{
+    constexpr int NW = 8;
+    const uint32_t n = (uint32_t)buckets.size();
+    std::vector<HotItem> items(n);
+    std::vector<uint32_t> idx(2 * n);
+    uint64_t ns = 0, tot = 0;
+    for (uint32_t i = 0; i < n; ++i) { items[i] = HotItem{buckets[i].b0, buckets[i].b1, (uint32_t)ns, log2p[i]}; ns += 1ull << log2p[i]; tot += inst[i]; idx[2 * i] = buckets[i].b0; idx[2 * i + 1] = buckets[i].b1; }
+    if (ns >= (1ull << 24)) { fail(DFK_E_NOMEM, "more than 2^24 sub-buckets in one pass"); return E_SPLIT_NO_ROOM; }   // (the record header keeps 24 bits)
+    const uint64_t mark = c->alloc_seq;
+    bool started = false;             // once a sub-bucket has been counted there is no way back to sub-passes: an error undoes the pass
+    auto undo = [&](int rc) {
+        (void)hipStreamSynchronize(c->stream);
+        if (!started) { c->release_since(mark); return rc == DFK_E_NOMEM ? E_SPLIT_NO_ROOM : rc; }
+        return rc;
+    };
+    // record ranges of the buckets -> chunk tickets
+    DevBuf d_idx, d_val, d_items, d_pre, d_tk, acc;
+    int rc = c->alloc(d_idx, 8ull * n, "gather index"); if (rc) return undo(rc);
+    rc = c->alloc(d_val, 16ull * n, "gather values"); if (rc) return undo(rc);
+    HIP_TRY(hipMemcpyAsync(d_idx.p, idx.data(), 8ull * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather_u64, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, (const uint64_t*)P.base.p, (const uint32_t*)d_idx.p, 2 * n, (uint64_t*)d_val.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint64_t> rec(2 * n), chunk_pre(n + 1, 0);
+    HIP_TRY(hipMemcpyAsync(rec.data(), d_val.p, 16ull * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; ++i) chunk_pre[i + 1] = chunk_pre[i] + (rec[2 * i + 1] - rec[2 * i] + COUNT_CHUNK - 1) / COUNT_CHUNK;
+    rc = c->alloc(d_items, (uint64_t)n * sizeof(HotItem), "hot buckets"); if (rc) return undo(rc);
+    rc = c->alloc(d_pre, 8ull * (n + 1), "hot bucket chunks"); if (rc) return undo(rc);
+    rc = c->alloc(d_tk, 16, "hot bucket ticket"); if (rc) return undo(rc);
+    rc = c->alloc(acc, 8ull * ns, "sub-bucket counters"); if (rc) return undo(rc);
+    HIP_TRY(hipMemcpyAsync(d_items.p, items.data(), (uint64_t)n * sizeof(HotItem), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_pre.p, chunk_pre.data(), 8ull * (n + 1), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_tk.p, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(acc.p, 0, 8ull * ns, c->stream));
+    const unsigned cus = (unsigned)c->prop.multiProcessorCount;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + NW * BIG_TICKET_CHUNKS - 1) / (NW * BIG_TICKET_CHUNKS), 8ull * cus));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hot_split<K, NW, false>), dim3(grid), dim3(NW * 64), 0, c->stream, (const uint4*)P.records.p, (const HotItem*)d_items.p,
+                       (const uint64_t*)P.base.p, (const uint64_t*)d_pre.p, n, (unsigned long long*)d_tk.p, (unsigned long long*)acc.p,
+                       (unsigned long long*)nullptr, (uint64_t)0, (uint4*)nullptr);
+    HIP_TRY(hipGetLastError());
+    Partition P2;
+    rc = pass_tables(c, acc, 0, 1, 0, (uint32_t)ns, item_budget<K>(c), &P2); if (rc) return undo(rc);
+    if (P2.n_inst != tot || P2.n_records != tot) return undo(fail(DFK_E_HIP, "hot buckets: %llu instances split, %llu expected", (unsigned long long)P2.n_inst, (unsigned long long)tot));
+    DevBuf cur;
+    rc = c->alloc(cur, 8ull * ns, "sub-bucket cursors"); if (rc) return undo(rc);
+    rc = c->alloc(P2.records, 32ull * tot, "hot buckets' k-mer records"); if (rc) return undo(rc);
+    HIP_TRY(hipMemcpyAsync(cur.p, P2.base.p, 8ull * ns, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_tk.p, 0, 16, c->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hot_split<K, NW, true>), dim3(grid), dim3(NW * 64), 0, c->stream, (const uint4*)P.records.p, (const HotItem*)d_items.p,
+                       (const uint64_t*)P.base.p, (const uint64_t*)d_pre.p, n, (unsigned long long*)d_tk.p, (unsigned long long*)nullptr,
+                       (unsigned long long*)cur.p, tot, (uint4*)P2.records.p);
+    HIP_TRY(hipGetLastError());
+    // the sub-buckets as a pass of their own
+    started = true;
+    c->st.n_items += P2.n_items;
+    std::vector<ItemRange> overflowed, singles;
+    float ignored = 0;
+    rc = launch_count<K, NBC>(c, P2, (const ItemRange*)P2.items.p, P2.n_items, R, &overflowed, &ignored); if (rc) return undo(rc);
+    while (!overflowed.empty()) {
+        std::vector<ItemRange> next;
+        for (const ItemRange& r : overflowed) {
+            if (r.b1 - r.b0 <= 1) { singles.push_back(r); continue; }
+            const uint32_t mid = r.b0 + (r.b1 - r.b0) / 2;
+            next.push_back({r.b0, mid}); next.push_back({mid, r.b1});
+        }
+        overflowed.clear();
+        if (next.empty()) break;
+        DevBuf d_next; rc = c->alloc(d_next, next.size() * sizeof(ItemRange), "split items"); if (rc) return undo(rc);
+        HIP_TRY(hipMemcpyAsync(d_next.p, next.data(), next.size() * sizeof(ItemRange), hipMemcpyHostToDevice, c->stream));
+        rc = launch_count<K, NBC>(c, P2, (const ItemRange*)d_next.p, next.size(), R, &overflowed, &ignored);
+        if (rc) return undo(rc);
+    }
+    TRACE("fallback: %u buckets (%llu instances) split into %llu sub-buckets, %llu items; %zu sub-buckets to HBM tables", n, (unsigned long long)tot,
+          (unsigned long long)ns, (unsigned long long)P2.n_items, singles.size());
+    if (!singles.empty()) { rc = launch_count_big<K, NBC>(c, P2, singles, R); if (rc) return undo(rc); }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // (everything allocated here goes back except R.big, the HBM path's output, which count_run collects)
+    const DevBuf keep_big = R.big;
+    for (size_t i = c->owned.size(); i-- > 0;)
+        if (c->owned[i].seq > mark && c->owned[i].p != keep_big.p) { DevBuf b; b.p = c->owned[i].p; b.bytes = c->owned[i].bytes; c->release(b); }
     return 0;
 }
 
@@ -930,7 +1035,26 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
         // and counted again -- its siblings are done and stay -- until p = MAX_P, where 1024 *instances* per sub-pass
         // are guaranteed.
         const double dpi = c->distinct_per_inst > 0.0 ? std::min(1.0, 2.0 * c->distinct_per_inst) : 0.5;   // (first pass: a guess)
+        // Buckets that would need four sub-passes or more (each sub-pass reads and extracts ALL of the bucket's
+        // instances again: work quadratic in the bucket's size, 6 s of a 9.5 s step at human scale with a 10 % repeat
+        // family) are partitioned a second time instead, by k-mer hash (count_split): linear work.
+        static const uint32_t split_from_p = getenv("DFK_SPLIT_FROM_LOG2") ? (uint32_t)atoi(getenv("DFK_SPLIT_FROM_LOG2")) : 2;
+        std::vector<ItemRange> sp_b; std::vector<uint64_t> sp_i; std::vector<uint32_t> sp_p; std::vector<uint32_t> sp_at;
         for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t inst = val[2 * i + 1] - val[2 * i];
+            const uint64_t guess = (uint64_t)((double)inst * dpi) + 1;
+            const uint32_t p = ceil_log2((guess + 699) / 700);
+            if (p >= split_from_p && p <= 22) { sp_b.push_back(singles[i]); sp_i.push_back(inst); sp_p.push_back(p); sp_at.push_back(i); }
+        }
+        std::vector<uint8_t> taken(n, 0);
+        if (!sp_b.empty()) {
+            const int r2 = count_split<K, NBC>(c, P, sp_b, sp_i, sp_p, R);
+            if (r2 == 0) { for (uint32_t i : sp_at) taken[i] = 1; }
+            else if (r2 != E_SPLIT_NO_ROOM) return r2;
+            else TRACE("fallback: no room to split %zu hot buckets (%s): sub-passes instead", sp_b.size(), g_err.c_str());
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            if (taken[i]) continue;
             const uint64_t inst = val[2 * i + 1] - val[2 * i];
             // (beyond MAX_P selector bits x 1024 instances the refinement below could not be guaranteed to end)
             if (ceil_log2((inst + PER_SUB - 1) / PER_SUB) > MAX_P) { huge.push_back(singles[i]); continue; }
@@ -1258,7 +1382,7 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
     // moves a range's records about 1.5 times as fast as k_count counts them, after ~10 ms of reading masks)
     if (running && overlap) n = std::min(n, 1.3 * (double)running->n_buckets);
     if (left <= 0.99 * fit && left < 1.06 * n) n = left;              // no sliver of a last pass if the rest (almost certainly) fits
-    else if (left > n && left < 1.7 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big and a small one
+    else if (left > n && left < 1.3 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big one and a sliver (1.7 while the cliff of section 9 was unexplained: a big count beside a small sweep)
     n = std::min(n, left);
     if (n < 16.0) return running ? 0u : (uint32_t)std::min(16.0, left);
     return (uint32_t)n;

@@ -884,6 +884,104 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     wave_sync();
 }
 
+constexpr int BIG_TICKET_CHUNKS = 4;                 // chunks a wave takes per ticket
+
+// item that owns position x of the concatenated chunk / slot space (pre[] ascending, pre[0] = 0, pre[n] = total)
+__device__ __forceinline__ uint32_t big_find(const uint64_t* __restrict__ pre, uint32_t n, uint64_t x)
+{
+    uint32_t lo = 0, hi = n;                         // pre[lo] <= x < pre[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ---- a fine bucket too rich for one LDS table: second-level partition by k-mer hash
+// All its instances are written out once as records of ONE k-mer each (same 32-byte format: nk = 1, the k-mer's own
+// predecessor / successor flags), grouped by `sel` = the top log2p bits of a second hash of the canonical k-mer: every
+// instance of a k-mer lands in the same sub-bucket, a sub-bucket holds ~700 distinct k-mers, and the sub-buckets are
+// then counted by the ordinary k_count as the buckets of a small pass of their own.  Work linear in the bucket's
+// instances -- counting it as 2^p sub-passes over the same records extracts every instance 2^p times.
+struct HotItem { uint32_t b0, b1; uint32_t sub_base; uint32_t log2p; };
+
+__device__ __forceinline__ uint32_t sub_bucket_hash(const Probe& A)
+{
+    uint32_t h = (A.k0 * 0x85EBCA77u) ^ __builtin_rotateleft32(A.k1 * 0xC2B2AE3Du, 7) ^ __builtin_rotateleft32(A.k2 * 0x27D4EB2Fu, 19) ^ (A.k3 * 0x9E3779B1u);
+    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 13;
+    return h;
+}
+
+template <int K, int NWAVES, bool WRITE>
+__global__ void __launch_bounds__(NWAVES * 64)
+k_hot_split(const uint4* __restrict__ records, const HotItem* __restrict__ items, const uint64_t* __restrict__ rec_base,
+            const uint64_t* __restrict__ chunk_pre, uint32_t n_items, unsigned long long* __restrict__ ticket,
+            unsigned long long* __restrict__ sub_acc,          // !WRITE: per sub-bucket records << 32 | instances (one each per instance)
+            unsigned long long* __restrict__ sub_cur,          // WRITE: per sub-bucket append cursor, starts at its first record
+            uint64_t n_out, uint4* __restrict__ out)
+{
+    __shared__ WaveStage<K> stages[NWAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveStage<K>* st = &stages[wave];
+    const uint64_t n_chunks = chunk_pre[n_items];
+    for (uint32_t guard = 0; guard < 0x7FFFFFFFu; ++guard) {
+        unsigned long long t0 = 0;
+        if (lane == 0) t0 = atomicAdd(ticket, (unsigned long long)BIG_TICKET_CHUNKS);
+        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)t0);
+        if (first >= n_chunks) break;
+        for (int k = 0; k < BIG_TICKET_CHUNKS; ++k) {
+            const uint64_t t = first + k;
+            if (t >= n_chunks) break;
+            const uint32_t it = big_find(chunk_pre, n_items, t);
+            const HotItem I = items[it];
+            const uint64_t rb = rec_base[I.b0] + (t - chunk_pre[it]) * COUNT_CHUNK, re = rec_base[I.b1];
+            // stage the chunk and map its instances onto lanes (as wave_count_chunk does)
+            const uint64_t hidx = 2 * rb + lane;
+            uint4 v{0, 0, 0, 0};
+            if (hidx < 2 * re) v = records[hidx];
+            reinterpret_cast<uint4*>(st->rec)[lane] = v;
+            st->msk[lane] = 0;
+            wave_sync();
+            const uint32_t nk = lane < COUNT_CHUNK ? (st->rec[8 * lane] & 63u) : 0u;
+            const uint32_t incl = wave_incl_scan(nk, lane);
+            const uint32_t start = incl - nk;
+            const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
+            if (lane < COUNT_CHUNK) st->starts[lane] = start;
+            if (nk) atomicOr(&st->msk[start >> 5], 1u << (start & 31u));
+            wave_sync();
+            const uint32_t c0 = __popc(tld(&st->msk[lane]));
+            st->pc[lane] = wave_incl_scan(c0, lane) - c0;
+            wave_sync();
+            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                if (i < total) {
+                    const InstRegs in = fetch_instance<K>(st, i);
+                    const Probe A = make_probe<K>(in, 2u, true);
+                    const uint32_t sub = I.sub_base + (I.log2p ? sub_bucket_hash(A) >> (32u - I.log2p) : 0u);
+                    if (!WRITE) atomicAdd(&sub_acc[sub], (1ull << 32) | 1ull);
+                    else {
+                        const uint64_t dst = atomicAdd(&sub_cur[sub], 1ull);
+                        if (dst < n_out) {
+                            // the instance's own stream: predecessor slot, K bases, successor slot
+                            const uint32_t q = in.q, sh = (2u * q) & 31u, rnk = in.hdr & 63u;
+                            const bool hp = q > 0 || (in.hdr & 64u), hs = q + 1 < rnk || (in.hdr & 128u);
+                            uint32_t o[4] = {alignbit(in.p1, in.p0, sh), alignbit(in.p2, in.p1, sh), alignbit(in.p3, in.p2, sh), alignbit(in.p4, in.p3, sh)};
+                            const uint32_t nbits = 2u * (1u + (uint32_t)K + (hs ? 1u : 0u));      // <= 124
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                const uint32_t lo = 32u * w;
+                                if (nbits <= lo) o[w] = 0;
+                                else if (nbits < lo + 32u) o[w] &= (1u << (nbits - lo)) - 1u;
+                            }
+                            if (!hp) o[0] &= ~3u;
+                            out[2 * dst] = uint4{rec_header(1u, hp, hs, sub), in.tag, o[0], o[1]};
+                            out[2 * dst + 1] = uint4{o[2], o[3], 0u, 0u};
+                        }
+                    }
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
 template <bool USE_BC>
 __device__ __forceinline__ bool bc_pass(uint32_t v, uint32_t min_bc)
 {
@@ -1232,16 +1330,6 @@ constexpr size_t count_lds_bytes()
 //   k_big_resolve  per solid slot and context bit: neighbour in the same table?  (as table_finish pass 2)
 //   k_big_emit     solid slots to the fallback's output buffer through a global cursor, spectrum, counters
 struct BigItem { uint32_t b0, b1; uint64_t tab_off; uint32_t log2s; uint32_t pad; };
-constexpr int BIG_TICKET_CHUNKS = 4;                 // chunks a wave takes per ticket
-
-// item that owns position x of the concatenated chunk / slot space (pre[] ascending, pre[0] = 0, pre[n] = total)
-__device__ __forceinline__ uint32_t big_find(const uint64_t* __restrict__ pre, uint32_t n, uint64_t x)
-{
-    uint32_t lo = 0, hi = n;                         // pre[lo] <= x < pre[hi]
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= x) lo = mid; else hi = mid; }
-    return lo;
-}
-
 template <int K, int NWAVES, int NBC>
 __global__ void __launch_bounds__(NWAVES * 64)
 k_big_insert(const uint4* __restrict__ records, const BigItem* __restrict__ items, const uint64_t* __restrict__ rec_base,
