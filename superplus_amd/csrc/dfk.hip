@@ -895,6 +895,16 @@ int count_split(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& bu
                        (const uint64_t*)P.base.p, (const uint64_t*)d_pre.p, n, (unsigned long long*)d_tk.p, (unsigned long long*)nullptr,
                        (unsigned long long*)cur.p, tot, (uint4*)P2.records.p);
     HIP_TRY(hipGetLastError());
+    {   // every sub-bucket must have received exactly what the counting pass saw for it
+        HIP_TRY(hipMemsetAsync(d_tk.p, 0, 16, c->stream));
+        hipLaunchKernelGGL(k_check_cursors, dim3((unsigned)std::min<uint64_t>((ns + 255) / 256, 4096)), dim3(256), 0, c->stream, (const unsigned long long*)cur.p,
+                           (const uint64_t*)P2.base.p, ns, (unsigned int*)d_tk.p);
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, d_tk.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (bad) return undo(fail(DFK_E_HIP, "hot buckets: %u of %llu sub-buckets did not receive the instances counted for them", bad, (unsigned long long)ns));
+    }
+    TRACE("fallback: %u hot buckets, %llu instances written out as %llu sub-buckets (%llu items)", n, (unsigned long long)tot, (unsigned long long)ns, (unsigned long long)P2.n_items);
     // the sub-buckets as a pass of their own
     started = true;
     c->st.n_items += P2.n_items;

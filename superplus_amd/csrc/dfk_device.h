@@ -112,6 +112,13 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A wave-uniform 64-bit value made scalar.  (__builtin_amdgcn_readfirstlane returns int: widened as it stands, a low
+// word >= 2^31 sign-extends into the high word -- a record index past 2^31 then addresses memory 64 GiB below its
+// block.  Every 64-bit broadcast goes through here.)
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) { return ((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | (uint64_t)uniform32((uint32_t)v); }
+__device__ __forceinline__ uint64_t uniform64(uint32_t lo, uint32_t hi) { return ((uint64_t)uniform32(hi) << 32) | (uint64_t)uniform32(lo); }
+
 // record header (word 0): nk in bits 0-5, has_pred bit 6, has_succ bit 7, fine bucket id in bits 8-31
 __device__ __forceinline__ uint32_t rec_header(uint32_t nk, bool hp, bool hs, uint32_t bucket)
 { return nk | (hp ? 64u : 0u) | (hs ? 128u : 0u) | (bucket << 8); }

@@ -205,8 +205,8 @@ __device__ __forceinline__ void reserve_edge(bool mine, uint64_t bytes, unsigned
     const uint64_t total = __shfl(incl, 63, 64);
     unsigned long long e0 = 0, b0 = 0;
     if (lane == 0) { e0 = atomicAdd(&ctr[0], (unsigned long long)__popcll(mk)); b0 = atomicAdd(&ctr[1], (unsigned long long)total); }
-    e0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(e0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)e0);
-    b0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)b0);
+    e0 = uniform64((uint64_t)e0);
+    b0 = uniform64((uint64_t)b0);
     *edge_no = e0 + __popcll(mk & ((1ull << lane) - 1ull));
     *byte_off = b0 + incl - (mine ? bytes : 0);
 }

@@ -924,7 +924,7 @@ k_hot_split(const uint4* __restrict__ records, const HotItem* __restrict__ items
     for (uint32_t guard = 0; guard < 0x7FFFFFFFu; ++guard) {
         unsigned long long t0 = 0;
         if (lane == 0) t0 = atomicAdd(ticket, (unsigned long long)BIG_TICKET_CHUNKS);
-        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)t0);
+        const uint64_t first = uniform64((uint64_t)t0);
         if (first >= n_chunks) break;
         for (int k = 0; k < BIG_TICKET_CHUNKS; ++k) {
             const uint64_t t = first + k;
@@ -1159,10 +1159,8 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         // rewritten on claim).  cnt, ctxs and the barcode words are contiguous.
         const uint32_t ns = __builtin_amdgcn_readfirstlane(tld(n_solid));
         const uint32_t used = __builtin_amdgcn_readfirstlane(tld(&ctl[CTL_USED]));
-        const unsigned long long cur = (unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OUT_LO])) |
-                                       ((unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OUT_HI])) << 32);
-        const unsigned long long nxt = (unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_NEXT_LO])) |
-                                       ((unsigned long long)__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_NEXT_HI])) << 32);
+        const unsigned long long cur = uniform64(tld(&ctl[CTL_OUT_LO]), tld(&ctl[CTL_OUT_HI]));
+        const unsigned long long nxt = uniform64(tld(&ctl[CTL_NEXT_LO]), tld(&ctl[CTL_NEXT_HI]));
 #ifdef DFK_ABLATE_EMIT
         for (uint32_t i = tid; i < 0 * ns; i += nthreads) {
 #else
@@ -1237,8 +1235,8 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         __syncthreads();                                               // table empty, counters reset, item published
         const uint32_t item = __builtin_amdgcn_readfirstlane(ctl[CTL_ITEM]);
         if (item >= cp.n_items) break;
-        const uint64_t rb = (uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RB_LO]) | ((uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RB_HI]) << 32);
-        const uint64_t re = (uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RE_LO]) | ((uint64_t)__builtin_amdgcn_readfirstlane(ctl[CTL_RE_HI]) << 32);
+        const uint64_t rb = uniform64(ctl[CTL_RB_LO], ctl[CTL_RB_HI]);
+        const uint64_t re = uniform64(ctl[CTL_RE_LO], ctl[CTL_RE_HI]);
         const uint32_t sub = __builtin_amdgcn_readfirstlane(ctl[CTL_SUB]);
         // (thread 0 keeps the prefetched ticket in registers: storing it to LDS here would make its wave wait
         // for the loads at the top of every item -- measured, +1 % on the whole kernel)
@@ -1346,7 +1344,7 @@ k_big_insert(const uint4* __restrict__ records, const BigItem* __restrict__ item
     for (uint32_t guard = 0; guard < 0x7FFFFFFFu; ++guard) {                 // every wave leaves when the tickets run out
         unsigned long long t0 = 0;
         if (lane == 0) t0 = atomicAdd(ticket, (unsigned long long)BIG_TICKET_CHUNKS);
-        const uint64_t first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(t0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)t0);
+        const uint64_t first = uniform64((uint64_t)t0);
         if (first >= n_chunks) break;
         for (int k = 0; k < BIG_TICKET_CHUNKS; ++k) {
             const uint64_t t = first + k;
@@ -1454,7 +1452,7 @@ k_big_emit(const BigItem* __restrict__ items, const uint64_t* __restrict__ slot_
         if (!mk) continue;
         unsigned long long wbase = 0;
         if (lane == 0) wbase = atomicAdd(&g->big_cursor, (unsigned long long)__popcll(mk));
-        wbase = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)wbase);
+        wbase = uniform64((uint64_t)wbase);
         if (!solid) continue;
         const uint32_t S = v.S, slot = v.slot, count = v.count();
         const uint32_t cw = tld(&v.ctxs[slot]);

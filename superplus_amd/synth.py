@@ -63,9 +63,13 @@ def make_genome(size, seed, device="cpu", repeat_frac=0.0, family_copies=0, fami
     if family_copies > 0 and size > 4 * family_len:
         elem = torch.randint(0, 4, (family_len,), generator=g, dtype=torch.uint8, device=dev)
         ar = torch.arange(family_len, device=dev)
+        # (copies sit in distinct family_len-wide slots: overlapping scatter writes have no defined winner on a GPU,
+        # and the same seed must give the same genome in every process)
+        slots = torch.randperm(size // family_len, generator=g, device=dev)[:family_copies] * family_len
+        family_copies = int(slots.numel())
         for a in range(0, family_copies, 1 << 18):              # in slabs: a million copies are 300 M cells
             m = min(1 << 18, family_copies - a)
-            pos = torch.randint(0, size - family_len, (m,), generator=g, device=dev)
+            pos = slots[a : a + m]
             copies = elem[None, :].repeat(m, 1)
             hit = torch.rand(copies.shape, generator=g, device=dev) < family_div
             sub = torch.randint(1, 4, copies.shape, generator=g, dtype=torch.uint8, device=dev)
@@ -76,9 +80,11 @@ def make_genome(size, seed, device="cpu", repeat_frac=0.0, family_copies=0, fami
         span = 200
         n = max(1, int(size * low_complexity_frac / span))
         ar = torch.arange(span, device=dev)
+        slots = torch.randperm(size // span, generator=g, device=dev)[:n] * span      # distinct slots, as above
+        n = int(slots.numel())
         for a in range(0, n, 1 << 18):
             m = min(1 << 18, n - a)
-            pos = torch.randint(0, size - span, (m,), generator=g, device=dev)
+            pos = slots[a : a + m]
             unit_len = torch.randint(1, 7, (m,), generator=g, device=dev)
             unit = torch.randint(0, 4, (m, 6), generator=g, dtype=torch.uint8, device=dev)
             cells = torch.gather(unit, 1, ar[None, :] % unit_len[:, None])
