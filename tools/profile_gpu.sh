@@ -7,7 +7,7 @@ R=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/bench_write.log 2>&1

@@ -44,11 +44,17 @@ for which in ("fetch", "write"):
             ctr[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(dst, f"{R}_hbm_counters.csv"), "w", newline="") as f:
     w = csv.writer(f)
-    w.writerow(["kernel", "launches", "FETCH_SIZE_KiB_mean", "WRITE_SIZE_KiB_mean", "read_bytes_x2_corrected", "write_bytes"])
+    # The guide's x2 on FETCH_SIZE is calibrated for wide coalesced streams (16 B per lane) only.  These kernels read
+    # their bulk that way (one uint4 of a record or entry per lane); for the others (4/8-byte loads, scattered probes,
+    # atomics) the width is uncalibrated: the raw figure is a lower bound and the doubled one an upper bound.
+    WIDE = ("k_count<", "k_hot_split<", "k_big_insert<", "k_boundary_list", "k_fill_holes", "k_digest")
+    w.writerow(["kernel", "launches", "FETCH_SIZE_KiB_mean", "WRITE_SIZE_KiB_mean", "read_bytes_raw", "read_bytes_x2", "x2_correction", "write_bytes"])
     for k, v in ctr.items():
         fs = sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"]))
         ws = sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"]))
-        w.writerow([k, len(v["FETCH_SIZE"]), f"{fs:.1f}", f"{ws:.1f}", int(2 * fs * 1024), int(ws * 1024)])
+        wide = any(t in k for t in WIDE)
+        w.writerow([k, len(v["FETCH_SIZE"]), f"{fs:.1f}", f"{ws:.1f}", int(fs * 1024), int(2 * fs * 1024),
+                    "calibrated: 16 B/lane streaming reads" if wide else "uncalibrated access width: read bytes lie between raw and x2", int(ws * 1024)])
 
 dom = [k for k in ctr if "k_count<" in k][0]
 bench = [l for l in open(os.path.join(src, "bench_trace.log")) if l.startswith("{")]
@@ -64,7 +70,7 @@ json.dump({"round": R, "kernel": dom, "main_launches": main, "avg_ns_per_main_la
            "fetch_size_kib_total": fs_tot, "write_size_kib_total": ws_tot,
            "hbm_bytes_per_launch": int((2 * fs_tot + ws_tot) * 1024 / main),
            "correction": "read bytes = 2 x FETCH_SIZE KiB (gfx950, 16 B/lane coalesced stream); write bytes = WRITE_SIZE KiB",
-           "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+           "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras",
            "bench_line_under_profiler": line or None},
           open(os.path.join(dst, f"{R}_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{R}_kernel_stats.csv")).read())
