@@ -30,6 +30,8 @@ def _reads(genome_mb, copies, seed):
 
 
 def _need_hbm(gb):
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info(0)
     if free < gb * 1e9:
         pytest.skip(f"needs {gb} GB of free HBM")
