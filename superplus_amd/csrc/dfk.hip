@@ -620,6 +620,18 @@ int count_run_end(dfk_ctx* c, CountRun* R)
     CountGlobals hg{};
     HIP_TRY(hipMemcpy(&hg, R->d_g.p, sizeof hg, hipMemcpyDeviceToHost));
     c->st.n_distinct = hg.n_distinct; c->n_boundary = hg.n_boundary;
+#ifdef DFK_PHASE_TIMES
+    {
+        unsigned long long ph[16] = {};
+        (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof ph);
+        unsigned long long tot = 0; for (int i = 0; i < 12; ++i) tot += ph[i];
+        static const char* nm[12] = {"item loop tail (thread 0 publishes)", "barrier: item start", "chunks (stage + insert)", "barrier: chunks done", "finish pass 1 (solidity)", "barrier", "finish pass 2 (adjacency look-ups)", "barrier", "finish pass 3 (emit)", "barrier", "clear + reduce", "drain"};
+        fprintf(stderr, "[dfk] k_count wave cycles by phase (%.3e memtime ticks in all):\n", (double)tot);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "[dfk]   %5.1f %%  %s\n", 100.0 * (double)ph[i] / (double)std::max(1ull, tot), nm[i]);
+        unsigned long long z[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z);
+    }
+#endif
 #ifdef DFK_PROBE_STATS
     {
         unsigned long long ps[4] = {};

@@ -90,16 +90,25 @@ __device__ __forceinline__ uint32_t key_hash(u128 c)
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)   // ((hi:lo) >> sh) low 32, sh in 0..31
 { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
-// wave64 inclusive scan (Hillis-Steele over ds_bpermute shuffles)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+// wave64 inclusive scan on the DPP path: four row_shr steps inside each row of 16 lanes (a source outside the row
+// reads 0), then lane 15 of rows 0 and 2 broadcast into rows 1 and 3, then lane 31 into the upper half.  Six VALU
+// operations of a few cycles each; as six ds_bpermute shuffles the same scan was ~400 cycles of LDS-crossbar latency in
+// the critical path of every staged chunk (twice) and of the finish.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return (uint32_t)x;
 }
+
+// sum over the wave, in every lane (scalar): the scan's last lane
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{ return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63); }
 
 // Lanes of one wave exchanging data through LDS.  The hardware runs a wave's LDS operations in
 // order, so no wait is needed, but the COMPILER must be told that other lanes may have written:

@@ -657,6 +657,18 @@ __device__ __forceinline__ Probe probe_begin(u128 c, uint32_t ctx, int32_t tag, 
 // kernel whatever happens.  Returns false if the probe sequence got too long.
 // (Two keys per lane in flight was tried and was slower.)
 #define DFK_COMPILER_FENCE() asm volatile("" ::: "memory")
+#ifdef DFK_PHASE_TIMES    // experiment only: where a k_count wave's cycles go (s_memtime deltas summed over all waves)
+__device__ unsigned long long g_phase[16];
+struct PhaseClock {
+    unsigned long long t, acc[12];
+    __device__ __forceinline__ void start() { t = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 12; ++i) acc[i] = 0; }
+    __device__ __forceinline__ void mark(int i) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc[i] += n - t; t = n; }
+    __device__ __forceinline__ void flush(int lane) { if (lane == 0) for (int i = 0; i < 12; ++i) atomicAdd(&g_phase[i], acc[i]); }
+};
+#define PH(i) phase.mark(i)
+#else
+#define PH(i) do { } while (0)
+#endif
 #ifdef DFK_PROBE_STATS   // experiment only: [0] loop iterations, [1] batches, [2] lane probes, [3] waits on a locked slot
 __device__ unsigned long long g_probe_stats[4];
 #endif
@@ -855,7 +867,7 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     const uint32_t nk = lane < COUNT_CHUNK ? (st->rec[8 * lane] & 63u) : 0u;
     const uint32_t incl = wave_incl_scan(nk, lane);
     const uint32_t start = incl - nk;
-    const uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (lane < COUNT_CHUNK) st->starts[lane] = start;
     if (nk) atomicOr(&st->msk[start >> 5], 1u << (start & 31u));
     wave_sync();
@@ -877,8 +889,7 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
         ok = table_insert<KTraits<K>::KW, NBC, LDS_TABLE>(keys, cnt, ctxs, bcw, S, A, n_claimed) && ok;
 #endif
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) n_claimed += __shfl_down(n_claimed, d, 64);
+    n_claimed = wave_sum(n_claimed);
     if (lane == 0 && n_claimed) atomicAdd(n_fill, n_claimed);
     if (!ok) atomicOr(overflow, 1u);
     wave_sync();
@@ -942,7 +953,7 @@ k_hot_split(const uint4* __restrict__ records, const HotItem* __restrict__ items
             const uint32_t nk = lane < COUNT_CHUNK ? (st->rec[8 * lane] & 63u) : 0u;
             const uint32_t incl = wave_incl_scan(nk, lane);
             const uint32_t start = incl - nk;
-            const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             if (lane < COUNT_CHUNK) st->starts[lane] = start;
             if (nk) atomicOr(&st->msk[start >> 5], 1u << (start & 31u));
             wave_sync();
@@ -1051,7 +1062,11 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
                                                  uint32_t* ctl, unsigned long long* part_cursor, unsigned int* seg_overflow,
                                                  uint32_t* hist_lds, unsigned long long* __restrict__ hist_global,
                                                  uint32_t* tasks, uint32_t* n_tasks, uint32_t* n_boundary,
-                                                 uint16_t* solid_list, uint32_t* n_solid, int tid, int nthreads)
+                                                 uint16_t* solid_list, uint32_t* n_solid, int tid, int nthreads
+#ifdef DFK_PHASE_TIMES
+                                                 , PhaseClock& phase
+#endif
+                                                 )
 {
     constexpr int KW = KTraits<K>::KW;
     const int lane = tid & 63;
@@ -1074,27 +1089,69 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         else if (!(tld(&bcw[f]) & FLAG_SOLID)) atomicAnd(&ctxs[slot], ~(1u << bit));           // here, and not solid
     };
     auto sync = [&]() { __syncthreads(); };
-    // ---- pass 1
-    for (uint32_t base = 0; base < S; base += nthreads) {
-        const uint32_t slot = base + tid;
-        if (slot >= S) continue;
-        const uint32_t c = tld(&cnt[slot]);
-        if (!c) continue;
-        ++n_occ;
-        const uint32_t count = c & CNT_MASK;                           // saturated at 2^24-1 by the insert (ReadPather.h:128-129)
-        const bool solid = count >= cp.min_freq && bc_pass<(NBC > 0)>(NBC > 0 ? tld(&bcw[slot]) : 0u, cp.min_bc);
-        if (solid) solid_list[atomicAdd(n_solid, 1u)] = (uint16_t)slot;
-        if (solid && cp.do_adj) {
-            const uint32_t ctx = tld(&ctxs[slot]) & 0xFFu;
-            if (cp.keep_pre) tst(&ctxs[slot], ctx | (ctx << 8));
-            const uint32_t nb = __popc(ctx);
-            uint32_t pos = nb ? atomicAdd(n_tasks, nb) : 0u;
-            if (pos + nb <= ADJ_TASKS)
-                for (uint32_t bit = 0; bit < 8; ++bit) if (ctx & (1u << bit)) tasks[pos++] = slot | (bit << 28);
+    // ---- pass 1: every thread takes S / nthreads slots; their state words are read first (independent loads).
+    // Solid slots are few (one slot in twenty), so the work on them is done on dense lanes: the wave reserves room in
+    // the list of solid slots once (wave scan of the lanes' needs, one atomic by the last lane) and writes its slots
+    // there; then the lanes take the wave's own entries back, one each, and queue their adjacency look-ups the same
+    // way (scan of the popcounts, one atomic, a loop over the set bits).  As it was -- per solid slot a returning
+    // atomic on ONE LDS word and an 8-step bit loop at three active lanes -- this pass took 17 % of all wave cycles.
+    {
+        constexpr uint32_t PER = 4;                                     // slots per thread and round
+        for (uint32_t base = 0; base < S; base += PER * nthreads) {
+            uint32_t c[PER], b[PER];
+#pragma unroll
+            for (uint32_t k = 0; k < PER; ++k) {
+                const uint32_t slot = base + k * nthreads + tid;
+                c[k] = slot < S ? tld(&cnt[slot]) : 0u;
+                b[k] = (NBC > 0 && slot < S) ? tld(&bcw[slot]) : 0u;
+            }
+            uint32_t solid_m = 0, need = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < PER; ++k) {
+                const uint32_t count = c[k] & CNT_MASK;                 // saturated at 2^24-1 by the insert (ReadPather.h:128-129)
+                const bool occ = c[k] != 0u;
+                const bool solid = occ && count >= cp.min_freq && bc_pass<(NBC > 0)>(b[k], cp.min_bc);
+                n_occ += occ;
+                if (solid) { solid_m |= 1u << k; ++need; }
+            }
+            const uint32_t incl = wave_incl_scan(need, lane);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t base_s = 0;
+            if (lane == 63 && total) base_s = atomicAdd(n_solid, total);
+            base_s = (uint32_t)__builtin_amdgcn_readlane((int)base_s, 63);
+            uint32_t ps = base_s + incl - need;
+#pragma unroll
+            for (uint32_t k = 0; k < PER; ++k) {
+                const uint32_t slot = base + k * nthreads + tid;
+                if (c[k] == 0u) continue;
+                const bool solid = (solid_m >> k) & 1u;
+                if (solid) solid_list[ps++] = (uint16_t)slot;
+                tst(&bcw[slot], solid ? FLAG_SOLID : 0u);
+            }
+            if (cp.do_adj && total) {
+                wave_sync();                                            // the wave's own list entries, written by other lanes
+                for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    const bool act = i < total;
+                    const uint32_t slot = act ? (uint32_t)solid_list[base_s + i] : 0u;
+                    uint32_t x = act ? (tld(&ctxs[slot]) & 0xFFu) : 0u;
+                    if (cp.keep_pre && act) tst(&ctxs[slot], x | (x << 8));
+                    const uint32_t nb = __popc(x);
+                    const uint32_t incl2 = wave_incl_scan(nb, lane);
+                    const uint32_t tot2 = (uint32_t)__builtin_amdgcn_readlane((int)incl2, 63);
+                    uint32_t base_t = 0;
+                    if (lane == 63 && tot2) base_t = atomicAdd(n_tasks, tot2);
+                    base_t = (uint32_t)__builtin_amdgcn_readlane((int)base_t, 63);
+                    uint32_t pt = base_t + incl2 - nb;
+                    if (pt + nb <= ADJ_TASKS)
+                        while (x) { const uint32_t bit = (uint32_t)__builtin_ctz(x); tasks[pt++] = slot | (bit << 28); x &= x - 1u; }
+                }
+            }
         }
-        tst(&bcw[slot], solid ? FLAG_SOLID : 0u);
     }
+    PH(4);
     sync();
+    PH(5);
     // ---- room for this item's solid k-mers: the rest of the workgroup's chunk, and a fresh one if that is not enough
     constexpr uint32_t OUT_CHUNK = 4 * ADJ_TASKS;                      // = 2 S entries: more than a table can emit
     if (tid == 0) {
@@ -1113,7 +1170,9 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         const uint32_t total = __builtin_amdgcn_readfirstlane(tld(n_tasks));
         if (total <= ADJ_TASKS) {
             for (uint32_t t = tid; t < total; t += nthreads) resolve(tasks[t]);
+            PH(6);
             sync();
+            PH(7);
         } else {
             // more look-ups than the queue holds (a table full of solid k-mers): redo the queueing in slot
             // ranges that cannot overflow it (<= 8 look-ups per slot)
@@ -1170,7 +1229,9 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
             const uint32_t pos = used + i;
             emit(slot, tld(&cnt[slot]), tld(&bcw[slot]), pos < OUT_CHUNK ? cur + pos : nxt + (pos - OUT_CHUNK));
         }
+        PH(8);
         __syncthreads();
+        PH(9);
         if (tid == 0) {
             if (used + ns > OUT_CHUNK) { tst(&ctl[CTL_OUT_LO], (uint32_t)nxt); tst(&ctl[CTL_OUT_HI], (uint32_t)(nxt >> 32)); tst(&ctl[CTL_USED], used + ns - OUT_CHUNK); }
             else tst(&ctl[CTL_USED], used + ns);
@@ -1179,9 +1240,9 @@ __device__ __forceinline__ uint32_t table_finish(uint32_t* keys, uint32_t* cnt, 
         uint4* z = reinterpret_cast<uint4*>(cnt);
         for (uint32_t i = tid; i < (3 + (NBC > 1 ? NBC - 1 : 0)) * S / 4; i += nthreads) z[i] = uint4{0, 0, 0, 0};
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) boundary += __shfl_down(boundary, d, 64);
+    boundary = wave_sum(boundary);
     if (lane == 0 && boundary) atomicAdd(n_boundary, boundary);
+    PH(10);
     return n_occ;
 }
 
@@ -1231,8 +1292,13 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         ctl[CTL_RE_LO] = (uint32_t)e0; ctl[CTL_RE_HI] = (uint32_t)(e0 >> 32);
         ctl[CTL_B0] = r0.b0; ctl[CTL_B1] = r0.b1; ctl[CTL_SUB] = s0;
     }
+#ifdef DFK_PHASE_TIMES
+    PhaseClock phase; phase.start();
+#endif
     for (;;) {
+        PH(0);
         __syncthreads();                                               // table empty, counters reset, item published
+        PH(1);
         const uint32_t item = __builtin_amdgcn_readfirstlane(ctl[CTL_ITEM]);
         if (item >= cp.n_items) break;
         const uint64_t rb = uniform64(ctl[CTL_RB_LO], ctl[CTL_RB_HI]);
@@ -1247,18 +1313,22 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         }
         // Waves pull chunks of the item from an LDS ticket.  All loop control is made scalar
         // (readfirstlane) so the compiler emits uniform branches, and the trip count is bounded.
-        const uint32_t n_chunks = (uint32_t)((re - rb + COUNT_CHUNK - 1) / COUNT_CHUNK);
-        for (uint32_t guard = 0; guard < n_chunks; ++guard) {
-            uint32_t ci = 0;
-            if (lane == 0) ci = atomicAdd(&ctl[CTL_CHUNK], 1u);
-            ci = __builtin_amdgcn_readfirstlane(ci);
-            if (ci >= n_chunks) break;
+        // The item's records are dealt to the waves in equal consecutive shares, worked off in pieces of COUNT_CHUNK.
+        // (They used to be pulled as 32-record chunks from an LDS ticket: an item is 7-9 such chunks, so one wave of the
+        // eight often took a second chunk while seven waited at the barrier below -- 22 % of all wave cycles.)
+        const uint32_t n_rec = (uint32_t)(re - rb);
+        const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
+        const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)wave);       // (scalar loop control)
+        const uint32_t w_lo = min(n_rec, wv * share), w_hi = min(n_rec, w_lo + share);
+        for (uint32_t at = w_lo; at < w_hi; at += COUNT_CHUNK) {
             if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
-            wave_count_chunk<K, NBC, true, SUB>(records, rb + (uint64_t)ci * COUNT_CHUNK, re, st, lane, keys, cnt, ctxs, bcw, S,
+            wave_count_chunk<K, NBC, true, SUB>(records, rb + at, rb + w_hi, st, lane, keys, cnt, ctxs, bcw, S,
                                              &ctl[CTL_FILL], &ctl[CTL_OVF], sub);
             if (lane == 0 && tld(&ctl[CTL_FILL]) > (S / 4) * 3) tst(&ctl[CTL_OVF], 1u);   // stop when 3/4 full
         }
+        PH(2);
         __syncthreads();
+        PH(3);
         if (__builtin_amdgcn_readfirstlane(ctl[CTL_OVF])) {
             if (tid == 0) {
                 const uint32_t b0 = ctl[CTL_B0], b1 = ctl[CTL_B1];
@@ -1284,9 +1354,12 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
 #endif
             table_finish<K, NBC, S / 2>(keys, cnt, ctxs, bcw, S, cp, seg_out, ctl, &g->part_cursor,
                                                          &g->solid_overflow, hist, hist_global, tasks, &ctl[CTL_NTASK],
-                                                         &ctl[CTL_BOUNDARY], solid_list, &ctl[CTL_NSOLID], tid, NT);
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d, 64);
+                                                         &ctl[CTL_BOUNDARY], solid_list, &ctl[CTL_NSOLID], tid, NT
+#ifdef DFK_PHASE_TIMES
+                                                         , phase
+#endif
+                                                         );
+            occ = wave_sum(occ);
             if (lane == 0 && occ) atomicAdd(&ctl[CTL_DISTINCT], occ);
         }
         if (tid == 0) {                                                // publish the next item (stack first), reset the per-item words
@@ -1304,6 +1377,9 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         }
     }
     __syncthreads();
+#ifdef DFK_PHASE_TIMES
+    PH(11); phase.flush(lane);
+#endif
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) if (hist[i]) atomicAdd(&hist_global[i], (unsigned long long)hist[i]);
     if (tid == 0) {
         wg_out[blockIdx.x] = WgOut{(unsigned long long)ctl[CTL_OUT_LO] | ((unsigned long long)ctl[CTL_OUT_HI] << 32), ctl[CTL_USED], 0u};

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_slice
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -- python3 bench.py --genome-mb 100 --pairs 15000000 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -- python3 bench.py --genome-mb 100 --pairs 15000000 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = max(glob.glob('gpurun_out/pmc_slice/*/*_counter_collection.csv'), key=lambda p: __import__('os').path.getmtime(p))
