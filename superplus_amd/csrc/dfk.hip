@@ -1379,8 +1379,10 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
         if (c->plan_derate * fit < left && overlap) {
             fit = room > fixed ? (room - fixed) / (2.0 * per_in + per_seg + per_out) : 0.0;
             // the very first scatter has nothing to hide under: keep it short (its fixed cost, reading every
-            // summary, is paid anyway; a sixteenth of the buckets adds about as much again)
-            if (lo == 0) fit = std::min(fit, (double)sub_nb / 16.0 / c->plan_derate);
+            // summary, is paid anyway; a tenth of the buckets -- a sixteenth while k_count ran at 75 G instances/s
+            // and a range could grow by 1.3 from pass to pass -- measured: DFK_PLAN_FIRST / DFK_PLAN_GROWTH, tools/plan_sweep.sh)
+            static const double first_div = getenv("DFK_PLAN_FIRST") ? atof(getenv("DFK_PLAN_FIRST")) : 10.0;
+            if (lo == 0) fit = std::min(fit, (double)sub_nb / first_div / c->plan_derate);
         }
     } else {
         const double now = room - fixed;                              // (the running pass's part is reserved already)
@@ -1400,9 +1402,12 @@ uint32_t plan_range(const dfk_ctx* c, const BucketTable& T, const CountRun& R, u
         fit = std::min(fit, std::max(0.0, room + (double)running->bytes_held - fixed) / (2.0 * (per_in + per_seg) + (per_out - per_seg)));
     }
     double n = c->plan_derate * fit;
-    // the range is scattered while the running pass is counted: no larger than what that count hides (a sweep
-    // moves a range's records about 1.5 times as fast as k_count counts them, after ~10 ms of reading masks)
-    if (running && overlap) n = std::min(n, 1.3 * (double)running->n_buckets);
+    // the range is scattered while the running pass is counted: no larger than what that count hides (beside
+    // k_count a sweep moves a range's records about 1.15 times as fast as k_count counts them -- 8.3 ms against 9.6 ms
+    // per percent of the human-scale set's buckets -- after ~10 ms of reading masks; with 1.3, the value from when
+    // k_count ran at 75 G instances/s, the first three counts each waited 13-18 ms for the records of the next)
+    static const double growth = getenv("DFK_PLAN_GROWTH") ? atof(getenv("DFK_PLAN_GROWTH")) : 1.1;
+    if (running && overlap) n = std::min(n, growth * (double)running->n_buckets);
     if (left <= 0.99 * fit && left < 1.06 * n) n = left;              // no sliver of a last pass if the rest (almost certainly) fits
     else if (left > n && left < 1.3 * n) n = 0.5 * left + 1.0;        // two even passes rather than a big one and a sliver (1.7 while the cliff of section 9 was unexplained: a big count beside a small sweep)
     n = std::min(n, left);
