@@ -355,8 +355,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     st = None
+    each = []                                  # (dfk_count_device returns when the step is done: host clock per step)
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         st = step()
+        each.append(round(1e3 * (time.perf_counter() - t1), 1))
     barrier()
     elapsed = time.perf_counter() - t0
     n_inst = st["n_inst"]
@@ -406,6 +409,7 @@ def main():
                        "reads_total": 2 * total_pairs, "kmer_instances_total": n_inst, "K": args.K,
                        "parallelism": "single GPU, bucket-range passes" if world == 1 else
                                       f"{world} ranks: read shards, all-to-all of super-k-mer records by minimizer bucket"},
+            "step_ms_each_rank0": each,
             "step_wall_s": elapsed / args.steps,      # one pass of the hot path, inputs resident in HBM (NOT the DF stage's wall-clock: see df_stage)
             **({"rehearsal": f"rank 0 of {args.emulate_world} against replicas of itself; per-rank time without the transfers"}
                if args.emulate_world > 1 else {}),

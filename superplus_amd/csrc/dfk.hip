@@ -1453,16 +1453,17 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     Job cur, nxt;
     auto drop_events = [&](Job& j) { if (j.sj.e0) { (void)hipEventDestroy(j.sj.e0); (void)hipEventDestroy(j.sj.e1); j.sj.e0 = j.sj.e1 = nullptr; } };
     // start the scatter of [lo, lo + n) on the second stream; NOMEM leaves nothing behind
-    // A range that is scattered beside a running count normally starts AHEAD of it (a sweep that starts after the
-    // persistent workgroups have filled the CUs runs 30 % longer, and for the large ranges of the first passes it would
-    // outlast the count).  For a SMALL range that order is the 2.5x cliff of DESIGN.md section 9: k_count launched into
-    // a chip full of short-lived sweep blocks (4 KB of LDS each) gets its 71-KB workgroups placed between them, and a
-    // workgroup that lands in the middle of a CU's 160 KB leaves no contiguous 71 KB for the second one as long as it
-    // lives -- it is persistent, so for the whole launch: half the workgroups, 30 G instead of 74 G instances/s, also
-    // after the sweep has ended (timeline: profiles/r02_cliff_timeline.txt; with the kernels serialised under --pmc
-    // every pass runs at the same 0.254 cycles per instance).  A small range's sweep is short, so it is launched
-    // BEHIND k_count instead: into what k_count leaves free.
-    static const double defer_below = getenv("DFK_DEFER_SWEEP_BELOW") ? atof(getenv("DFK_DEFER_SWEEP_BELOW")) : 0.045;
+    // A range that is scattered beside a running count is launched BEHIND that count's k_count, into what k_count
+    // leaves free.  The other order is the 2.5x cliff of DESIGN.md section 9: k_count launched into a chip on which
+    // short-lived sweep blocks (4 KB of LDS each) are already resident gets its 71-KB workgroups placed between them,
+    // and a workgroup that lands in the middle of a CU's 160 KB leaves no contiguous 71 KB for the second one as long
+    // as it lives -- it is persistent, so for the whole launch: half the workgroups on that CU, also after the sweep
+    // has ended (timeline: profiles/r02_cliff_timeline.txt; with the kernels serialised under --pmc every pass runs at
+    // the same 0.254 cycles per instance).  It was first seen on small ranges, whose predecessor's sweep was still
+    // running; with the sweep launched microseconds ahead of k_count it is a race that large ranges lose too, now
+    // and then (one step in four under a kernel trace, whose launch overhead gives the sweep a head start: pass 3 at
+    // 272 ms instead of 116).  Behind k_count a sweep runs a few percent longer: 4 ms per step (tools/defer_test.sh).
+    static const double defer_below = getenv("DFK_DEFER_SWEEP_BELOW") ? atof(getenv("DFK_DEFER_SWEEP_BELOW")) : 1.0;
     auto start = [&](Job& j, uint32_t lo, uint32_t n, bool may_defer = false) -> int {
         j.sj = ScatterJob{}; j.mark = c->alloc_seq; j.valid = false;
         const bool defer = may_defer && (double)n < defer_below * (double)sub_nb;
