@@ -216,15 +216,26 @@ def df_stage_wall(args, dev, local):
         torch.cuda.synchronize(); torch.cuda.empty_cache()
         cmd = [os.path.join(ROOT, "superplus_amd", "DF"), f"ROOT={root}", f"LR={root}/reads.fastb", "PIPELINE=cs", "ALIGN=False",
                f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}", "GRAPH=False"]   # (ingest + count)
+        env = dict(os.environ, DFK_HOST_THREADS=str(min(args.df_threads, 16)))
+        if args.df_gpus > 1 or args.df_transport:
+            # the C++ multi-GPU host (df_shard.h): DF forks one rank per GPU and moves the records over RCCL itself;
+            # `loopback` runs the ranks as threads on ONE GPU (the rehearsal a one-GPU box allows)
+            cmd.append(f"NUM_GPUS={max(1, args.df_gpus)}")
+            if args.df_transport == "loopback": env["DF_TRANSPORT"] = "loopback"
+            elif args.df_gpus <= 1: env["DF_FORCE_SHARDED"] = "1"
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, DFK_HOST_THREADS=str(min(args.df_threads, 16))))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": f"DF exited {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
         timing = {}
         for line in r.stdout.splitlines():
             if line.startswith("DF_TIMING "):
-                timing = json.loads(line[len("DF_TIMING "):])
+                o = json.loads(line[len("DF_TIMING "):])
+                if "rank0" in o:                     # the C++ sharded host: rank 0's phases, beside the parent's line
+                    timing["shard"] = dict(o["rank0"], ranks=o.get("ranks"))
+                    for k in ("kmer_instances", "solid"): timing.setdefault(k, o.get(k))
+                else: timing.update(o)
         w = root + "/GapToy/1"
         out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(w) for f in fs)
         full = pairs == 900_000_000 and Gd == 3_100_000_000
@@ -237,6 +248,8 @@ def df_stage_wall(args, dev, local):
                 "kmers_per_s_whole_stage": (timing.get("kmer_instances", 0) / wall) if wall > 0 else None,
                 "breakdown_s": {k: timing.get(k) for k in ("open_validate_s", "ingest_outputs_s", "upload_s", "count_s",
                                                            "spectrum_kvec_write_s", "total_s")},
+                "host": ("C++ sharded host, %d rank(s), transport %s" % (max(1, args.df_gpus), args.df_transport or "rccl")) if (args.df_gpus > 1 or args.df_transport) else "single GPU (dfk_count)",
+                "shard_times_s": timing.get("shard"),
                 "input_bytes": in_bytes, "output_bytes": out_bytes, "files_on": root, "host_threads": args.df_threads,
                 "solid": timing.get("solid"), "kmer_instances": timing.get("kmer_instances"),
                 "input_files_written_in_s": round(t_files, 2)}
@@ -271,6 +284,9 @@ def main():
                          "inputs + outputs of the full 900 M-pair set (~300 GB) exceed the box's 270 GiB host memory cap")
     ap.add_argument("--df-dir", default="/dev/shm", help="where the DF leg's files go")
     ap.add_argument("--df-threads", type=int, default=16, help="NUM_THREADS of the DF leg (the box's CPU share for one GPU)")
+    ap.add_argument("--df-gpus", type=int, default=1, help="DF leg: NUM_GPUS of the C++ multi-GPU host (DF forks one rank per GPU, RCCL directly)")
+    ap.add_argument("--df-transport", default="", choices=["", "rccl", "loopback"],
+                    help="DF leg: run the C++ sharded host even with one rank (rccl), or all ranks as threads on one GPU (loopback)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (torch.distributed + DistDfk) even with one rank: a check of that path on one GPU")
     ap.add_argument("--backend", default="nccl",
