@@ -891,9 +891,11 @@ int count_split(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& bu
     HIP_TRY(hipMemsetAsync(acc.p, 0, 8ull * ns, c->stream));
     const unsigned cus = (unsigned)c->prop.multiProcessorCount;
     const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + NW * BIG_TICKET_CHUNKS - 1) / (NW * BIG_TICKET_CHUNKS), 8ull * cus));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hot_split<K, NW, false>), dim3(grid), dim3(NW * 64), 0, c->stream, (const uint4*)P.records.p, (const HotItem*)d_items.p,
-                       (const uint64_t*)P.base.p, (const uint64_t*)d_pre.p, n, (unsigned long long*)d_tk.p, (unsigned long long*)acc.p,
-                       (unsigned long long*)nullptr, (uint64_t)0, (uint4*)nullptr);
+    {   // counting pass: sub-bucket counters in LDS, HOT_BLOCK chunks per workgroup ticket
+        const unsigned gc = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + HOT_BLOCK - 1) / HOT_BLOCK, 2ull * cus));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hot_count<K, NW>), dim3(gc), dim3(NW * 64), 0, c->stream, (const uint4*)P.records.p, (const HotItem*)d_items.p,
+                           (const uint64_t*)P.base.p, (const uint64_t*)d_pre.p, n, (unsigned long long*)d_tk.p, (unsigned long long*)acc.p);
+    }
     HIP_TRY(hipGetLastError());
     Partition P2;
     rc = pass_tables(c, acc, 0, 1, 0, (uint32_t)ns, item_budget<K>(c), &P2); if (rc) return undo(rc);

@@ -846,17 +846,13 @@ __device__ __forceinline__ Probe make_probe(const InstRegs& in, uint32_t S, bool
     return probe_begin(c, ctx, (int32_t)in.tag, S, active);
 }
 
-// Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
-// block barriers).  Lanes load half a record each (1 KiB per wave, coalesced).
-template <int K, int NBC, bool LDS_TABLE, bool SUB = false>
-__device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
-                                                 WaveStage<K>* __restrict__ st, int lane,
-                                                 uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
-                                                 uint32_t S, uint32_t* n_fill, uint32_t* overflow, uint32_t sub = 0)
+// Stage records [rb, min(rb+COUNT_CHUNK, re)) in the calling wave's LDS area and index their instances: a bit at each
+// record's first instance index, popcount prefixes of the mask words (fetch_instance finds instance t's record by rank).
+// Returns the number of instances staged (wave-uniform).  Lanes load half a record each (1 KiB per wave, coalesced).
+template <int K>
+__device__ __forceinline__ uint32_t wave_stage_piece(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
+                                                     WaveStage<K>* __restrict__ st, int lane)
 {
-    // sub != 0: one of 2^(sub >> 8) sub-passes over a fine bucket too rich for one table -- only the k-mers whose
-    // selector (a mix of the key words, 8 bits) equals sub & 0xFF are counted in this one
-    const uint32_t sel_mask = (1u << (sub >> 8)) - 1u, sel = sub & 0xFFu;
     static_assert(COUNT_CHUNK == 32, "one uint4 per lane");
     const uint64_t hidx = 2 * rb + lane;
     uint4 v{0, 0, 0, 0};
@@ -874,6 +870,21 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     const uint32_t c0 = __popc(tld(&st->msk[lane]));
     st->pc[lane] = wave_incl_scan(c0, lane) - c0;
     wave_sync();
+    return total;
+}
+
+// Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
+// block barriers).
+template <int K, int NBC, bool LDS_TABLE, bool SUB = false>
+__device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
+                                                 WaveStage<K>* __restrict__ st, int lane,
+                                                 uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
+                                                 uint32_t S, uint32_t* n_fill, uint32_t* overflow, uint32_t sub = 0)
+{
+    // sub != 0: one of 2^(sub >> 8) sub-passes over a fine bucket too rich for one table -- only the k-mers whose
+    // selector (a mix of the key words, 8 bits) equals sub & 0xFF are counted in this one
+    const uint32_t sel_mask = (1u << (sub >> 8)) - 1u, sel = sub & 0xFFu;
+    const uint32_t total = wave_stage_piece<K>(records, rb, re, st, lane);
     bool ok = true;
     uint32_t n_claimed = 0;
     const uint32_t total_u = __builtin_amdgcn_readfirstlane(total);     // scalar loop control
@@ -989,6 +1000,69 @@ k_hot_split(const uint4* __restrict__ records, const HotItem* __restrict__ items
                 }
             }
             wave_sync();
+        }
+    }
+}
+
+// The counting pass of the second-level partition, with the sub-bucket counters of the hot bucket being read kept in
+// LDS: a workgroup takes HOT_BLOCK consecutive chunks (almost always of one hot bucket: a bucket with 10^6 instances
+// is 2400 chunks), counts their instances per sub-bucket with LDS atomics and adds the non-zero counters to the global
+// ones when it moves on -- 2^p global atomics per 50 000 instances instead of one per instance (the per-instance
+// version ran at the rate of scattered HBM atomics, 20 G instances/s: 1.3 s of a repeat-rich human-scale step).
+// Buckets with more than 2^HOT_LDS_LOG2 sub-buckets (a minimizer owning 10^7 distinct k-mers) keep the global atomics.
+constexpr int HOT_BLOCK = 128;                       // chunks per workgroup ticket
+constexpr uint32_t HOT_LDS_LOG2 = 14;                // sub-bucket counters a workgroup keeps in LDS (64 KB)
+template <int K, int NWAVES>
+__global__ void __launch_bounds__(NWAVES * 64)
+k_hot_count(const uint4* __restrict__ records, const HotItem* __restrict__ items, const uint64_t* __restrict__ rec_base,
+            const uint64_t* __restrict__ chunk_pre, uint32_t n_items, unsigned long long* __restrict__ ticket,
+            unsigned long long* __restrict__ sub_acc)
+{
+    __shared__ WaveStage<K> stages[NWAVES];
+    __shared__ uint32_t hist[1u << HOT_LDS_LOG2];
+    __shared__ unsigned long long blk_first;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WaveStage<K>* st = &stages[wave];
+    const uint64_t n_chunks = chunk_pre[n_items];
+    for (uint32_t guard = 0; guard < 0x7FFFFFFFu; ++guard) {
+        __syncthreads();                                               // (blk_first of the round before has been read)
+        if (tid == 0) blk_first = atomicAdd(ticket, (unsigned long long)HOT_BLOCK);
+        __syncthreads();
+        const uint64_t first = uniform64((uint64_t)blk_first);
+        if (first >= n_chunks) break;
+        const uint64_t last = min(first + (uint64_t)HOT_BLOCK, n_chunks);
+        uint64_t t = first;
+        while (t < last) {                                             // one segment per hot bucket touched (uniform)
+            const uint32_t it = big_find(chunk_pre, n_items, t);
+            const HotItem I = items[it];
+            const uint64_t c0 = chunk_pre[it], seg_end = min(last, chunk_pre[it + 1]);
+            const uint64_t rb0 = rec_base[I.b0], re = rec_base[I.b1];
+            const bool in_lds = I.log2p <= HOT_LDS_LOG2;
+            const uint32_t n_sub = 1u << I.log2p;
+            if (in_lds) { for (uint32_t i = tid; i < n_sub; i += NWAVES * 64) hist[i] = 0; __syncthreads(); }
+            for (uint64_t c = t + wave; c < seg_end; c += NWAVES) {
+                const uint64_t rb = rb0 + (c - c0) * COUNT_CHUNK;
+                const uint32_t total = wave_stage_piece<K>(records, rb, re, st, lane);
+                for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    if (i < total) {
+                        const Probe A = make_probe<K>(fetch_instance<K>(st, i), 2u, true);
+                        const uint32_t sub = I.log2p ? sub_bucket_hash(A) >> (32u - I.log2p) : 0u;
+                        if (in_lds) atomicAdd(&hist[sub], 1u);
+                        else atomicAdd(&sub_acc[I.sub_base + sub], (1ull << 32) | 1ull);
+                    }
+                }
+                wave_sync();
+            }
+            if (in_lds) {
+                __syncthreads();
+                for (uint32_t i = tid; i < n_sub; i += NWAVES * 64) {
+                    const uint32_t h = hist[i];
+                    if (h) atomicAdd(&sub_acc[I.sub_base + i], ((unsigned long long)h << 32) | h);
+                }
+                __syncthreads();
+            }
+            t = seg_end;
         }
     }
 }

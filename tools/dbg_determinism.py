@@ -34,7 +34,7 @@ elif oracle:
         pr = subprocess.Popen(["oracle/_ref/refdrv", "dict", "48", d + "/s", d + "/o", "7", "3", "2", "1", str(min(32, os.cpu_count()))], stdout=subprocess.DEVNULL)
         while pr.poll() is None:
             time.sleep(30); print(f"  (oracle running, {time.time() - t0:.0f} s)", flush=True)
-        assert pr.returncode == 0
+        assert pr.returncode == 0, f"refdrv exited {pr.returncode}"
         truth = np.fromfile(d + "/o/solid.bin", ENTRY_DTYPE)
     np.save(CACHE, truth)
     print(f"oracle: {len(truth)} solid, digest {digest_of(truth)}, {time.time() - t0:.0f} s", flush=True)
