@@ -890,12 +890,11 @@ int count_split(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& bu
     HIP_TRY(hipMemsetAsync(d_tk.p, 0, 16, c->stream));
     HIP_TRY(hipMemsetAsync(acc.p, 0, 8ull * ns, c->stream));
     const unsigned cus = (unsigned)c->prop.multiProcessorCount;
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + NW * BIG_TICKET_CHUNKS - 1) / (NW * BIG_TICKET_CHUNKS), 8ull * cus));
-    {   // counting pass: sub-bucket counters in LDS, HOT_BLOCK chunks per workgroup ticket
-        const unsigned gc = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + HOT_BLOCK - 1) / HOT_BLOCK, 2ull * cus));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hot_count<K, NW>), dim3(gc), dim3(NW * 64), 0, c->stream, (const uint4*)P.records.p, (const HotItem*)d_items.p,
-                           (const uint64_t*)P.base.p, (const uint64_t*)d_pre.p, n, (unsigned long long*)d_tk.p, (unsigned long long*)acc.p);
-    }
+    // counting pass (sub-bucket counters in LDS, HOT_BLOCK chunks per workgroup ticket)
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((chunk_pre[n] + HOT_BLOCK - 1) / HOT_BLOCK, 2ull * cus));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hot_pass<K, NW, false>), dim3(grid), dim3(NW * 64), 0, c->stream, (const uint4*)P.records.p, (const HotItem*)d_items.p,
+                       (const uint64_t*)P.base.p, (const uint64_t*)d_pre.p, n, (unsigned long long*)d_tk.p, (unsigned long long*)acc.p,
+                       (unsigned long long*)nullptr, (const uint64_t*)nullptr, (uint64_t)0, (uint4*)nullptr);
     HIP_TRY(hipGetLastError());
     Partition P2;
     rc = pass_tables(c, acc, 0, 1, 0, (uint32_t)ns, item_budget<K>(c), &P2); if (rc) return undo(rc);
@@ -905,9 +904,9 @@ int count_split(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& bu
     rc = c->alloc(P2.records, 32ull * tot, "hot buckets' k-mer records"); if (rc) return undo(rc);
     HIP_TRY(hipMemcpyAsync(cur.p, P2.base.p, 8ull * ns, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_tk.p, 0, 16, c->stream));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hot_split<K, NW, true>), dim3(grid), dim3(NW * 64), 0, c->stream, (const uint4*)P.records.p, (const HotItem*)d_items.p,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_hot_pass<K, NW, true>), dim3(grid), dim3(NW * 64), 0, c->stream, (const uint4*)P.records.p, (const HotItem*)d_items.p,
                        (const uint64_t*)P.base.p, (const uint64_t*)d_pre.p, n, (unsigned long long*)d_tk.p, (unsigned long long*)nullptr,
-                       (unsigned long long*)cur.p, tot, (uint4*)P2.records.p);
+                       (unsigned long long*)cur.p, (const uint64_t*)P2.base.p, tot, (uint4*)P2.records.p);
     HIP_TRY(hipGetLastError());
     {   // every sub-bucket must have received exactly what the counting pass saw for it
         HIP_TRY(hipMemsetAsync(d_tk.p, 0, 16, c->stream));

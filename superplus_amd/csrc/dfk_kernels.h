@@ -931,93 +931,47 @@ __device__ __forceinline__ uint32_t sub_bucket_hash(const Probe& A)
     return h;
 }
 
-template <int K, int NWAVES, bool WRITE>
-__global__ void __launch_bounds__(NWAVES * 64)
-k_hot_split(const uint4* __restrict__ records, const HotItem* __restrict__ items, const uint64_t* __restrict__ rec_base,
-            const uint64_t* __restrict__ chunk_pre, uint32_t n_items, unsigned long long* __restrict__ ticket,
-            unsigned long long* __restrict__ sub_acc,          // !WRITE: per sub-bucket records << 32 | instances (one each per instance)
-            unsigned long long* __restrict__ sub_cur,          // WRITE: per sub-bucket append cursor, starts at its first record
-            uint64_t n_out, uint4* __restrict__ out)
+// one instance written out as a record of its own (the 32-byte format: nk = 1, its own predecessor / successor flags)
+template <int K>
+__device__ __forceinline__ void hot_write_record(const InstRegs& in, uint32_t sub, uint64_t dst, uint4* __restrict__ out)
 {
-    __shared__ WaveStage<K> stages[NWAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    WaveStage<K>* st = &stages[wave];
-    const uint64_t n_chunks = chunk_pre[n_items];
-    for (uint32_t guard = 0; guard < 0x7FFFFFFFu; ++guard) {
-        unsigned long long t0 = 0;
-        if (lane == 0) t0 = atomicAdd(ticket, (unsigned long long)BIG_TICKET_CHUNKS);
-        const uint64_t first = uniform64((uint64_t)t0);
-        if (first >= n_chunks) break;
-        for (int k = 0; k < BIG_TICKET_CHUNKS; ++k) {
-            const uint64_t t = first + k;
-            if (t >= n_chunks) break;
-            const uint32_t it = big_find(chunk_pre, n_items, t);
-            const HotItem I = items[it];
-            const uint64_t rb = rec_base[I.b0] + (t - chunk_pre[it]) * COUNT_CHUNK, re = rec_base[I.b1];
-            // stage the chunk and map its instances onto lanes (as wave_count_chunk does)
-            const uint64_t hidx = 2 * rb + lane;
-            uint4 v{0, 0, 0, 0};
-            if (hidx < 2 * re) v = records[hidx];
-            reinterpret_cast<uint4*>(st->rec)[lane] = v;
-            st->msk[lane] = 0;
-            wave_sync();
-            const uint32_t nk = lane < COUNT_CHUNK ? (st->rec[8 * lane] & 63u) : 0u;
-            const uint32_t incl = wave_incl_scan(nk, lane);
-            const uint32_t start = incl - nk;
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (lane < COUNT_CHUNK) st->starts[lane] = start;
-            if (nk) atomicOr(&st->msk[start >> 5], 1u << (start & 31u));
-            wave_sync();
-            const uint32_t c0 = __popc(tld(&st->msk[lane]));
-            st->pc[lane] = wave_incl_scan(c0, lane) - c0;
-            wave_sync();
-            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                if (i < total) {
-                    const InstRegs in = fetch_instance<K>(st, i);
-                    const Probe A = make_probe<K>(in, 2u, true);
-                    const uint32_t sub = I.sub_base + (I.log2p ? sub_bucket_hash(A) >> (32u - I.log2p) : 0u);
-                    if (!WRITE) atomicAdd(&sub_acc[sub], (1ull << 32) | 1ull);
-                    else {
-                        const uint64_t dst = atomicAdd(&sub_cur[sub], 1ull);
-                        if (dst < n_out) {
-                            // the instance's own stream: predecessor slot, K bases, successor slot
-                            const uint32_t q = in.q, sh = (2u * q) & 31u, rnk = in.hdr & 63u;
-                            const bool hp = q > 0 || (in.hdr & 64u), hs = q + 1 < rnk || (in.hdr & 128u);
-                            uint32_t o[4] = {alignbit(in.p1, in.p0, sh), alignbit(in.p2, in.p1, sh), alignbit(in.p3, in.p2, sh), alignbit(in.p4, in.p3, sh)};
-                            const uint32_t nbits = 2u * (1u + (uint32_t)K + (hs ? 1u : 0u));      // <= 124
+    const uint32_t q = in.q, sh = (2u * q) & 31u, rnk = in.hdr & 63u;
+    const bool hp = q > 0 || (in.hdr & 64u), hs = q + 1 < rnk || (in.hdr & 128u);
+    uint32_t o[4] = {alignbit(in.p1, in.p0, sh), alignbit(in.p2, in.p1, sh), alignbit(in.p3, in.p2, sh), alignbit(in.p4, in.p3, sh)};
+    const uint32_t nbits = 2u * (1u + (uint32_t)K + (hs ? 1u : 0u));      // <= 124
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                const uint32_t lo = 32u * w;
-                                if (nbits <= lo) o[w] = 0;
-                                else if (nbits < lo + 32u) o[w] &= (1u << (nbits - lo)) - 1u;
-                            }
-                            if (!hp) o[0] &= ~3u;
-                            out[2 * dst] = uint4{rec_header(1u, hp, hs, sub), in.tag, o[0], o[1]};
-                            out[2 * dst + 1] = uint4{o[2], o[3], 0u, 0u};
-                        }
-                    }
-                }
-            }
-            wave_sync();
-        }
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t lo = 32u * w;
+        if (nbits <= lo) o[w] = 0;
+        else if (nbits < lo + 32u) o[w] &= (1u << (nbits - lo)) - 1u;
     }
+    if (!hp) o[0] &= ~3u;
+    out[2 * dst] = uint4{rec_header(1u, hp, hs, sub), in.tag, o[0], o[1]};
+    out[2 * dst + 1] = uint4{o[2], o[3], 0u, 0u};
 }
 
-// The counting pass of the second-level partition, with the sub-bucket counters of the hot bucket being read kept in
-// LDS: a workgroup takes HOT_BLOCK consecutive chunks (almost always of one hot bucket: a bucket with 10^6 instances
-// is 2400 chunks), counts their instances per sub-bucket with LDS atomics and adds the non-zero counters to the global
-// ones when it moves on -- 2^p global atomics per 50 000 instances instead of one per instance (the per-instance
-// version ran at the rate of scattered HBM atomics, 20 G instances/s: 1.3 s of a repeat-rich human-scale step).
+// The two passes of the second-level partition (WRITE = false: count the instances of every sub-bucket; WRITE = true:
+// write every instance out as a record of its own, grouped by sub-bucket), with the counters of the hot bucket being
+// read kept in LDS.  A workgroup takes HOT_BLOCK consecutive chunks -- almost always of one hot bucket: a bucket with
+// 10^6 instances is 2400 chunks -- and counts their instances per sub-bucket with LDS atomics.  The counting pass then
+// adds the non-zero counters to the global ones: 2^p global atomics per 50 000 instances instead of one per instance.
+// The writing pass takes room for each sub-bucket's instances of this block with one global atomic per sub-bucket,
+// leaves the positions in the LDS counters, and extracts the instances a second time to write them there (LDS atomic
+// per instance): the records of one sub-bucket from one block are consecutive.  (With a global atomic per instance
+// both passes ran at the rate of scattered HBM atomics: 1.3 s + 1.2 s of a repeat-rich human-scale step; 0.24 s + ...)
 // Buckets with more than 2^HOT_LDS_LOG2 sub-buckets (a minimizer owning 10^7 distinct k-mers) keep the global atomics.
 constexpr int HOT_BLOCK = 128;                       // chunks per workgroup ticket
 constexpr uint32_t HOT_LDS_LOG2 = 14;                // sub-bucket counters a workgroup keeps in LDS (64 KB)
-template <int K, int NWAVES>
+template <int K, int NWAVES, bool WRITE>
 __global__ void __launch_bounds__(NWAVES * 64)
-k_hot_count(const uint4* __restrict__ records, const HotItem* __restrict__ items, const uint64_t* __restrict__ rec_base,
-            const uint64_t* __restrict__ chunk_pre, uint32_t n_items, unsigned long long* __restrict__ ticket,
-            unsigned long long* __restrict__ sub_acc)
+k_hot_pass(const uint4* __restrict__ records, const HotItem* __restrict__ items, const uint64_t* __restrict__ rec_base,
+           const uint64_t* __restrict__ chunk_pre, uint32_t n_items, unsigned long long* __restrict__ ticket,
+           unsigned long long* __restrict__ sub_acc,          // !WRITE: per sub-bucket records << 32 | instances
+           unsigned long long* __restrict__ sub_cur,          // WRITE: per sub-bucket append cursor, starts at its first record
+           const uint64_t* __restrict__ sub_first,            // WRITE: first record of every sub-bucket (the pass's bucket bases)
+           uint64_t n_out, uint4* __restrict__ out)
 {
+    constexpr int NT = NWAVES * 64;
     __shared__ WaveStage<K> stages[NWAVES];
     __shared__ uint32_t hist[1u << HOT_LDS_LOG2];
     __shared__ unsigned long long blk_first;
@@ -1039,28 +993,48 @@ k_hot_count(const uint4* __restrict__ records, const HotItem* __restrict__ items
             const uint64_t rb0 = rec_base[I.b0], re = rec_base[I.b1];
             const bool in_lds = I.log2p <= HOT_LDS_LOG2;
             const uint32_t n_sub = 1u << I.log2p;
-            if (in_lds) { for (uint32_t i = tid; i < n_sub; i += NWAVES * 64) hist[i] = 0; __syncthreads(); }
-            for (uint64_t c = t + wave; c < seg_end; c += NWAVES) {
-                const uint64_t rb = rb0 + (c - c0) * COUNT_CHUNK;
-                const uint32_t total = wave_stage_piece<K>(records, rb, re, st, lane);
-                for (uint32_t i0 = 0; i0 < total; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    if (i < total) {
-                        const Probe A = make_probe<K>(fetch_instance<K>(st, i), 2u, true);
-                        const uint32_t sub = I.log2p ? sub_bucket_hash(A) >> (32u - I.log2p) : 0u;
-                        if (in_lds) atomicAdd(&hist[sub], 1u);
-                        else atomicAdd(&sub_acc[I.sub_base + sub], (1ull << 32) | 1ull);
+            const uint64_t item_first = WRITE ? sub_first[I.sub_base] : 0ull;
+            // a sweep over the segment's chunks; `mode` 0: count into LDS, 1: global atomics per instance (and write),
+            // 2: write at the positions the LDS counters hold
+            auto sweep = [&](const int mode) {
+                for (uint64_t c = t + wave; c < seg_end; c += NWAVES) {
+                    const uint64_t rb = rb0 + (c - c0) * COUNT_CHUNK;
+                    const uint32_t total = wave_stage_piece<K>(records, rb, re, st, lane);
+                    for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        if (i < total) {
+                            const InstRegs in = fetch_instance<K>(st, i);
+                            const Probe A = make_probe<K>(in, 2u, true);
+                            const uint32_t sub = I.log2p ? sub_bucket_hash(A) >> (32u - I.log2p) : 0u;
+                            if (mode == 0) atomicAdd(&hist[sub], 1u);
+                            else if (mode == 1) {
+                                if (!WRITE) atomicAdd(&sub_acc[I.sub_base + sub], (1ull << 32) | 1ull);
+                                else {
+                                    const uint64_t dst = atomicAdd(&sub_cur[I.sub_base + sub], 1ull);
+                                    if (dst < n_out) hot_write_record<K>(in, I.sub_base + sub, dst, out);
+                                }
+                            } else {
+                                const uint64_t dst = item_first + atomicAdd(&hist[sub], 1u);
+                                if (dst < n_out) hot_write_record<K>(in, I.sub_base + sub, dst, out);
+                            }
+                        }
                     }
+                    wave_sync();
                 }
-                wave_sync();
-            }
-            if (in_lds) {
+            };
+            if (!in_lds) sweep(1);
+            else {
+                for (uint32_t i = tid; i < n_sub; i += NT) hist[i] = 0;
                 __syncthreads();
-                for (uint32_t i = tid; i < n_sub; i += NWAVES * 64) {
+                sweep(0);
+                __syncthreads();
+                for (uint32_t i = tid; i < n_sub; i += NT) {
                     const uint32_t h = hist[i];
-                    if (h) atomicAdd(&sub_acc[I.sub_base + i], ((unsigned long long)h << 32) | h);
+                    if (!WRITE) { if (h) atomicAdd(&sub_acc[I.sub_base + i], ((unsigned long long)h << 32) | h); }
+                    else hist[i] = h ? (uint32_t)(atomicAdd(&sub_cur[I.sub_base + i], (unsigned long long)h) - item_first) : 0u;
                 }
                 __syncthreads();
+                if (WRITE) { sweep(2); __syncthreads(); }
             }
             t = seg_end;
         }
