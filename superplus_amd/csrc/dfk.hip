@@ -206,6 +206,13 @@ struct dfk_ctx {
         if (bytes >= (1ull << 30)) TRACE("alloc %-28s %8.2f GB at %p (%s), held %.2f GB", what, bytes / 1e9, b.p, top ? "top" : "bottom", held / 1e9);
         return 0;
     }
+    // the largest block alloc() could hand out now: a free block of a chunk, or a new chunk within the budget
+    uint64_t largest_allocatable() const
+    {
+        uint64_t best = budget > reserved ? (budget - reserved) & ~(uint64_t)0xFFF : 0;
+        for (const Chunk& k : chunks) for (const Free& f : k.free_list) best = std::max<uint64_t>(best, f.bytes);
+        return std::min<uint64_t>(best, budget > held ? budget - held : 0);
+    }
     void release(DevBuf& b)
     {
         if (!b.p) return;
@@ -1070,11 +1077,23 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
             if (p >= split_from_p && p <= 22) { sp_b.push_back(singles[i]); sp_i.push_back(inst); sp_p.push_back(p); sp_at.push_back(i); }
         }
         std::vector<uint8_t> taken(n, 0);
-        if (!sp_b.empty()) {
-            const int r2 = count_split<K, NBC>(c, P, sp_b, sp_i, sp_p, R);
-            if (r2 == 0) { for (uint32_t i : sp_at) taken[i] = 1; }
+        // The expanded records of the split buckets (32 B per instance: 30 GB for a pass of a human-scale set with a 10 %
+        // repeat family) must fit one free block of the arena, which the pass plan does not reserve: the buckets are
+        // split in as many groups as that takes.  (All at once or not at all, three passes in twenty found no block
+        // and fell back to 250 000 sub-passes and HBM tables: 0.45 s each.)
+        for (size_t i0 = 0; i0 < sp_b.size();) {
+            const uint64_t can = c->largest_allocatable(), keep = 512ull << 20;
+            const uint64_t cap_inst = can > keep ? (uint64_t)(0.95 * (double)(can - keep)) / 34 : 0;
+            size_t i1 = i0; uint64_t sum = 0;
+            while (i1 < sp_b.size() && sum + sp_i[i1] <= cap_inst) sum += sp_i[i1++];
+            if (i1 == i0) { TRACE("fallback: no room to split a hot bucket of %llu instances (%.2f GB free in one piece): sub-passes instead", (unsigned long long)sp_i[i0], can / 1e9); break; }
+            const std::vector<ItemRange> gb(sp_b.begin() + i0, sp_b.begin() + i1);
+            const std::vector<uint64_t> gi(sp_i.begin() + i0, sp_i.begin() + i1);
+            const std::vector<uint32_t> gp(sp_p.begin() + i0, sp_p.begin() + i1);
+            const int r2 = count_split<K, NBC>(c, P, gb, gi, gp, R);
+            if (r2 == 0) { for (size_t i = i0; i < i1; ++i) taken[sp_at[i]] = 1; i0 = i1; }
             else if (r2 != E_SPLIT_NO_ROOM) return r2;
-            else TRACE("fallback: no room to split %zu hot buckets (%s): sub-passes instead", sp_b.size(), g_err.c_str());
+            else { TRACE("fallback: no room to split %zu hot buckets (%s): sub-passes instead", i1 - i0, g_err.c_str()); break; }
         }
         for (uint32_t i = 0; i < n; ++i) {
             if (taken[i]) continue;

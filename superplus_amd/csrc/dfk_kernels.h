@@ -958,7 +958,7 @@ __device__ __forceinline__ void hot_write_record(const InstRegs& in, uint32_t su
 // The writing pass takes room for each sub-bucket's instances of this block with one global atomic per sub-bucket,
 // leaves the positions in the LDS counters, and extracts the instances a second time to write them there (LDS atomic
 // per instance): the records of one sub-bucket from one block are consecutive.  (With a global atomic per instance
-// both passes ran at the rate of scattered HBM atomics: 1.3 s + 1.2 s of a repeat-rich human-scale step; 0.24 s + ...)
+// both passes ran at the rate of scattered HBM atomics: 1.3 s + 1.2 s of a repeat-rich human-scale step, against 0.24 s + 0.3 s.)
 // Buckets with more than 2^HOT_LDS_LOG2 sub-buckets (a minimizer owning 10^7 distinct k-mers) keep the global atomics.
 constexpr int HOT_BLOCK = 128;                       // chunks per workgroup ticket
 constexpr uint32_t HOT_LDS_LOG2 = 14;                // sub-bucket counters a workgroup keeps in LDS (64 KB)
