@@ -691,7 +691,7 @@ int launch_boundary_list(dfk_ctx* c)
 // one k_count launch over `n_items` device-resident items; overflowed items come back as bucket ranges
 template <int K, int NBC>
 int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint64_t n_items, const CountRun& R,
-                 std::vector<ItemRange>* overflowed, float* kernel_ms, const uint32_t* d_sub = nullptr)
+                 std::vector<ItemRange>* overflowed, float* kernel_ms, const uint32_t* d_sub = nullptr, bool single_kmer_records = false)
 {
     constexpr int LOG2S = CountCfg<K>::LOG2S, NW = CountCfg<K>::NWAVES;
     if (n_items == 0) return 0;
@@ -699,7 +699,7 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
     DevBuf d_ovf;
     int rc = c->alloc(d_ovf, n_items * sizeof(ItemRange), "overflow list"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(&R.g->next_item, 0, 8, c->stream));      // next_item, n_overflow
-    CountParams cp = R.cp; cp.n_items = (uint32_t)n_items;
+    CountParams cp = R.cp; cp.n_items = (uint32_t)n_items; cp.single = single_kmer_records ? 1u : 0u;
     const size_t lds = count_lds_bytes<K, LOG2S, NW, NBC>();
     auto kern = d_sub ? k_count<K, LOG2S, NW, NBC, true> : k_count<K, LOG2S, NW, NBC, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -930,7 +930,7 @@ int count_split(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& bu
     c->st.n_items += P2.n_items;
     std::vector<ItemRange> overflowed, singles;
     float ignored = 0;
-    rc = launch_count<K, NBC>(c, P2, (const ItemRange*)P2.items.p, P2.n_items, R, &overflowed, &ignored); if (rc) return undo(rc);
+    rc = launch_count<K, NBC>(c, P2, (const ItemRange*)P2.items.p, P2.n_items, R, &overflowed, &ignored, nullptr, true); if (rc) return undo(rc);
     while (!overflowed.empty()) {
         std::vector<ItemRange> next;
         for (const ItemRange& r : overflowed) {
@@ -942,7 +942,7 @@ int count_split(dfk_ctx* c, const Partition& P, const std::vector<ItemRange>& bu
         if (next.empty()) break;
         DevBuf d_next; rc = c->alloc(d_next, next.size() * sizeof(ItemRange), "split items"); if (rc) return undo(rc);
         HIP_TRY(hipMemcpyAsync(d_next.p, next.data(), next.size() * sizeof(ItemRange), hipMemcpyHostToDevice, c->stream));
-        rc = launch_count<K, NBC>(c, P2, (const ItemRange*)d_next.p, next.size(), R, &overflowed, &ignored);
+        rc = launch_count<K, NBC>(c, P2, (const ItemRange*)d_next.p, next.size(), R, &overflowed, &ignored, nullptr, true);
         if (rc) return undo(rc);
     }
     TRACE("fallback: %u buckets (%llu instances) split into %llu sub-buckets, %llu items; %zu sub-buckets to HBM tables", n, (unsigned long long)tot,

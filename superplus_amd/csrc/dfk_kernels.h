@@ -579,7 +579,7 @@ struct ItemRange { uint32_t b0, b1; };     // a work item: fine buckets [b0,b1) 
 struct CountParams {
     uint32_t min_freq, min_bc;
     uint32_t n_items;
-    uint32_t reserved0;              // (unused)
+    uint32_t single;                 // every record of this launch holds ONE k-mer (the sub-buckets of split hot buckets): no staging
     uint64_t seg_cap;                // entries the output buffer holds (k_count: the part's reservation; k_big_emit: the fallback buffer)
     uint32_t do_adj;                 // resolve adjacencies inside the table where possible (min_freq > 1)
     uint32_t keep_pre;               // keep the pre-adjacency context byte in the entry's pad field (tests)
@@ -1368,6 +1368,24 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         const uint32_t share = (n_rec + NWAVES - 1) / NWAVES;
         const uint32_t wv = __builtin_amdgcn_readfirstlane((uint32_t)wave);       // (scalar loop control)
         const uint32_t w_lo = min(n_rec, wv * share), w_hi = min(n_rec, w_lo + share);
+        if (!SUB && cp.single) {
+            // one-k-mer records (k_hot_pass wrote them): a lane takes a record straight from HBM -- staged 32 at a
+            // time they would fill half the lanes of a batch
+            for (uint32_t at = w_lo; at < w_hi; at += 64) {
+                if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
+                const uint32_t r = at + (uint32_t)lane;
+                uint4 a{0, 0, 0, 0}, b{0, 0, 0, 0};
+                if (r < w_hi) { a = records[2 * (rb + r)]; b = records[2 * (rb + r) + 1]; }
+                const InstRegs in{a.x, a.y, a.z, a.w, b.x, b.y, b.z, 0u};
+                const Probe A = make_probe<K>(in, S, (a.x & 63u) != 0u);
+                uint32_t claimed = 0;
+                const bool ok = table_insert<KW, NBC, true>(keys, cnt, ctxs, bcw, S, A, claimed);
+                claimed = wave_sum(claimed);
+                if (lane == 0 && claimed) atomicAdd(&ctl[CTL_FILL], claimed);
+                if (!ok) atomicOr(&ctl[CTL_OVF], 1u);
+                if (lane == 0 && tld(&ctl[CTL_FILL]) > (S / 4) * 3) tst(&ctl[CTL_OVF], 1u);
+            }
+        } else
         for (uint32_t at = w_lo; at < w_hi; at += COUNT_CHUNK) {
             if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
             wave_count_chunk<K, NBC, true, SUB>(records, rb + at, rb + w_hi, st, lane, keys, cnt, ctxs, bcw, S,
