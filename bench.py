@@ -215,7 +215,8 @@ def df_stage_wall(args, dev, local):
         del rs
         torch.cuda.synchronize(); torch.cuda.empty_cache()
         cmd = [os.path.join(ROOT, "superplus_amd", "DF"), f"ROOT={root}", f"LR={root}/reads.fastb", "PIPELINE=cs", "ALIGN=False",
-               f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}", "GRAPH=False"]   # (ingest + count)
+               f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}",
+               "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (ingest + count; --df-graph adds row f-1: edges + HBV + a.<K>/)
         env = dict(os.environ, DFK_HOST_THREADS=str(min(args.df_threads, 16)))
         if args.df_gpus > 1 or args.df_transport:
             # the C++ multi-GPU host (df_shard.h): DF forks one rank per GPU and moves the records over RCCL itself;
@@ -248,6 +249,9 @@ def df_stage_wall(args, dev, local):
                 "kmers_per_s_whole_stage": (timing.get("kmer_instances", 0) / wall) if wall > 0 else None,
                 "breakdown_s": {k: timing.get(k) for k in ("open_validate_s", "ingest_outputs_s", "upload_s", "count_s",
                                                            "spectrum_kvec_write_s", "total_s")},
+                "graph": ({"graph_s": timing.get("graph_s"), "device_s": timing.get("graph_device_s"), "host_s": timing.get("graph_host_s"),
+                           "write_s": timing.get("graph_write_s"), "edges": timing.get("graph_edges"), "vertices": timing.get("graph_vertices")}
+                          if args.df_graph else None),
                 "host": ("C++ sharded host, %d rank(s), transport %s" % (max(1, args.df_gpus), args.df_transport or "rccl")) if (args.df_gpus > 1 or args.df_transport) else "single GPU (dfk_count)",
                 "shard_times_s": timing.get("shard"),
                 "input_bytes": in_bytes, "output_bytes": out_bytes, "files_on": root, "host_threads": args.df_threads,
@@ -284,6 +288,7 @@ def main():
                          "inputs + outputs of the full 900 M-pair set (~300 GB) exceed the box's 270 GiB host memory cap")
     ap.add_argument("--df-dir", default="/dev/shm", help="where the DF leg's files go")
     ap.add_argument("--df-threads", type=int, default=16, help="NUM_THREADS of the DF leg (the box's CPU share for one GPU)")
+    ap.add_argument("--df-graph", action="store_true", help="DF leg: also build the unipath graph and write a.<K>/ (row f-1)")
     ap.add_argument("--df-gpus", type=int, default=1, help="DF leg: NUM_GPUS of the C++ multi-GPU host (DF forks one rank per GPU, RCCL directly)")
     ap.add_argument("--df-transport", default="", choices=["", "rccl", "loopback"],
                     help="DF leg: run the C++ sharded host even with one rank (rccl), or all ranks as threads on one GPU (loopback)")

@@ -626,16 +626,19 @@ int main(int argc, char** argv)
         T.fetch_write = now_s() - t0;
         // ---- buildEdges + buildHBVFromEdges + the graph files of WriteAssemblyFiles (BuildReadQGraph48.cc:1636,1664;
         //      10X/WriteFiles.cc:69-101): a.<K>/{a.k,a.hbv,a.hbx,a.to_left,a.to_right,a.inv,a.fastb,a.kmers}
-        double t_graph = 0;
+        double t_graph = 0, t_g_dev = 0, t_g_host = 0, t_g_write = 0;
         uint64_t g_ce = 0, g_v = 0, g_e = 0;
         if (truthy(a["GRAPH"])) {
             t0 = now_s();
             printf("%s: finding edge sequences.\n", date().c_str());
             if (dfk_graph_build(ctx)) throw std::runtime_error(dfk_last_error());
+            { dfk_stats gs{}; dfk_get_stats(ctx, &gs); t_g_dev = 1e-6 * (double)gs.reserved[1]; t_g_host = 1e-6 * (double)gs.reserved[2]; }
             const std::string dir = work_dir + "/a." + std::to_string(K);
             mkpath(dir);
             printf("%s: writing files\n", date().c_str());
+            const double tw = now_s();
             if (dfk_graph_write(ctx, dir.c_str())) throw std::runtime_error(dfk_last_error());
+            t_g_write = now_s() - tw;
             dfk_graph_stats(ctx, &g_ce, &g_v, &g_e);
             t_graph = now_s() - t0;
         }
@@ -647,10 +650,10 @@ int main(int argc, char** argv)
                (unsigned long long)st.n_inst, st.ms_total, st.ms_count, T.total);
         // one machine-readable line (bench.py reads it): where the stage's wall time went
         printf("DF_TIMING {\"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"threads\": %u, \"open_validate_s\": %.3f, "
-               "\"ingest_outputs_s\": %.3f, \"upload_s\": %.3f, \"count_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, \"graph_s\": %.3f, "
+               "\"ingest_outputs_s\": %.3f, \"upload_s\": %.3f, \"count_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, \"graph_s\": %.3f, \"graph_device_s\": %.3f, \"graph_host_s\": %.3f, \"graph_write_s\": %.3f, "
                "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"total_s\": %.3f, \"fast_path\": %s}\n",
                (unsigned long long)n_reads, (unsigned long long)st.n_inst, (unsigned long long)nk, g_threads, T.read, T.ingest_out,
-               T.upload, T.count, T.fetch_write, t_graph, (unsigned long long)g_e, (unsigned long long)g_v, T.total, fast ? "true" : "false");
+               T.upload, T.count, T.fetch_write, t_graph, t_g_dev, t_g_host, t_g_write, (unsigned long long)g_e, (unsigned long long)g_v, T.total, fast ? "true" : "false");
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());
         for (pid_t pid : children) kill(pid, SIGTERM);
