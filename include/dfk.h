@@ -224,6 +224,16 @@ int dfk_shard_begin_host(dfk_ctx* ctx,
 int dfk_shard_plan(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t* log2_passes);
 int dfk_shard_partition(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t log2_passes, uint32_t pass,
               const void** d_records, uint64_t* send_counts /* [world], in 32-byte records */);
+/* The same in two steps, for a driver that hides the partition of pass p+2 under the count of pass p (while the
+ * records of pass p+1 travel): _begin returns the send buffer and the send counts at once -- the counts are known from
+ * the counting scan -- and starts the kernels now (defer = 0) or, on the library's second stream, right behind the
+ * k_count of the dfk_shard_count call that follows (defer = 1); _end waits for them and checks that every slice
+ * received what the scan counted.  The buffer may be sent only after _end.  One partition at a time; the send buffers
+ * of two consecutive passes are alive together, the one of pass p is given back when pass p is counted or pass p+2
+ * begun.  dfk_shard_partition = _begin(defer = 0) + _end. */
+int dfk_shard_partition_begin(dfk_ctx* ctx, uint32_t world, uint64_t n_inst_global, uint32_t log2_passes, uint32_t pass, int defer,
+              const void** d_records, uint64_t* send_counts /* [world], in 32-byte records */);
+int dfk_shard_partition_end(dfk_ctx* ctx, uint32_t pass);
 /* Room for the records this rank is about to receive, from the library's own HBM budget (so that the
  * send, receive and regroup buffers of a pass are all planned in one place); dfk_shard_count frees it.
  * Optional: dfk_shard_count accepts any device pointer. */

@@ -109,34 +109,53 @@ inline void shard_create_dict(dfk_ctx* ctx, Transport& T, uint64_t n_inst_local,
     { uint64_t v = lp; T.all_reduce(&v, 1, true); lp = (uint32_t)v; }                 // every rank runs the same passes
     const uint32_t n_pass = 1u << lp;
     times->n_passes = n_pass;
-    std::vector<uint64_t> sc(w), rc(w), all((size_t)w * w);
-    struct Cut { const void* send = nullptr; void* recv = nullptr; uint64_t n_recv = 0; };
-    auto cut = [&](uint32_t p) -> Cut {                                               // partition pass p, size and start its exchange
-        Cut c;
+    std::vector<uint64_t> rc(w), all((size_t)w * w);
+    // Two passes ahead: while pass p is counted, the records of pass p+1 travel (a second receive buffer in the
+    // library) and those of pass p+2 are cut by a sweep the library starts behind the count's k_count, on its second
+    // stream (a second send buffer).
+    struct Cut { const void* send = nullptr; std::vector<uint64_t> sc; void* recv = nullptr; uint64_t n_recv = 0; };
+    auto part = [&](uint32_t p, bool defer) -> Cut {                                  // room and send counts of pass p; its kernels now or behind the next k_count
+        Cut c; c.sc.assign(w, 0);
         auto t1 = clock::now();
-        if (!pending) note(dfk_shard_partition(ctx, (uint32_t)w, n_global, lp, p, &c.send, sc.data()));
+        if (!pending) note(dfk_shard_partition_begin(ctx, (uint32_t)w, n_global, lp, p, defer ? 1 : 0, &c.send, c.sc.data()));
         times->partition += secs(t1);
-        agree("dfk_shard_partition");                                                 // (also covers the count of the pass before)
-        t1 = clock::now();
-        T.all_gather(sc.data(), w, all.data());
-        for (int s = 0; s < w; ++s) { rc[s] = all[(size_t)s * w + r]; c.n_recv += rc[s]; if (s != r) times->bytes_sent += 32 * sc[s]; }
-        note(dfk_shard_recv_buffer(ctx, c.n_recv, &c.recv));
-        agree("dfk_shard_recv_buffer");
-        all_to_all_v(T, c.send, sc.data(), c.recv, rc.data(), 32, piece, /*wait=*/false);
-        times->exchange_wait += secs(t1);
         return c;
     };
-    auto wait = [&] { auto t1 = clock::now(); T.wait(); times->exchange_wait += secs(t1); };
-    Cut cur = cut(0);
-    wait();
-    for (uint32_t p = 0; p < n_pass; ++p) {
-        Cut nxt;
-        if (p + 1 < n_pass) nxt = cut(p + 1);                                         // its records travel while this pass is counted
+    auto part_end = [&](uint32_t p) {
         auto t1 = clock::now();
-        if (!pending) note(dfk_shard_count(ctx, cur.recv, cur.n_recv, p));            // a failure is agreed on at the next cut / after the loop
+        if (!pending) note(dfk_shard_partition_end(ctx, p));
+        times->partition += secs(t1);
+    };
+    auto send_off = [&](Cut& c) {                                                     // size and start the exchange of a partitioned pass
+        auto t1 = clock::now();
+        T.all_gather(c.sc.data(), w, all.data());
+        c.n_recv = 0;
+        for (int s = 0; s < w; ++s) { rc[s] = all[(size_t)s * w + r]; c.n_recv += rc[s]; if (s != r) times->bytes_sent += 32 * c.sc[s]; }
+        note(dfk_shard_recv_buffer(ctx, c.n_recv, &c.recv));
+        agree("dfk_shard_recv_buffer");
+        all_to_all_v(T, c.send, c.sc.data(), c.recv, rc.data(), 32, piece, /*wait=*/false);
+        times->exchange_wait += secs(t1);
+    };
+    auto wait = [&] { auto t1 = clock::now(); T.wait(); times->exchange_wait += secs(t1); };
+    Cut cur = part(0, false); part_end(0);
+    agree("dfk_shard_partition");
+    send_off(cur);
+    wait();
+    Cut ahead; bool have_ahead = false;
+    if (n_pass > 1) { ahead = part(1, false); part_end(1); agree("dfk_shard_partition"); have_ahead = true; }   // (nothing to hide under yet)
+    for (uint32_t p = 0; p < n_pass; ++p) {
+        Cut nxt; bool sent = false;
+        if (have_ahead) { nxt = ahead; send_off(nxt); sent = true; }                  // pass p+1 travels while p is counted
+        have_ahead = false;
+        if (p + 2 < n_pass) { ahead = part(p + 2, true); have_ahead = true; }
+        auto t1 = clock::now();
+        if (!pending) note(dfk_shard_count(ctx, cur.recv, cur.n_recv, p));            // a failure is agreed on below / after the loop
         times->count += secs(t1);
-        if (p + 1 < n_pass) { wait(); cur = nxt; }
+        if (p + 2 < n_pass) part_end(p + 2);
+        if (sent) { wait(); cur = nxt; }
+        if (p + 2 < n_pass) agree("dfk_shard_count / dfk_shard_partition");
     }
+    std::vector<uint64_t> sc(w);
     // recomputeAdjacencies across ranks: queries to the owners, answers back in query order
     t0 = clock::now();
     const void* keys = nullptr;

@@ -107,8 +107,8 @@ struct dfk_ctx {
     const void* sh_in[7] = {};                // caller's device arrays, valid until dfk_shard_partition returns
     uint64_t sh_packed_bytes = 0, sh_pq_bytes = 0, sh_n_reads = 0, sh_n_inst_local = 0;
     int64_t sh_read_id0 = 0;
-    DevBuf shard_records;                     // send buffer of the pass partitioned last (records grouped by destination rank)
-    uint32_t shard_send_pass = 0;             //   ... and which pass that is
+    DevBuf shard_send[2];                     // send buffers (records grouped by destination rank) of the two passes partitioned
+    uint32_t shard_send_pass[2] = {~0u, ~0u}; //   last, by pass parity: one travels while the next is being written
     DevBuf shard_recv[2];                     // receive buffers handed to the caller by dfk_shard_recv_buffer: the pass being
     unsigned shard_recv_seq = 0;              //   counted and the one being received under it alternate between the two
     uint64_t budget_taken = 0;                //   ... and the part of the budget they stand for
@@ -256,14 +256,15 @@ struct dfk_ctx {
     void release_all()
     {
         // results of the previous run go back to the pool (sizes come from the DevBufs that own them)
-        DevBuf* live[] = {&good_len, &shard_records, &shard_recv[0], &shard_recv[1], &adj_keys, &adj_src, &set};
+        DevBuf* live[] = {&good_len, &shard_send[0], &shard_send[1], &shard_recv[0], &shard_recv[1], &adj_keys, &adj_src, &set};
         for (DevBuf* d : live) release(*d);
         for (Part& pt : parts) { release(pt.buf); release(pt.pre); }
         parts.clear();
         // anything an aborted run left behind: the arena is simply declared empty again
         owned.clear(); held = 0;
         for (Chunk& k : chunks) k.free_list.assign(1, Free{0, k.bytes});
-        good_len = shard_records = shard_recv[0] = shard_recv[1] = adj_keys = adj_src = set = DevBuf{};
+        good_len = shard_send[0] = shard_send[1] = shard_recv[0] = shard_recv[1] = adj_keys = adj_src = set = DevBuf{};
+        shard_send_pass[0] = shard_send_pass[1] = ~0u;
         have = false; sorted_ok = sorted_pre_ok = false; sorted.clear(); sorted_pre.clear(); hist.clear();
         n_solid = 0; adj_n = 0; shard_open = false;
         if (shard_state) { shard_state_free(shard_state); shard_state = nullptr; }

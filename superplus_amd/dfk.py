@@ -22,7 +22,7 @@ ENTRY_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("edge_id", "<u4"), ("coun
 EXPORTS = [
     "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_device",
     "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
-    "dfk_write_kvec", "dfk_write_kvec_part", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_begin_host", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
+    "dfk_write_kvec", "dfk_write_kvec_part", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_begin_host", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_partition_begin", "dfk_shard_partition_end", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
 ]
 

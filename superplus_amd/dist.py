@@ -236,6 +236,18 @@ class DistDfk(Dfk):
         counts = list(counts)
         return _view(ptr.value, 32 * sum(counts), self._device), counts
 
+    def partition_begin(self, world, n_inst_global, log2_passes, pass_, defer):
+        """Room and send counts of pass `pass_` at once; its kernels start now, or (defer) behind the k_count of the
+        count_records call that follows, on the library's second stream.  The buffer may be sent after partition_end."""
+        ptr = C.c_void_p(); counts = (C.c_uint64 * world)()
+        _check(lib().dfk_shard_partition_begin(self._ctx, C.c_uint32(world), C.c_uint64(n_inst_global), C.c_uint32(log2_passes),
+                                               C.c_uint32(pass_), C.c_int(1 if defer else 0), C.byref(ptr), counts))
+        counts = list(counts)
+        return _view(ptr.value, 32 * sum(counts), self._device), counts
+
+    def partition_end(self, pass_):
+        _check(lib().dfk_shard_partition_end(self._ctx, C.c_uint32(pass_)))
+
     def recv_buffer(self, n_records):
         ptr = C.c_void_p()
         _check(lib().dfk_shard_recv_buffer(self._ctx, C.c_uint64(n_records), C.byref(ptr)))
@@ -309,9 +321,11 @@ class DistDfk(Dfk):
         mine = timed("plan", self.plan, world, n_global)
         agree("dfk_shard_plan")
         log2_passes = comm.all_reduce_max(mine, packed.device)   # every rank runs the same passes
-        # The k-mer shuffle, one bucket range at a time -- and one range ahead: while pass p is counted, the records
-        # of pass p+1 have been cut and are on their way (the library keeps a second receive buffer for them).
+        # The k-mer shuffle, one bucket range at a time -- and two ranges ahead: while pass p is counted, the records of
+        # pass p+1 are on their way (the library keeps a second receive buffer for them) and those of pass p+2 are being
+        # cut, by a sweep the library starts behind the count's k_count on its second stream (a second send buffer).
         n_pass = 1 << log2_passes
+        serial = bool(os.environ.get("DFK_SHARD_SERIAL"))          # debugging aid: nothing under the count
         def cut(p):
             r = timed("partition", self.partition, world, n_global, log2_passes, p)
             agree("dfk_shard_partition")               # (also covers the count of the pass before: see below)
@@ -337,21 +351,32 @@ class DistDfk(Dfk):
             return token
 
         recv, _ = wait_for(start(send, counts))
+        ahead = cut(1) if n_pass > 1 else None         # (nothing to hide under yet)
         for p in range(n_pass):
             token = None
-            if p + 1 < n_pass:
-                send, counts = cut(p + 1)
+            if ahead is not None:                      # pass p+1: partitioned, checked and agreed on; send it off
+                send, counts = ahead
                 sent += 32 * (sum(counts) - counts[comm.rank])
                 token = start(send, counts)
-                if os.environ.get("DFK_SHARD_SERIAL"):                          # debugging aid: no transfer under the count
+                if serial:
                     token = (*wait_for(token), None, None)
-            # a failure here is agreed on at the next cut() -- after the exchange that is already in flight has been
-            # waited for, so that no rank is left inside a transfer
+            ahead = None
+            if p + 2 < n_pass:
+                if serial:
+                    ahead = cut(p + 2)
+                else:
+                    ahead = timed("partition", self.partition_begin, world, n_global, log2_passes, p + 2, True)
+            # a failure here is agreed on below -- after the exchange that is already in flight has been waited for,
+            # so that no rank is left inside a transfer
             timed("count", self.count_records, recv, p)
             del recv
+            if p + 2 < n_pass and not serial:
+                timed("partition", self.partition_end, p + 2)
             if token is not None:
                 recv, _ = wait_for(token)
                 del token
+            if p + 2 < n_pass and not serial:
+                agree("dfk_shard_count / dfk_shard_partition")
         del send
         t_adj = time.perf_counter()
         q = timed("adjacency", self.adj_queries, world)
@@ -406,6 +431,31 @@ def run_inprocess(ranks, shards, pipelined=False):
     n_global = sum(n_local)
     log2_passes = max(ranks[r].plan(world, n_global) for r in range(world))
 
+    def deliver(sends):
+        recv, _ = _a2a([s[0] for s in sends], [s[1] for s in sends], 32)
+        out = []
+        for r in range(world):                  # receive into the library's own buffers, as the real driver does
+            buf = ranks[r].recv_buffer(recv[r].numel() // 32)
+            buf.copy_(recv[r])
+            out.append(buf)
+        return out
+
+    if pipelined:
+        # the order DistDfk.count_device uses: pass p+1 travels and pass p+2 is cut (behind the k_count) while p is counted
+        n_pass = 1 << log2_passes
+        recv = deliver([ranks[r].partition(world, n_global, log2_passes, 0) for r in range(world)])
+        ahead = [ranks[r].partition(world, n_global, log2_passes, 1) for r in range(world)] if n_pass > 1 else None
+        for p in range(n_pass):
+            nxt = deliver(ahead) if ahead is not None else None
+            ahead = [ranks[r].partition_begin(world, n_global, log2_passes, p + 2, True) for r in range(world)] if p + 2 < n_pass else None
+            for r in range(world):
+                ranks[r].count_records(recv[r], p)
+                ranks[r]._n_inst_global = n_global
+                if p + 2 < n_pass:
+                    ranks[r].partition_end(p + 2)
+            recv = nxt
+        return _inprocess_adjacency(ranks, world, n_global)
+
     def shuffle(p):
         sends = [ranks[r].partition(world, n_global, log2_passes, p) for r in range(world)]
         recv, _ = _a2a([s[0] for s in sends], [s[1] for s in sends], 32)
@@ -428,6 +478,10 @@ def run_inprocess(ranks, shards, pipelined=False):
         for r in range(world):
             ranks[r].count_records(recv[r], p)
             ranks[r]._n_inst_global = n_global
+    return _inprocess_adjacency(ranks, world, n_global)
+
+
+def _inprocess_adjacency(ranks, world, n_global):
     q = [ranks[r].adj_queries(world) for r in range(world)]
     rkeys, rcounts = _a2a([x[0] for x in q], [x[1] for x in q], 16)
     answers = [ranks[r].adj_answer(rkeys[r].contiguous()) for r in range(world)]

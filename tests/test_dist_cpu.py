@@ -137,8 +137,10 @@ def _failing_rank(rank, world, port, q, fail_in):
                     raise DfkError(-4, f"injected failure in {what}")
 
             def begin(self, *a, **k): self._maybe("begin"); return 1000
-            def plan(self, world, n): self._maybe("plan"); return 1            # two passes
+            def plan(self, world, n): self._maybe("plan"); return 2            # four passes: the pipeline reaches its steady state
             def partition(self, world, n, l, p): self._maybe("partition%d" % p); return torch.zeros(32 * 3 * world, dtype=torch.uint8), [3] * world
+            def partition_begin(self, world, n, l, p, defer): return self.partition(world, n, l, p)
+            def partition_end(self, p): self._maybe("partend%d" % p)
             def recv_buffer(self, n): self._maybe("recv"); return torch.zeros(32 * n, dtype=torch.uint8)
             def count_records(self, recv, p): self._maybe("count%d" % p)
             def adj_queries(self, world): self._maybe("adjq"); return torch.zeros(16 * 2 * world, dtype=torch.uint8), [2] * world
@@ -159,7 +161,8 @@ def _failing_rank(rank, world, port, q, fail_in):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fail_in", ["none", "begin", "plan", "partition0", "recv", "count0", "partition1", "count1", "adjq", "adja"])
+@pytest.mark.parametrize("fail_in", ["none", "begin", "plan", "partition0", "recv", "count0", "partition1", "count1", "partition2", "partend2",
+                                     "partition3", "count2", "count3", "adjq", "adja"])
 def test_one_rank_failing_stops_every_rank(fail_in):
     """A library call that fails on one rank only (its own data, its own HBM budget) must end the run on EVERY rank
     with an error, not leave the others inside the next collective: the driver all-reduces a status
