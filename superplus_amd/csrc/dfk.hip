@@ -255,6 +255,9 @@ struct dfk_ctx {
     void drop_pool() { for (Chunk& k : chunks) (void)hipFree(k.p); chunks.clear(); reserved = 0; }
     void release_all()
     {
+        // (an aborted sharded run may have left a partition registered for launch, or running on the second stream)
+        after_count_launch = nullptr;
+        if (stream2) (void)hipStreamSynchronize(stream2);
         // results of the previous run go back to the pool (sizes come from the DevBufs that own them)
         DevBuf* live[] = {&good_len, &shard_send[0], &shard_send[1], &shard_recv[0], &shard_recv[1], &adj_keys, &adj_src, &set};
         for (DevBuf* d : live) release(*d);
