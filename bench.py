@@ -224,13 +224,15 @@ def df_stage_wall(args, dev, local):
             cmd.append(f"NUM_GPUS={max(1, args.df_gpus)}")
             if args.df_transport == "loopback": env["DF_TRANSPORT"] = "loopback"
             elif args.df_gpus <= 1: env["DF_FORCE_SHARDED"] = "1"
-        t0 = time.perf_counter()
+        t0 = time.perf_counter(); e0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
-        wall = time.perf_counter() - t0
+        wall = time.perf_counter() - t0; e1 = time.time()
         if r.returncode != 0:
             return {"error": f"DF exited {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
         timing = {}
         for line in r.stdout.splitlines():
+            if line.startswith("DF_MAIN_EPOCH "): timing["spawn_to_main_s"] = round(float(line.split()[1]) - e0, 3)
+            if line.startswith("DF_EXIT_EPOCH "): timing["exit_to_reaped_s"] = round(e1 - float(line.split()[1]), 3)
             if line.startswith("DF_TIMING "):
                 o = json.loads(line[len("DF_TIMING "):])
                 if "rank0" in o:                     # the C++ sharded host: rank 0's phases, beside the parent's line
@@ -247,8 +249,8 @@ def df_stage_wall(args, dev, local):
                               "(runall.sh:127) from start to exit: map inputs, re-emit frag_reads_orig.*, lens/qhist/dti, upload, "
                               "createDict on the GPU, spectrum JSON, kmers.kvec -- ingest + count, not the other seven DF stages",
                 "kmers_per_s_whole_stage": (timing.get("kmer_instances", 0) / wall) if wall > 0 else None,
-                "breakdown_s": {k: timing.get(k) for k in ("open_validate_s", "ingest_outputs_s", "upload_s", "count_s",
-                                                           "spectrum_kvec_write_s", "total_s")},
+                "breakdown_s": {k: timing.get(k) for k in ("spawn_to_main_s", "open_validate_s", "ingest_outputs_s", "upload_s", "count_s",
+                                                           "spectrum_kvec_write_s", "total_s", "exit_to_reaped_s")},
                 "graph": ({"graph_s": timing.get("graph_s"), "device_s": timing.get("graph_device_s"), "host_s": timing.get("graph_host_s"),
                            "write_s": timing.get("graph_write_s"), "edges": timing.get("graph_edges"), "vertices": timing.get("graph_vertices")}
                           if args.df_graph else None),

@@ -340,6 +340,7 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
 
 int main(int argc, char** argv)
 {
+    { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); printf("DF_MAIN_EPOCH %.3f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
     const double t_start = now_s();
     std::map<std::string, std::string> a = {
         {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
@@ -654,6 +655,7 @@ int main(int argc, char** argv)
                "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"total_s\": %.3f, \"fast_path\": %s}\n",
                (unsigned long long)n_reads, (unsigned long long)st.n_inst, (unsigned long long)nk, g_threads, T.read, T.ingest_out,
                T.upload, T.count, T.fetch_write, t_graph, t_g_dev, t_g_host, t_g_write, (unsigned long long)g_e, (unsigned long long)g_v, T.total, fast ? "true" : "false");
+        { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); printf("DF_EXIT_EPOCH %.3f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());
         for (pid_t pid : children) kill(pid, SIGTERM);
