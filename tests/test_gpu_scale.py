@@ -10,8 +10,8 @@ from superplus_amd.dfk import Dfk
 pytestmark = pytest.mark.gpu
 
 
-def _counts(shard, passes):
-    d = Dfk(K=48, device=0, passes=passes)
+def _counts(shard, passes, K=48):
+    d = Dfk(K=K, device=0, passes=passes)
     d.count_device(*shard)
     st, dg = d.stats(), d.digest()
     d.close()
@@ -61,3 +61,16 @@ def test_hot_buckets_beyond_2_pow_31_instances_in_one_pass():
     assert one == four
     again, _ = _counts(shard, 4)                      # and from run to run
     assert again == four
+
+
+@pytest.mark.parametrize("K", [40, 60])
+def test_other_k_with_hot_buckets_one_pass_equals_four(K):
+    """The same property at the other two k-mer widths (K = 60 keys are four words wide: its own table layout, its own
+    instantiation of every kernel), on a genome a third of which is one repeat family: the hot-bucket paths (second-level
+    partition, one-k-mer records, HBM tables) run at scale for each K."""
+    _need_hbm(200)
+    shard = _reads(310, 344_444, 777 + K)
+    one, st1 = _counts(shard, 1, K)
+    four, st4 = _counts(shard, 4, K)
+    assert st1["n_passes"] == 1 and st4["n_passes"] == 4 and st1["n_overflow_items"] > 1000
+    assert one == four
