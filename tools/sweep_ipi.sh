@@ -1,5 +1,9 @@
-#!/bin/bash
-# tools/sweep_ipi.sh -- instances per work item on the 100 Mb slice (GPU box)
-for ipi in ${@:-2560 3072 3584 4096 4608 5120}; do
-  echo "inst_per_item=$ipi $(python bench.py --genome-mb 100 --pairs 15000000 --steps 3 --warmup 1 --no-cpu-baseline --inst-per-item $ipi 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],2), d["stage_ms_rank0"]["ms_count"], d["stage_ms_rank0"]["ms_fallback"], d["counts_rank0"]["n_items"], d["counts_rank0"]["n_overflow_items"])')"
+rm -f gpurun_out/ipi.txt
+for n in 0 2304 2688 3328 3840; do
+  python3 bench.py --no-cpu-baseline --no-extras --steps 2 --inst-per-item $n 2>/dev/null | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); c=d['counts_rank0']; s=d['stage_ms_rank0']; print('ipi=$n', round(d['ms_per_step'],1), 'count', s['ms_count'], 'items', c['n_items'], 'overflow', c['n_overflow_items'], 'passes', c['n_passes'])
+" >> gpurun_out/ipi.txt
 done
