@@ -290,6 +290,9 @@ def main():
                          "inputs + outputs of the full 900 M-pair set (~300 GB) exceed the box's 270 GiB host memory cap")
     ap.add_argument("--df-dir", default="/dev/shm", help="where the DF leg's files go")
     ap.add_argument("--df-threads", type=int, default=16, help="NUM_THREADS of the DF leg (the box's CPU share for one GPU)")
+    ap.add_argument("--sharded-one", action="store_true",
+                    help="run the whole set through the SHARDED pipeline with one rank (class-count scan without scattered atomics, "
+                         "slices, two-level LDS regroup): the alternative single-GPU design, for comparison (DESIGN.md section 9)")
     ap.add_argument("--df-graph", action="store_true", help="DF leg: also build the unipath graph and write a.<K>/ (row f-1)")
     ap.add_argument("--df-gpus", type=int, default=1, help="DF leg: NUM_GPUS of the C++ multi-GPU host (DF forks one rank per GPU, RCCL directly)")
     ap.add_argument("--df-transport", default="", choices=["", "rccl", "loopback"],
@@ -350,9 +353,9 @@ def main():
 
     kw = dict(K=args.K, device=local, minimizer_len=args.minimizer, inst_per_item=args.inst_per_item, passes=args.passes,
               hbm_budget_bytes=int(args.hbm_budget_gb * 1e9))
-    if args.emulate_world > 1:
+    if args.emulate_world > 1 or args.sharded_one:
         from superplus_amd.dist import DistDfk, ReplicaComm
-        d = DistDfk(comm=ReplicaComm(args.emulate_world), **kw)
+        d = DistDfk(comm=ReplicaComm(max(1, args.emulate_world)), **kw)
         def step():
             d.count_device(*shard, read_id0=0)
             return d.stats()
