@@ -148,6 +148,35 @@ def test_ragged_and_degenerate_reads(oracle):
         util.check_parity(ref, d)
 
 
+@pytest.mark.parametrize("nbits", [1, 2, 3, 4, 5, 6])
+def test_quality_fields_of_every_width(oracle, nbits):
+    """k_trim decodes per-base quality fields 64 bits at a time: every field width a PQVec block can have, read
+    lengths that put the fields at every bit offset of the 8-byte windows, thresholds that cut inside the field range."""
+    rng = np.random.default_rng(100 + nbits)
+    g = rng.integers(0, 4, 4000, dtype=np.uint8)
+    lo = 7 - (1 << nbits) // 2 if (1 << nbits) // 2 <= 7 else 0       # MIN_QUAL = 7 falls inside [lo, lo + 2^nbits)
+    reads, quals = [], []
+    for i in range(1500):
+        L = int(rng.integers(1, 330))
+        pos = int(rng.integers(0, 4000 - 330))
+        q = (lo + rng.integers(0, 1 << nbits, L)).astype(np.uint8)
+        q[rng.random(L) < 0.8] = lo + (1 << nbits) - 1                 # mostly good, so that runs of K good bases exist
+        if L > 2:
+            q[0], q[1] = lo, lo + (1 << nbits) - 1                       # the block's range is exactly nbits wide
+        reads.append(g[pos:pos + L].copy()); quals.append(q)
+    rs = _custom(reads, quals, None)
+    from superplus_amd import feudal
+    widths = set()
+    for q in quals[:50]:
+        e = feudal.pq_encode(q); p = 0
+        while e[p]:
+            widths.add(e[p + 1] & 7); p += ((e[p] * (e[p + 1] & 7) + 24) >> 3)
+    assert nbits in widths
+    ref, d = util.run_both(oracle, rs, K=48, min_freq=1, use_bc=False)
+    st = util.check_parity(ref, d)
+    assert st["n_solid"] > 0 and int(np.count_nonzero(ref["good_len"] != rs["read_len"])) > 100    # (the trim did cut reads)
+
+
 def test_long_reads_take_the_scanning_scatter(oracle):
     """240-base reads have more than the ten runs a summary holds: most of them go through the scanning
     scatter (k_partition<K,true>) in every pass, and its words through several refills of the scan's LDS ring."""
