@@ -1638,7 +1638,9 @@ void host_sort_entries(std::vector<dfk_entry32>& v)
 // pinned buffers and a stream, pull chunks off a shared counter, and overlap their memcpy (or file write) with the
 // DMA of their other buffer.  Small transfers take the plain call.
 // (DFK_XFER_CHUNK: the tests push a few hundred reads through the many-chunk path)
-const size_t XFER_CHUNK = [] { const char* e = getenv("DFK_XFER_CHUNK"); return e && atoll(e) >= 64 ? ((size_t)atoll(e) & ~(size_t)31) : (size_t)16 << 20; }();
+// (4 MiB: a 45-GB upload takes 1.65 s; 2.3 s with 16-MiB pieces, 3.1 s with 32, 1.8 s with 1-2 MiB, and at 512 KiB the
+// dictionary's way out slows from 7.6 to 9 s -- tools/xfer_sweep.sh)
+const size_t XFER_CHUNK = [] { const char* e = getenv("DFK_XFER_CHUNK"); return e && atoll(e) >= 64 ? ((size_t)atoll(e) & ~(size_t)31) : (size_t)4 << 20; }();
 unsigned xfer_threads()
 {
     static const unsigned n = [] {
