@@ -279,7 +279,7 @@ def main():
                     help="reads of the sample the CPU baseline (and the parity check) runs on (about 30 s of reference code on 32 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the reported-only legs (K sweep, repeat-rich genome, DF stage wall-clock)")
-    ap.add_argument("--legs", default="ksweep,repeat,df", help="which reported-only legs run (comma list of ksweep, repeat, df)")
+    ap.add_argument("--legs", default="ksweep,repeat,rehearsal,df", help="which reported-only legs run (comma list of ksweep, repeat, rehearsal, df)")
     ap.add_argument("--extra-steps", type=int, default=3, help="timed steps of each reported-only leg")
     ap.add_argument("--family-copies", type=int, default=0,
                     help="plant this many diverged copies of one 300-bp element in the genome (hot minimizer buckets)")
@@ -514,6 +514,39 @@ def main():
                 extra["repeat_genome"] = {"error": repr(e)}
                 d2 = rs2 = genome = None
             torch.cuda.synchronize(); torch.cuda.empty_cache()
+            # row (e) without a multi-GPU node: rank 0 of G on its 1/G of the headline set against replicas of itself
+            # (ReplicaComm: real volumes and coverage, no bytes moved) -- the per-rank compute time of a G-GPU run
+            reh = {}
+            for Gr in ((2, 8) if "rehearsal" in legs else ()):
+                try:
+                    from superplus_amd.dist import DistDfk, ReplicaComm
+                    genome = synth.make_genome(G, SEED, device=dev)
+                    rs3 = synth.make_reads(genome, total_pairs // Gr, SEED + 17)
+                    del genome
+                    torch.cuda.synchronize(); torch.cuda.empty_cache()
+                    d3 = DistDfk(comm=ReplicaComm(Gr), **kw)
+                    sh3 = (rs3.packed, rs3.base_off, rs3.read_len, rs3.pq_bytes, rs3.pq_off, rs3.bc)
+                    d3.count_device(*sh3, read_id0=0)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.extra_steps):
+                        d3.count_device(*sh3, read_id0=0)
+                    torch.cuda.synchronize()
+                    secs = (time.perf_counter() - t1) / args.extra_steps
+                    s3 = d3.stats()
+                    reh[str(Gr)] = {"per_rank_step_s": round(secs, 4), "pairs_per_rank": total_pairs // Gr, "n_passes": s3["n_passes"],
+                                    "ms_scan": round(s3["ms_part_count"], 1), "ms_scatter_regroup": round(s3["ms_part_scatter"], 1),
+                                    "ms_count": round(s3["ms_count"], 1), "ms_adjacency": round(s3["ms_adjacency"], 1),
+                                    "bytes_sent_to_peers": d3.timing.get("bytes_sent_to_peers"),
+                                    "kmers_per_s_if_all_ranks_took_this_long": round(st["n_inst"] / secs)}
+                    d3.close()
+                    del rs3, sh3, d3
+                except Exception as e:
+                    reh[str(Gr)] = {"error": repr(e)}
+                torch.cuda.synchronize(); torch.cuda.empty_cache()
+            if reh:
+                extra["sharded_rehearsal"] = dict(reh, note="REHEARSAL on one GPU, not a multi-GPU measurement: rank 0 of G against replicas of "
+                                                            "itself; the all-to-all is a device copy (a real run hides it under the counts, DESIGN.md section 6)")
             try:
                 if "df" not in legs:
                     raise RuntimeError("leg not selected")
