@@ -15,7 +15,7 @@ mkdir -p "$OUT/obj"
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 COMMON="-std=gnu++11 -O2 -w -fno-access-control -fopenmp -ffunction-sections -fdata-sections -include $HERE/ref_compat.h -I$REF"
 cd "$REF"
-LIST=$(ls system/*.cc system/file/*.cc feudal/*.cc dna/*.cc kmers/KMerContext.cc kmers/ReadPather.cc 10X/Martian.cc \
+LIST=$(ls system/*.cc system/file/*.cc feudal/*.cc dna/*.cc kmers/KMerContext.cc kmers/ReadPather.cc paths/long/ReadPath.cc 10X/Martian.cc \
           random/RNGen.cc math/PowerOf2.cc *.cc | grep -v -e MakeDepend.cc \
           -e '^Alignment.cc' -e BlockAlign.cc -e Fastavector.cc -e IndexedAlignmentPlusVector.cc \
           -e PackAlign.cc -e PrintAlignment.cc -e ScoreAlignment.cc -e VecAlignmentPlus.cc -e '^Vec.cc')

@@ -42,6 +42,7 @@
 #include "Qualvector.h"
 #include "feudal/PQVec.h"
 #include "feudal/BinaryStream.h"
+#include "dna/CanonicalForm.h"
 #include "kmers/ReadPather.h"
 #include "system/System.h"
 #include <algorithm>
@@ -54,7 +55,8 @@
 #include <string>
 #include <vector>
 
-int graph_main( unsigned K, std::string const& edgesFile, std::string const& dir );   // ref_graph.cc
+int graph_main( unsigned K, std::string const& edgesFile, std::string const& dir,
+                std::string const& readsHead, std::string const& partsFile );   // ref_graph.cc (reads + parts: a.paths too)
 
 namespace {
 
@@ -244,6 +246,57 @@ struct EdgeGlue
       for ( auto const& hhs : dict ) for ( Entry const& e : hhs ) if ( e.getKDef().isNull() ) circle(e); }
 };
 
+// ---- glue restated from BuildReadQGraph48.cc:685-733 (Pather::path) and :593-606,622-682 (EdgeLoc / PathPart) ----
+// One read against the real KmerDict (findEntry canonicalises and looks up in the reference's hopscotch set) and the
+// canonical edges EdgeGlue left behind (every entry's KDef carries (edge, offset) by KDef::set): the real KMer
+// (construction from an iterator, toSuccessor), CF<K>::isRC and bvec's forward / reverse-complement iterators do the
+// arithmetic; what is restated is the loop: skip k-mers that are not in the dictionary (a gap part counts them), and
+// from a k-mer that is, run along its edge while the bases agree (matchLen, :532-541).
+// A part travels as 16 bytes: edge, offset (~offset when the read runs along the edge's reverse complement, EdgeLoc
+// :596-598), k-mers covered, k-mers on the edge (0 = gap; then only `len` means anything).
+struct PartOut { uint32_t edge; int32_t off; uint32_t len, elen; };
+
+template <unsigned K>
+struct PatherGlue
+{
+    typedef KMer<K> Kmer;
+    typedef KmerDictEntry<K> Entry;
+    typedef KmerDict<K> Dict;
+    Dict const& dict; std::vector<bvec> const& edges;
+    PatherGlue( Dict const& d, std::vector<bvec> const& e ) : dict(d), edges(e) {}
+
+    template <class I1, class I2> static size_t agree( I1 a, I1 aEnd, I2 b, I2 bEnd )
+    { size_t n = 0; while ( a != aEnd && b != bEnd && *a == *b ) { ++n; ++a; ++b; } return n; }
+
+    void path( bvec const& read, std::vector<PartOut>* out ) const
+    { out->clear();
+      if ( read.size() < K ) { out->push_back(PartOut{~0u,0,unsigned(read.size()),0u}); return; }
+      auto at = read.begin(); auto const stop = read.end()-K+1;
+      while ( at != stop )
+      { Kmer kmer(at);
+        Entry const* hit = dict.findEntry(kmer);
+        if ( !hit )
+        { unsigned missed = 1; auto nextBase = at+K; ++at;
+          while ( nextBase != read.end() )
+          { kmer.toSuccessor(*nextBase); ++nextBase;
+            if ( (hit = dict.findEntry(kmer)) ) break;
+            ++missed; ++at; }
+          out->push_back(PartOut{~0u,0,missed,0u}); }
+        if ( hit )
+        { KDef const& def = hit->getKDef();
+          bvec const& edge = edges[def.getEdgeID().val()];
+          int off = def.getEdgeOffset();
+          size_t len = 1;
+          bool rc = CF<K>::isRC(at,edge.begin(off));
+          if ( !rc ) len += agree(at+K,read.end(),edge.begin(off)+K,edge.end());
+          else
+          { off = edge.size()-off;
+            len += agree(at+K,read.end(),edge.rcbegin(off),edge.rcend());
+            off -= K; }
+          out->push_back(PartOut{unsigned(def.getEdgeID().val()),rc?~off:off,unsigned(len),unsigned(edge.size()-K+1)});
+          at += len; } } }
+};
+
 struct Rec { uint64_t w0, w1; uint32_t edge, cc; int32_t bc; uint32_t pad; };
 
 template <unsigned K>
@@ -340,9 +393,20 @@ int runDict( std::string const& head, std::string const& outdir, unsigned minQua
           for ( bvec const& b : found ) edges.push_back(b);
           edges.WriteAll((outdir+"/edges.fastb").c_str()); }
         double t7 = now_s();
-        int rc = graph_main(K,outdir+"/edges.fastb",outdir+"/a."+std::to_string(K));
+        {   // pathReads, first half (Pather::path per read, BuildReadQGraph48.cc:1420-1442 calls it through HBVPather): the parts
+            // of every read go to parts.bin; ref_graph.cc turns them into ReadPaths on the real digraphE
+            std::vector<bvec> canon; { vecbvec e; e.ReadAll((outdir+"/edges.fastb").c_str()); for ( size_t i = 0; i != e.size(); ++i ) canon.push_back(e[i]); }
+            PatherGlue<K> pg(dict,canon);
+            FILE* pf = fopen((outdir+"/parts.bin").c_str(),"wb");
+            uint64_t nr = reads.size(); fwrite(&nr,8,1,pf);
+            std::vector<PartOut> parts;
+            for ( size_t r = 0; r != reads.size(); ++r )
+            { pg.path(reads[r],&parts); uint32_t n = parts.size(); fwrite(&n,4,1,pf); fwrite(parts.data(),16,n,pf); }
+            fclose(pf); }
+        double t8 = now_s();
+        int rc = graph_main(K,outdir+"/edges.fastb",outdir+"/a."+std::to_string(K),head,outdir+"/parts.bin");
         f = fopen((outdir+"/times.txt").c_str(),"a");
-        fprintf(f,"edges_s %.6f\nhbv_s %.6f\n",t7-t6,now_s()-t7); fclose(f);
+        fprintf(f,"edges_s %.6f\nparts_s %.6f\nhbv_paths_s %.6f\n",t7-t6,t8-t7,now_s()-t8); fclose(f);
         return rc;
     }
     return 0;
@@ -490,7 +554,7 @@ int main( int argc, char** argv )
     if ( cmd == "rdreads" && argc == 4 ) return rdreads(argv[2],argv[3]);
     if ( cmd == "side" && argc == 4 ) return side(argv[2],argv[3]);
     if ( cmd == "side" && argc == 5 ) return side(argv[2],argv[3],atof(argv[4]));
-    if ( cmd == "hbv" && argc == 5 ) return graph_main(atoi(argv[2]),argv[3],argv[4]);   // hbv K edges.fastb outdir
+    if ( cmd == "hbv" && argc == 5 ) return graph_main(atoi(argv[2]),argv[3],argv[4],std::string(),std::string());   // hbv K edges.fastb outdir
     if ( ( cmd == "dict" || cmd == "graph" ) && ( argc == 10 || argc == 11 ) )
     {
         bool graph = cmd == "graph";                             // graph: dict + edges.fastb + a.<K>/{a.fastb,a.hbv,a.kmers,a.inv,...}

@@ -12,15 +12,29 @@
 //                                                                 queue-ordered numbering of vertices and edges
 //   paths/HyperBasevector.cc:121-125,133-137,668-680              K | digraphE ; K | digraphEX ; Involution
 //   10X/WriteFiles.cc:69-101                                      which files a.<K>/ holds
+// Row f-2 (read pathing) ends here too: ref_driver.cc's Pather glue leaves every read's path parts in parts.bin (made with
+// the real KmerDict / KMer / CF<K>::isRC / bvec iterators); this file edits them into ReadPaths on the REAL digraphE
+// (ToLeft/ToRight, To/From, ToEdgeObj/FromEdgeObj, ToSize/FromSize, EdgeObject) and writes a.paths with the real
+// ReadPath / ReadPathVec feudal writer (paths/long/ReadPath.h, compiled in place).  Restated glue, in its own words:
+//   paths/long/BuildReadQGraph48.cc:1212-1317   HBVPather::algorithmTwo (what StageBuildGraph selects: useNewAligner = True,
+//                                               10X/runstages/RunStages.cc:389-390)
+//   paths/long/BuildReadQGraph48.cc:657-666,796-803,1365-1402   isConformingCapturedGap, isJoinable, pathPartsToReadPath
+//   paths/long/ExtendReadPath.cc:15-333         the two overlap scorers and the left / right extension
 // Input: the canonical unipath edges (edges.fastb, written by ref_driver.cc's buildEdges glue through the real Dict).
 #include "Basevector.h"
 #include "feudal/BinaryStream.h"
 #include "graph/Digraph.h"
 #include "graph/DigraphTemplate.h"
+#include "paths/long/ReadPath.h"
+#include "feudal/PQVec.h"
+#include "Qualvector.h"
 #include "math/Hash.h"
 #include "system/System.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <limits>
 #include <deque>
 #include <map>
 #include <string>
@@ -40,9 +54,197 @@ struct Vtx { int id = -1; std::vector<IO> inc; };
 // length descending, then lexical (HBVFromEdges.cc:106-111)
 bool edgeLess( bvec const& a, bvec const& b ) { return a.size() != b.size() ? a.size() > b.size() : a < b; }
 
+
+// ------------------------------------------------------------------------------------------------ row f-2 glue
+struct Part                                       // as ref_driver.cc wrote it: elen == 0 is a gap
+{   uint32_t edge; int32_t off; uint32_t len, elen;
+    bool gap() const { return elen == 0; }
+    bool rc() const { return off < 0; }
+    unsigned offset() const { return off < 0 ? ~off : off; }
+    unsigned endOffset() const { return offset()+len; }
+    bool sameEdge( Part const& o ) const { return edge == o.edge && rc() == o.rc(); }
+    static Part gapOf( unsigned n ) { return Part{~0u,0,n,0u}; } };
+
+struct PathGlue
+{
+    digraphE<basevector> const& g; vecbvec const& canon; vec<int> const& fwd; vec<int> const& rev; unsigned K;
+    vec<int> toLeft, toRight;
+    static unsigned const JITTER = 3;             // HBVPather::MAX_JITTER (:1404)
+    mutable size_t hit[16] = {};                  // how often each rule fired (printed: the fixtures must reach every one)
+
+    PathGlue( digraphE<basevector> const& g_, vecbvec const& c, vec<int> const& f, vec<int> const& r, unsigned k )
+    : g(g_), canon(c), fwd(f), rev(r), K(k) { g.ToLeft(toLeft); g.ToRight(toRight); }
+
+    int hbvEdge( Part const& p ) const { return p.rc() ? rev[p.edge] : fwd[p.edge]; }
+    int kmersOf( int e ) const { return int(g.EdgeObject(e).size())-int(K)+1; }
+
+    // PathPart::isConformingCapturedGap (:657-666): all in unsigned, then through int
+    bool conforming( Part const& before, Part const& gap, Part const& after ) const
+    { unsigned dist = after.offset()-before.endOffset();
+      if ( !before.sameEdge(after) ) dist += before.elen;
+      return unsigned(std::abs(int(gap.len-dist))) <= JITTER; }
+
+    // Pather::isJoinable (:796-803): the last K-1 bases of the first part's edge, as the read runs along it, against the
+    // first K-1 of the second's
+    bool joinable( Part const& a, Part const& b ) const
+    { if ( a.edge == b.edge ) return true;
+      bvec const& e1 = canon[a.edge]; bvec const& e2 = canon[b.edge];
+      unsigned const klo = K-1;
+      for ( unsigned i = 0; i != klo; ++i )
+      { unsigned char x = a.rc() ? *(e1.rcbegin(e1.size()-klo+i)) : e1[e1.size()-klo+i];
+        unsigned char y = b.rc() ? *(e2.rcbegin(i)) : e2[i];
+        if ( x != y ) return false; }
+      return true; }
+
+    // pathPartsToReadPath (:1365-1402)
+    void toReadPath( std::vector<Part> const& parts, ReadPath& path ) const
+    { path.clear();
+      Part const* last = nullptr;
+      for ( Part const& p : parts )
+      { if ( p.gap() ) continue;
+        if ( last && last->sameEdge(p) ) continue;
+        path.push_back(hbvEdge(p)); last = &p; }
+      if ( path.empty() ) path.setOffset(0);
+      else if ( !parts.front().gap() ) path.setOffset(parts.front().offset());
+      else path.setOffset(int(parts[1].offset())-int(parts.front().len)); }
+
+    // scoreLeftOverlap / scoreRightOverlap (ExtendReadPath.cc:15-113): mismatches cost the base's quality (Q2 counts as
+    // 20) plus a running penalty that a matching base shrinks by a fifth -- `unsigned -= double`, i.e. truncation of
+    // penalty - 0.2*penalty in double; read bases left over beyond the edge cost 10 each
+    static unsigned score( bvec const& read, qvec const& q, size_t start, bvec const& edge, unsigned K, bool left )
+    { double const decay = 0.2;
+      unsigned sum = 0, penalty = 0;
+      long r = left ? long(start)-1 : long(read.size())-long(start);      // read index, moving outwards
+      long e = left ? long(edge.size())-long(K) : long(K)-1;              // edge index beside the shared K-1 bases
+      long const step = left ? -1 : 1;
+      auto readIn = [&]() { return r >= 0 && r < long(read.size()); };
+      auto edgeIn = [&]() { return e >= 0 && e < long(edge.size()); };
+      while ( readIn() && edgeIn() )
+      { if ( read[r] != edge[e] ) { int cost = q[r] == 2 ? 20 : int(q[r]); penalty += cost; sum += penalty; }
+        else if ( penalty > 0 ) penalty -= (decay*penalty);
+        r += step; e += step; }
+      while ( readIn() ) { sum += 10; r += step; }
+      return sum; }
+
+    // attemptLeftwardExtension / attemptRightwardExtension (ExtendReadPath.cc:130-244, 247-378)
+    bool extend( ReadPath& path, bvec const& read, qvec const& q, bool left ) const
+    { if ( !path.size() ) return false;
+      size_t hang;
+      if ( left )
+      { if ( path.getOffset() >= 0 ) return false;
+        hang = -path.getOffset(); }
+      else
+      { int h = read.size(); h += path.getOffset();
+        for ( int e : path ) h -= kmersOf(e);
+        h -= int(K)-1;
+        if ( h < 10 ) return false;
+        hang = h; }
+      if ( hang < 10 ) return false;
+      int const v = left ? toLeft[path.front()] : toRight[path.back()];
+      vec<int> const& cand = left ? g.ToEdgeObj(v) : g.FromEdgeObj(v);
+      vec<int> const& far = left ? g.To(v) : g.From(v);
+      auto deadEnd = [&]( int w ) { return left ? ( g.ToSize(w) == 0 && g.FromSize(w) == 1 ) : ( g.FromSize(w) == 0 && g.ToSize(w) == 1 ); };
+      std::vector<bool> hanging(cand.size(),false), reaches(cand.size(),false);
+      std::vector<int> shortTo;
+      size_t nReach = 0;
+      for ( size_t i = 0; i != cand.size(); ++i )
+      { hanging[i] = deadEnd(far[i]);
+        reaches[i] = g.EdgeObject(cand[i]).size()-(K-1) >= hang;
+        nReach += reaches[i];
+        if ( !reaches[i] && !hanging[i] ) shortTo.push_back(far[i]); }
+      if ( cand.size() != 1 && !shortTo.empty() )
+      { ++hit[12]; if ( nReach ) return false;
+        std::sort(shortTo.begin(),shortTo.end()); shortTo.erase(std::unique(shortTo.begin(),shortTo.end()),shortTo.end());
+        if ( shortTo.size() != 1 ) return false;
+        if ( ( left ? g.ToSize(shortTo.back()) : g.FromSize(shortTo.back()) ) != 1 ) return false; ++hit[13]; }
+      int best = -1; unsigned least = std::numeric_limits<unsigned>::max();
+      for ( size_t i = 0; i != cand.size(); ++i )
+        if ( !hanging[i] || cand.size() == 1 )
+        { unsigned s = score(read,q,hang,g.EdgeObject(cand[i]),K,left);
+          if ( s < least ) { least = s; best = cand[i]; } }
+      if ( best == -1 || least > hang*10 ) { ++hit[ best == -1 ? 14 : 15 ]; return false; }
+      if ( left )
+      { ReadPath longer; longer.setOffset(path.getOffset()+kmersOf(best));
+        longer.push_back(best);
+        for ( int e : path ) longer.push_back(e);
+        path = longer; }
+      else path.push_back(best);
+      return true; }
+
+    // HBVPather::algorithmTwo (:1212-1317) on the parts Pather::path produced
+    void edit( std::vector<Part> parts, bvec const& read, qvec const& q, ReadPath& path ) const
+    { // seeds on short hanging edges become gaps; neighbouring gaps merge
+      std::vector<Part> kept;
+      for ( Part p : parts )
+      { if ( !p.gap() )
+        { int e = hbvEdge(p); int vl = toLeft[e], vr = toRight[e];
+          if ( g.ToSize(vl) == 0 && g.ToSize(vr) > 1 && g.FromSize(vr) > 0 && p.elen <= 100 ) { p = Part::gapOf(p.len); ++hit[0]; } }
+        if ( p.gap() && !kept.empty() && kept.back().gap() ) { kept.back().len += p.len; ++hit[1]; }
+        else kept.push_back(p); }
+      parts.swap(kept);
+      // the first captured gap that the graph does not explain ends the path: with more than one seed before it the seed
+      // in front of it goes too
+      if ( parts.size() >= 3 )
+      { size_t seeds = parts.front().gap() ? 0 : 1;
+        for ( size_t i = 1; i+1 < parts.size(); ++i )
+        { if ( !parts[i].gap() ) { ++seeds; continue; }
+          if ( conforming(parts[i-1],parts[i],parts[i+1]) && joinable(parts[i-1],parts[i+1]) ) { ++hit[2]; continue; }
+          ++hit[ conforming(parts[i-1],parts[i],parts[i+1]) ? 3 : 4 ];
+          if ( seeds > 1 )
+          { ++hit[5]; Part tail = Part::gapOf(parts[i-1].len);
+            for ( size_t j = i; j != parts.size(); ++j ) tail.len += parts[j].len;
+            parts.resize(i-1); parts.push_back(tail); }
+          else
+          { ++hit[6]; for ( size_t j = i+1; j != parts.size(); ++j ) parts[i].len += parts[j].len;
+            parts.resize(i+1); }
+          break; } }
+      // a last seed of at most five k-mers at the very start of its edge is not trusted
+      if ( parts.back().gap() && parts.size() > 1 )
+      { Part const& seed = parts[parts.size()-2];
+        if ( seed.offset() == 0 && seed.len <= 5 )
+        { ++hit[7]; Part merged = parts.back(); merged.len += seed.len;
+          parts.pop_back(); parts.pop_back(); parts.push_back(merged); } }
+      else if ( !parts.back().gap() )
+      { Part& seed = parts.back();
+        if ( seed.offset() == 0 && seed.len <= 5 ) { seed = Part::gapOf(seed.len); ++hit[8]; } }
+      toReadPath(parts,path);
+      // consecutive edges must meet at a vertex
+      for ( size_t i = 0; i+1 < path.size(); ++i )
+        if ( toRight[path[i]] != toLeft[path[i+1]] ) { path.resize(i+1); ++hit[9]; break; }
+      while ( extend(path,read,q,true) ) ++hit[10];
+      while ( extend(path,read,q,false) ) ++hit[11]; }
+};
+
+int paths_main( digraphE<basevector> const& g, vecbvec const& canon, vec<int> const& fwd, vec<int> const& rev, unsigned K,
+                std::string const& readsHead, std::string const& partsFile, std::string const& dir )
+{
+    vecbvec reads; reads.ReadAll((readsHead+".fastb").c_str());
+    VecPQVec quals; quals.ReadAll((readsHead+".qualp").c_str());
+    std::ifstream in(partsFile.c_str(),std::ios::binary);
+    uint64_t n = 0; in.read((char*)&n,8);
+    if ( n != reads.size() ) { fprintf(stderr,"parts.bin holds %lu reads, the input %lu\n",(unsigned long)n,(unsigned long)reads.size()); return 2; }
+    PathGlue pg(g,canon,fwd,rev,K);
+    ReadPathVec paths; paths.reserve(n);
+    std::vector<Part> parts; qvec q; ReadPath path;
+    size_t placed = 0, nEdges = 0;
+    for ( uint64_t r = 0; r != n; ++r )
+    { uint32_t m = 0; in.read((char*)&m,4); parts.resize(m); in.read((char*)parts.data(),16*size_t(m));
+      quals[r].unpack(&q);
+      pg.edit(parts,reads[r],q,path);
+      placed += path.size() != 0; nEdges += path.size();
+      paths.push_back(path); }
+    paths.WriteAll((dir+"/a.paths").c_str());                               // WriteFiles.cc:78-82
+    printf("paths: %lu reads, %zu placed, %zu path edges\n",(unsigned long)n,placed,nEdges);
+    static char const* what[16] = { "seed on a hanging edge dropped", "gaps merged", "captured gap accepted", "captured gap not joinable", "captured gap not conforming",
+        "... cut with the seed before it", "... cut after it", "short last seed before a gap dropped", "short last seed dropped", "path cut at a non-adjacent edge",
+        "left extensions", "right extensions", "short-edge rule consulted", "short-edge rule passed", "no candidate edge", "best score too high" };
+    for ( int i = 0; i != 16; ++i ) printf("paths:   %-40s %zu\n",what[i],pg.hit[i]);
+    return 0;
+}
+
 } // namespace
 
-int graph_main( unsigned K, std::string const& edgesFile, std::string const& dir )
+int graph_main( unsigned K, std::string const& edgesFile, std::string const& dir, std::string const& readsHead, std::string const& partsFile )
 {
     vecbvec edges; edges.ReadAll(edgesFile.c_str());
     size_t const nE = edges.size();
@@ -125,5 +327,6 @@ int graph_main( unsigned K, std::string const& edgesFile, std::string const& dir
     BinaryWriter::writeFile((dir + "/fwd_xlat").c_str(), fwd);
     BinaryWriter::writeFile((dir + "/rev_xlat").c_str(), rev);
     printf("graph: %zu canonical edges -> %d vertices, %d edges\n", nE, g.N(), E);
+    if ( !readsHead.empty() ) return paths_main(g, edges, fwd, rev, K, readsHead, partsFile, dir);
     return 0;
 }

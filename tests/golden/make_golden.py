@@ -82,7 +82,18 @@ def make_hot(seed, n_reads):
     return reads, quals, bci
 
 
-GRAPH_FILES = ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right")
+GRAPH_FILES = ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right", "a.paths")
+
+
+def refdrv(*args):
+    """Run oracle/_ref/refdrv and READ what it prints: a MapReduceEngine run that overflowed a buffer says so
+    ("There were N buffer overflows", MapReduceEngine.h:533-538) and has dropped barcodes -- not a golden run
+    (caveat 2)."""
+    out = subprocess.run([REFDRV, *map(str, args)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if out.returncode != 0 or "buffer overflow" in out.stdout:
+        sys.stderr.write(out.stdout)
+        raise SystemExit(f"refdrv {args[0]}: exit code {out.returncode}" + (", MapReduceEngine buffer overflows" if "buffer overflow" in out.stdout else ""))
+    return out.stdout
 
 
 def make_special(seed):
@@ -114,11 +125,75 @@ def make_special(seed):
     return reads, quals, bci
 
 
+def make_pathy(seed, G=9000, n_pairs=2600):
+    """A diploid genome with SNP bubbles, a diverged repeat family and a tandem repeat; reads of 100-151 bases from both
+    haplotypes and strands, 1 % errors that mostly carry low qualities, some exact duplicates (solid error k-mers: tips)
+    and a few haplotype-switching reads: paths cross several short edges, end in gaps that the extension rules must
+    resolve, and jump between repeat copies."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 4, G, dtype=np.uint8)
+    fam = rng.integers(0, 4, 260, dtype=np.uint8)
+    for s in (1200, 4100, 7000):                              # a diverged repeat family (3 % apart)
+        c = fam.copy(); hit = rng.random(260) < 0.03
+        c[hit] = (c[hit] + rng.integers(1, 4, int(hit.sum()))) & 3
+        a[s:s + 260] = c
+    unit = rng.integers(0, 4, 37, dtype=np.uint8)
+    a[5200:5200 + 37 * 6] = np.tile(unit, 6)                  # a tandem repeat shorter than a read
+    b = a.copy()
+    pos = 300
+    while pos < G - 300:                                      # heterozygous SNPs, some closer than K, some far apart
+        b[pos] = (b[pos] + rng.integers(1, 4)) & 3
+        pos += int(rng.choice([20, 35, 60, 90, 130, 200, 400]))
+    # an exact repeat of K-1 = 47 bases at two loci with different flanks: no k-mer is shared, so the graph does not branch
+    # there -- but a read that enters at one locus and leaves at the other (its switch inside a Q2 tail, where createDict
+    # does not look) steps from the middle of one edge into the middle of another: the adjacency check of algorithmTwo
+    l1, l2 = 2500, 6100
+    for h in (a, b):
+        h[l2:l2 + 47] = h[l1:l1 + 47]
+        for d in (-1, 47):
+            if h[l1 + d] == h[l2 + d]: h[l2 + d] = (h[l2 + d] + 1) & 3
+    haps = (a, b)
+    reads, quals = [], []
+    for p in range(n_pairs):
+        for mate in range(2):
+            L = int(rng.choice([100, 100, 100, 120, 150, 151]))
+            start = int(rng.integers(0, G - L))
+            h = haps[int(rng.integers(0, 2))]
+            r = h[start:start + L].copy()
+            if rng.random() < 0.04:                           # switches haplotype in the middle
+                cut = int(rng.integers(20, L - 20)); r[cut:] = haps[1 - (h is b)][start + cut:start + L]
+            q = rng.choice([37, 37, 37, 35, 30, 25], L).astype(np.uint8)
+            err = rng.random(L) < 0.01
+            if rng.random() < 0.25:
+                err[int(rng.integers(0, L))] = True           # at least one error in a quarter of the reads
+            r[err] = (r[err] + rng.integers(1, 4, int(err.sum()))) & 3
+            lowq = err & (rng.random(L) < 0.7)
+            q[lowq] = rng.choice([2, 2, 8, 12, 15], int(lowq.sum()))
+            if rng.random() < 0.1:
+                t = int(rng.integers(1, 12)); q[L - t:] = 2
+            if rng.random() < 0.5:
+                r = (3 - r[::-1]).astype(np.uint8); q = q[::-1].copy()
+            if rng.random() < 0.06 and reads:                 # an exact duplicate of an earlier read (errors and all)
+                k = int(rng.integers(0, len(reads))); r = reads[k].copy(); q = quals[k].copy()
+            reads.append(r); quals.append(q)
+    for i in range(8):                                        # the switching reads (they replace ordinary ones)
+        q = np.full(100, 37, np.uint8); q[80:] = 2            # the switch lies in the 3' tail that the trim removes
+        if i % 2 == 0: r = np.concatenate([a[l1 - 38 - i:l1 + 47], a[l2 + 47:l2 + 47 + 15 - i]])
+        else: r = (3 - np.concatenate([a[l2 - 15 + i:l2], a[l1:l1 + 85 + i]])[::-1]).astype(np.uint8)
+        assert len(r) == 100
+        reads[40 + 2 * i] = r; quals[40 + 2 * i] = q
+    n_unbar = n_pairs // 10
+    bcs = np.sort(np.concatenate([np.zeros(n_unbar, int), rng.integers(1, 25, n_pairs - n_unbar)]))
+    bci = np.concatenate([[0], np.cumsum(np.bincount(bcs, minlength=25) * 2)]).astype(np.int64)
+    return reads, quals, bci
+
+
 def run_graph(head, out, K, use_bc, min_bc, min_freq, dest):
-    """refdrv graph: dict, then the unipath edges through the real KmerDict and a.<K>/ through the real digraphE."""
+    """refdrv graph: dict, then the unipath edges through the real KmerDict, a.<K>/ through the real digraphE, and a.paths:
+    every read pathed through the real KmerDict / digraphE and written by the real ReadPathVec writer (row f-2)."""
     os.makedirs(out, exist_ok=True)
-    subprocess.check_call([REFDRV, "graph", str(K), head, out, "7", str(min_freq), str(min_bc), str(use_bc), "4", "0"],
-                          stdout=subprocess.DEVNULL)
+    log = refdrv("graph", K, head, out, 7, min_freq, min_bc, use_bc, 4, 0)
+    print("   ", " | ".join(l.strip() for l in log.splitlines() if l.startswith("paths:") and not l.startswith("paths:  ")))
     os.makedirs(dest, exist_ok=True)
     for f in GRAPH_FILES:
         open(os.path.join(dest, f), "wb").write(open(os.path.join(out, f"a.{K}", f), "rb").read())
@@ -130,8 +205,7 @@ def run_graph(head, out, K, use_bc, min_bc, min_freq, dest):
 
 def run_dict(head, out, K, use_bc, min_bc, min_freq=3, ign=0):
     os.makedirs(out, exist_ok=True)
-    subprocess.check_call([REFDRV, "dict", str(K), head, out, "7", str(min_freq), str(min_bc), str(use_bc), "4", str(ign)],
-                          stdout=subprocess.DEVNULL)
+    refdrv("dict", K, head, out, 7, min_freq, min_bc, use_bc, 4, ign)
     post = np.fromfile(out + "/solid.bin", ENTRY)
     kv = open(out + "/kmers.kvec", "rb").read()
     assert kv[:8] == b"BINWRITE"
@@ -230,6 +304,22 @@ def main():
     post, ne = run_graph(sp, os.path.join(HERE, "tmp_gsp"), 48, 0, 0, 3, os.path.join(HERE, "graph_special_k48"))
     np.savez_compressed(os.path.join(HERE, "expect_special_k48_nobc.npz"), solid_post=post)
     print("graph special: solid", len(post), "HBV edges", ne)
+    # Row f-2: an input made for the read pather -- bubbles, tips, repeat copies, a K-1 repeat -- on which every rule of
+    # HBVPather::algorithmTwo and of the two extensions fires (refdrv prints how often; see oracle/ref_graph.cc)
+    reads, quals, bci = make_pathy(5, 9000, 1800)
+    raw = os.path.join(HERE, "pathy.raw")
+    write_raw(raw, reads, quals)
+    pa = os.path.join(HERE, "pathy")
+    subprocess.check_call([REFDRV, "mkreads", raw, pa], stdout=subprocess.DEVNULL)
+    os.remove(raw)
+    feudal.write_bci(pa + ".bci", bci)
+    os.makedirs(os.path.join(HERE, "tmp_rules"), exist_ok=True)
+    open(os.path.join(HERE, "pathy_rules.txt"), "w").write(
+        "".join(l + "\n" for l in refdrv("graph", 48, pa, os.path.join(HERE, "tmp_rules"), 7, 3, 2, 1, 4, 0).splitlines() if l.startswith(("paths:", "graph:"))))
+    subprocess.check_call(["rm", "-rf", os.path.join(HERE, "tmp_rules")])
+    post, ne = run_graph(pa, os.path.join(HERE, "tmp_gpa"), 48, 1, 2, 3, os.path.join(HERE, "graph_pathy_k48"))
+    np.savez_compressed(os.path.join(HERE, "expect_pathy_k48.npz"), solid_post=post)
+    print("graph pathy: solid", len(post), "HBV edges", ne)
 
 
 if __name__ == "__main__":
