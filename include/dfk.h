@@ -59,6 +59,7 @@ typedef struct dfk_config {
 } dfk_config;
 
 #define DFK_F_KEEP_PRE_ADJ   1u   /* also keep contexts before recomputeAdjacencies (kmers.kvec view) */
+#define DFK_F_KEEP_INPUTS    2u   /* dfk_count keeps its device copies of the reads (for dfk_paths_build) until the next count */
 
 /* 32-byte image of KmerDictEntry<K> (kmers/ReadPather.h:105-146,169-195):
  * w0 = bases 0..31 MSB-first, w1 = remaining bases left-aligned (kmers/KMer.h:154-160),
@@ -184,6 +185,28 @@ int dfk_get_stats(dfk_ctx* ctx, dfk_stats* out);
 int dfk_graph_build(dfk_ctx* ctx);
 int dfk_graph_stats(dfk_ctx* ctx, uint64_t* n_canonical_edges, uint64_t* n_vertices, uint64_t* n_edges);
 int dfk_graph_write(dfk_ctx* ctx, const char* dir);
+
+/* ---- read pathing ("correction by pathing") on the graph dfk_graph_build left in the context ----
+ * dfk_paths_build replaces pathReads (paths/long/BuildReadQGraph48.cc:1420-1442) as buildReadQGraph48 calls it
+ * (:1664-1665, with useNewAligner = True from StageBuildGraph, 10X/runstages/RunStages.cc:389-390): every read --
+ * whole, not quality-trimmed -- is looked up k-mer by k-mer in the dictionary and followed along the unipath edges
+ * (Pather::path, :685-733), the parts are edited by the rules of HBVPather::algorithmTwo (:1212-1317) and the path is
+ * extended left and right over read ends that hang beyond it by the quality-weighted scores of ExtendReadPath
+ * (paths/long/ExtendReadPath.cc).  One ReadPath per read: an offset on its first edge and HBV edge ids.
+ *   dfk_paths_build         reads in host memory, laid out as for dfk_count (uploaded, pathed, freed); all five arrays
+ *                           NULL = the reads the last dfk_count uploaded and kept (DFK_F_KEEP_INPUTS)
+ *   dfk_paths_build_device  the same arrays already resident on the context's device
+ *   dfk_paths_write         a.<K>/a.paths as WriteAssemblyFiles writes it (10X/WriteFiles.cc:78-82: ReadPathVec::WriteAll, a feudal
+ *                           file of {i32 offset, u32 lastSkip = 0, i32 edges...}, paths/long/ReadPath.h:56-63) -- byte for byte
+ *   dfk_paths_fetch         offsets[n], first_edge[n+1] (read r's edges are edges[first_edge[r] .. first_edge[r+1])), edges
+ * Needs dfk_graph_build on the same count.  dfk_stats.reserved[3]: microseconds spent pathing. */
+int dfk_paths_build(dfk_ctx* ctx, const uint8_t* packed_bases, const uint64_t* base_off, const uint32_t* read_len,
+              const uint8_t* pq_bytes, const uint64_t* pq_off, uint64_t n_reads);
+int dfk_paths_build_device(dfk_ctx* ctx, const void* d_packed_bases, uint64_t packed_bytes, const void* d_base_off,
+              const void* d_read_len, const void* d_pq_bytes, uint64_t pq_nbytes, const void* d_pq_off, uint64_t n_reads);
+int dfk_paths_stats(dfk_ctx* ctx, uint64_t* n_reads, uint64_t* n_placed, uint64_t* n_path_edges);
+int dfk_paths_write(dfk_ctx* ctx, const char* path);
+int dfk_paths_fetch(dfk_ctx* ctx, int32_t* offsets, uint64_t* first_edge, int32_t* edges, uint64_t edges_cap);
 
 /* ---- multi-GPU pieces (one process per GPU; the caller owns the RCCL exchange) ----
  * The reference's only exchange is MapReduceEngine's thread all-to-all ("swizzle",

@@ -120,6 +120,10 @@ struct dfk_ctx {
     void (*shard_state_free)(void*) = nullptr;
     void* graph_state = nullptr;              // the graph built from the last count (dfk_graph.inc)
     void (*graph_state_free)(void*) = nullptr;
+    // DFK_F_KEEP_INPUTS: the device copies dfk_count made of the caller's reads (hipMalloc, outside the arena), kept for
+    // dfk_paths_build until the next count: packed, base_off, read_len, pq, pq_off, bc
+    void* kept[6] = {};
+    uint64_t kept_packed_bytes = 0, kept_pq_bytes = 0, kept_n_reads = 0, kept_budget = 0;
 
     // Device memory comes from a few large chunks that are kept for the life of the context and managed
     // by first-fit free lists with coalescing.  hipMalloc/hipFree of multi-GB blocks cost milliseconds to
@@ -274,6 +278,11 @@ struct dfk_ctx {
         for (void*& p : sh_staged) if (p) { (void)hipFree(p); p = nullptr; }
         budget += budget_taken; budget_taken = 0;
         if (graph_state) { graph_state_free(graph_state); graph_state = nullptr; }
+    }
+    void drop_kept()
+    {
+        for (void*& p : kept) if (p) { (void)hipFree(p); p = nullptr; }
+        budget += kept_budget; kept_budget = 0; kept_n_reads = 0;
     }
 };
 
@@ -1840,6 +1849,7 @@ void dfk_destroy(dfk_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->release_all();
+    c->drop_kept();
     c->drop_pool();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1874,6 +1884,7 @@ int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const
     if (n_reads && (!packed || !base_off || !read_len || !pq || !pq_off)) return fail(DFK_E_ARG, "null input array");
     HIP_TRY(hipSetDevice(c->device));
     c->release_all();
+    c->drop_kept();
     // (the host tables may sit at any address -- e.g. inside a mapped feudal file -- so they are not dereferenced as u64)
     uint64_t pb = 0, qb = 0;
     if (n_reads) { memcpy(&pb, (const char*)base_off + 8 * n_reads, 8); memcpy(&qb, (const char*)pq_off + 8 * n_reads, 8); }
@@ -1900,8 +1911,15 @@ int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const
         uint64_t saved = c->budget;
         c->budget = c->budget > staged ? c->budget - staged : 0;
         rc = dfk_count_device(c, d_packed, pb, d_boff, d_len, d_pq, qb, d_poff, d_bc, n_reads);
-        c->budget = saved;
         c->st.ms_upload = ms_up;
+        if (!rc && (c->cfg.flags & DFK_F_KEEP_INPUTS)) {
+            // the reads stay on the device for dfk_paths_build, and the arena's budget stays reduced by them
+            void* k[6] = {d_packed, d_boff, d_len, d_pq, d_poff, d_bc};
+            memcpy(c->kept, k, sizeof k);
+            c->kept_packed_bytes = pb; c->kept_pq_bytes = qb; c->kept_n_reads = n_reads; c->kept_budget = saved - c->budget;
+            return 0;
+        }
+        c->budget = saved;
     }
     (void)hipFree(d_packed); (void)hipFree(d_boff); (void)hipFree(d_len); (void)hipFree(d_pq); (void)hipFree(d_poff); (void)hipFree(d_bc);
     return rc;
@@ -2070,3 +2088,4 @@ int dfk_get_stats(dfk_ctx* c, dfk_stats* out)
 
 #include "dfk_shard.inc"
 #include "dfk_graph.inc"
+#include "dfk_paths.inc"

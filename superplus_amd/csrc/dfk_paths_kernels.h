@@ -1,0 +1,398 @@
+// superplus_amd/csrc/dfk_paths_kernels.h -- SURVEY 8(f)-2: read pathing on the device (gfx950, wave64).
+//
+// What the reference does per read in pathReads (paths/long/BuildReadQGraph48.cc:1420-1442, parallelForBatch over
+// HBVPather::algorithmTwo) is done here by one lane per read: dictionary look-ups through the index the edge builder
+// left behind (every entry carries (edge, offset) by then, dfk_graph_kernels.h), base comparisons against the edge store,
+// and the graph rules of algorithmTwo / ExtendReadPath against device copies of the HyperBasevector's tables.  Integer
+// work except one double multiply-subtract per matching base of an extension score (ExtendReadPath.cc:50).  Bound by
+// the latency of dependent random reads (index slot -> entry -> edge bases), like the edge walks.
+//
+// Reference lines each device function follows:
+//   path_parts     Pather::path                         BuildReadQGraph48.cc:685-733   (matchLen :532-541, CF<K>::isRC dna/CanonicalForm.h:84-91)
+//   PartD          EdgeLoc / PathPart                   :593-682
+//   conforming     PathPart::isConformingCapturedGap    :657-666
+//   joinable       Pather::isJoinable                   :796-803
+//   edit_parts     HBVPather::algorithmTwo              :1212-1317 (the part edits)
+//   to_read_path   HBVPather::pathPartsToReadPath       :1365-1402
+//   score_overlap  scoreLeftOverlap / scoreRightOverlap paths/long/ExtendReadPath.cc:15-113
+//   extend_path    attemptLeftward/RightwardExtension   paths/long/ExtendReadPath.cc:130-378
+#pragma once
+#include "dfk_graph_kernels.h"
+
+namespace dfk {
+
+// A path part: `edge` = canonical edge (as numbered by the edge builder), `off` = k-mer offset on the edge in the
+// orientation the read runs along it, stored as ~off when that is the reverse complement (EdgeLoc :596-598), `len` =
+// k-mers covered, `elen` = k-mers on the edge; elen == 0 is a gap, of which only `len` means anything.
+struct PartD { uint32_t edge; int32_t off; uint32_t len, elen; };
+__device__ __forceinline__ bool part_gap(const PartD& p) { return p.elen == 0; }
+__device__ __forceinline__ bool part_rc(const PartD& p) { return p.off < 0; }
+__device__ __forceinline__ uint32_t part_off(const PartD& p) { return p.off < 0 ? (uint32_t)~p.off : (uint32_t)p.off; }
+__device__ __forceinline__ bool part_same_edge(const PartD& a, const PartD& b) { return a.edge == b.edge && part_rc(a) == part_rc(b); }
+__device__ __forceinline__ PartD part_gap_of(uint32_t n) { return PartD{0xFFFFFFFFu, 0, n, 0u}; }
+
+// Device copy of what pathing needs of the HyperBasevector (built on the host by build_hbv, dfk_graph.inc)
+struct PathGraph {
+    const EdgeRec* ce;            // canonical edges: n = k-mers, byte_off = first byte of its bases in `store`
+    const uint8_t* store;         // 2-bit bases, LSB-first, byte aligned per edge
+    const int2* xlat;             // canonical edge -> HBV edge id {forward, reverse complement}  (fwdEdgeXlat / revEdgeXlat)
+    const uint32_t* he_ce;        // HBV edge -> canonical edge << 1 | is reverse complement
+    const int32_t* he_left;       // ToLeft / ToRight
+    const int32_t* he_right;
+    const uint32_t* from_start;   // per vertex, CSR over digraphE's own (sorted) adjacency order: From(v) / FromEdgeObj(v)
+    const int32_t* from_vtx;
+    const int32_t* from_edge;
+    const uint32_t* to_start;     // To(v) / ToEdgeObj(v)
+    const int32_t* to_vtx;
+    const int32_t* to_edge;
+    uint32_t n_ce, n_he, n_v;
+};
+
+__device__ __forceinline__ uint32_t seq_base(const uint8_t* __restrict__ p, uint64_t i) { return (p[i >> 2] >> (2 * (i & 3))) & 3u; }
+
+// a canonical edge read along (rc = false) or against (rc = true) its stored orientation
+struct EdgeView {
+    const uint8_t* p; uint32_t L; bool rc;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return rc ? 3u - seq_base(p, L - 1u - i) : seq_base(p, i); }
+};
+template <int K> __device__ __forceinline__ EdgeView edge_view(const PathGraph& G, uint32_t c, bool rc)
+{ const EdgeRec r = G.ce[c]; return EdgeView{G.store + r.byte_off, r.n + (uint32_t)K - 1u, rc}; }
+template <int K> __device__ __forceinline__ EdgeView hbv_edge_view(const PathGraph& G, int32_t e)
+{ const uint32_t x = G.he_ce[e]; return edge_view<K>(G, x >> 1, (x & 1u) != 0u); }
+__device__ __forceinline__ int32_t hbv_kmers(const PathGraph& G, int32_t e) { return (int32_t)G.ce[G.he_ce[e] >> 1].n; }
+__device__ __forceinline__ uint32_t to_size(const PathGraph& G, int32_t v) { return G.to_start[v + 1] - G.to_start[v]; }
+__device__ __forceinline__ uint32_t from_size(const PathGraph& G, int32_t v) { return G.from_start[v + 1] - G.from_start[v]; }
+__device__ __forceinline__ int32_t part_hbv_edge(const PathGraph& G, const PartD& p) { const int2 x = G.xlat[p.edge]; return part_rc(p) ? x.y : x.x; }
+
+// ---- Pather::path
+// KmerDict::findEntry (kmers/ReadPather.h:222-225) through the edge builder's index: entry index or GRAPH_EMPTY
+template <int K>
+__device__ __forceinline__ uint32_t dict_find(const PartTable& pt, const uint32_t* __restrict__ index, uint64_t mask, u128 v)
+{ uint32_t ctx; bool pal; return graph_lookup<K>(pt, index, mask, v, &ctx, &pal); }
+
+template <int K>
+__device__ uint32_t path_parts(const PartTable& pt, const uint32_t* __restrict__ index, uint64_t mask, const PathGraph& G,
+                               const uint8_t* __restrict__ read, uint32_t n, PartD* __restrict__ parts, unsigned int* __restrict__ bad)
+{
+    if (n < (uint32_t)K) { parts[0] = part_gap_of(n); return 1; }
+    uint32_t np = 0, at = 0;
+    const uint32_t stop = n - K + 1;
+    while (at != stop) {
+        u128 km{0, 0};
+        for (int i = 0; i < K; ++i) km = kmer_succ<K>(km, seq_base(read, at + i));
+        uint32_t hit = dict_find<K>(pt, index, mask, km);
+        if (hit == GRAPH_EMPTY) {
+            uint32_t missed = 1, nxt = at + K;
+            ++at;
+            while (nxt != n) {
+                km = kmer_succ<K>(km, seq_base(read, nxt)); ++nxt;
+                if ((hit = dict_find<K>(pt, index, mask, km)) != GRAPH_EMPTY) break;
+                ++missed; ++at;
+            }
+            parts[np++] = part_gap_of(missed);
+        }
+        if (hit != GRAPH_EMPTY) {
+            const uint4 b = entry_ptr(pt, hit)[1];
+            const uint32_t c = b.x;
+            if (c >= G.n_ce) { atomicOr(bad, 4u); parts[np++] = part_gap_of(stop - at); break; }   // (an entry without an edge: the graph is not the dictionary's)
+            int32_t off = (int32_t)(b.y & 0xFFFFFFu);
+            const EdgeView fw = edge_view<K>(G, c, false);
+            // CF<K>::isRC: at the first position where the read's k-mer differs from its own reverse complement, does it
+            // differ from the edge's k-mer too?  (a palindrome never does)
+            const u128 R = kmer_rc<K>(km);
+            bool rc = false;
+            if (!eq128(R, km)) {
+                const u128 x{km.lo ^ R.lo, km.hi ^ R.hi};
+                const int lead = x.hi ? __clzll((long long)x.hi) : 64 + __clzll((long long)x.lo);     // leading equal bits of the 128-bit words
+                const int i = (lead - (128 - KTraits<K>::BITS)) >> 1;
+                rc = kmer_base<K>(km, i) != fw.at((uint32_t)off + (uint32_t)i);
+            }
+            uint32_t len = 1;
+            if (!rc) {
+                for (uint32_t i = at + K, j = (uint32_t)off + K; i < n && j < fw.L && seq_base(read, i) == fw.at(j); ++i, ++j) ++len;
+            } else {
+                const EdgeView bw{fw.p, fw.L, true};
+                off = (int32_t)fw.L - off;
+                for (uint32_t i = at + K, j = (uint32_t)off; i < n && j < bw.L && seq_base(read, i) == bw.at(j); ++i, ++j) ++len;
+                off -= K;
+            }
+            parts[np++] = PartD{c, rc ? ~off : off, len, fw.L - (uint32_t)K + 1u};
+            at += len;
+        }
+    }
+    return np;
+}
+
+// ---- the part edits of algorithmTwo
+__device__ __forceinline__ bool conforming(const PartD& before, const PartD& gap, const PartD& after)
+{
+    uint32_t dist = part_off(after) - (part_off(before) + before.len);         // all unsigned, as in the reference
+    if (!part_same_edge(before, after)) dist += before.elen;
+    const int32_t d = (int32_t)(gap.len - dist);
+    return (uint32_t)(d < 0 ? -d : d) <= 3u;                                    // HBVPather::MAX_JITTER
+}
+
+template <int K>
+__device__ bool joinable(const PathGraph& G, const PartD& a, const PartD& b)
+{
+    if (a.edge == b.edge) return true;
+    const EdgeView e1 = edge_view<K>(G, a.edge, part_rc(a)), e2 = edge_view<K>(G, b.edge, part_rc(b));
+    for (uint32_t i = 0; i < (uint32_t)K - 1u; ++i)
+        if (e1.at(e1.L - (K - 1) + i) != e2.at(i)) return false;
+    return true;
+}
+
+template <int K>
+__device__ uint32_t edit_parts(const PathGraph& G, PartD* __restrict__ parts, uint32_t np)
+{
+    // seeds on short hanging edges become gaps; neighbouring gaps merge (in place: the write index never passes the read index)
+    uint32_t w = 0;
+    for (uint32_t i = 0; i < np; ++i) {
+        PartD p = parts[i];
+        if (!part_gap(p)) {
+            const int32_t e = part_hbv_edge(G, p), vl = G.he_left[e], vr = G.he_right[e];
+            if (to_size(G, vl) == 0 && to_size(G, vr) > 1 && from_size(G, vr) > 0 && p.elen <= 100u) p = part_gap_of(p.len);
+        }
+        if (part_gap(p) && w && part_gap(parts[w - 1])) parts[w - 1].len += p.len;
+        else parts[w++] = p;
+    }
+    np = w;
+    // the first captured gap the graph does not explain ends the path
+    if (np >= 3) {
+        uint32_t seeds = part_gap(parts[0]) ? 0u : 1u;
+        for (uint32_t i = 1; i + 1 < np; ++i) {
+            if (!part_gap(parts[i])) { ++seeds; continue; }
+            if (conforming(parts[i - 1], parts[i], parts[i + 1]) && joinable<K>(G, parts[i - 1], parts[i + 1])) continue;
+            if (seeds > 1) {
+                uint32_t tail = parts[i - 1].len;
+                for (uint32_t j = i; j < np; ++j) tail += parts[j].len;
+                parts[i - 1] = part_gap_of(tail);
+                np = i;
+            } else {
+                uint32_t more = 0;
+                for (uint32_t j = i + 1; j < np; ++j) more += parts[j].len;
+                parts[i].len += more;
+                np = i + 1;
+            }
+            break;
+        }
+    }
+    // a last seed of at most five k-mers at the very start of its edge is not trusted.  (The part in front of a final gap
+    // can itself be a gap -- the cut above leaves one behind a gap -- and reads as offset 0 like the reference's.)
+    if (part_gap(parts[np - 1]) && np > 1) {
+        const PartD seed = parts[np - 2];
+        if (part_off(seed) == 0 && seed.len <= 5u) { parts[np - 2] = part_gap_of(parts[np - 1].len + seed.len); --np; }
+    } else if (!part_gap(parts[np - 1])) {
+        const PartD seed = parts[np - 1];
+        if (part_off(seed) == 0 && seed.len <= 5u) parts[np - 1] = part_gap_of(seed.len);
+    }
+    return np;
+}
+
+// ---- ExtendReadPath
+// Mismatches cost the base's quality (2 counts as 20) plus a running penalty that every matching base shrinks by a
+// fifth -- `penalty -= pDecay*penalty` on an unsigned with a double on the right: the product and the difference are IEEE
+// doubles, rounded separately (no fused multiply-add), and the result is truncated.  Read bases left over past the edge
+// cost 10 each.
+__device__ __forceinline__ uint32_t decay_penalty(uint32_t penalty)
+{
+#pragma clang fp contract(off)
+    const double p = (double)penalty;
+    const double d = 0.2 * p;
+    return (uint32_t)(p - d);
+}
+
+__device__ uint32_t score_overlap(const uint8_t* __restrict__ read, const uint8_t* __restrict__ q, uint32_t n, uint32_t start,
+                                  const EdgeView& edge, uint32_t K, bool left)
+{
+    uint32_t sum = 0, penalty = 0;
+    int64_t r = left ? (int64_t)start - 1 : (int64_t)n - (int64_t)start;          // read index, moving outwards
+    int64_t e = left ? (int64_t)edge.L - (int64_t)K : (int64_t)K - 1;             // edge index beside the shared K-1 bases
+    const int64_t step = left ? -1 : 1;
+    while (r >= 0 && r < (int64_t)n && e >= 0 && e < (int64_t)edge.L) {
+        if (seq_base(read, (uint64_t)r) != edge.at((uint32_t)e)) { const uint32_t qv = q[r]; penalty += qv == 2u ? 20u : qv; sum += penalty; }
+        else if (penalty > 0) penalty = decay_penalty(penalty);
+        r += step; e += step;
+    }
+    while (r >= 0 && r < (int64_t)n) { sum += 10u; r += step; }
+    return sum;
+}
+
+// PQVecEncoder::decode (feudal/PQVec.cc:129-188) of one read into `out` (n bytes); false if the stream does not hold n values
+__device__ bool decode_quals(const uint8_t* __restrict__ pq, uint64_t p, uint64_t end, uint8_t* __restrict__ out, uint32_t n)
+{
+    uint32_t idx = 0;
+    while (p < end) {
+        const uint32_t nQs = pq[p];
+        if (!nQs) break;
+        if (p + 3 > end) return false;
+        const uint32_t hdr = pq[p + 1] | ((uint32_t)pq[p + 2] << 8);
+        const uint32_t nBits = hdr & 7u, minQ = (hdr >> 3) & 63u;
+        const uint64_t blk = ((uint64_t)nQs * nBits + 24) >> 3;
+        if (p + blk > end || idx + nQs > n) return false;
+        uint64_t bit = 8 * (p + 1) + 9;
+        for (uint32_t i = 0; i < nQs; ++i) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < nBits; ++k, ++bit) v |= ((uint32_t)(pq[bit >> 3] >> (bit & 7)) & 1u) << k;
+            out[idx++] = (uint8_t)(minQ + v);
+        }
+        p += blk;
+    }
+    return idx == n;
+}
+
+// One attempt to extend the path by one edge.  `path` points at the first edge of the path (room in front and behind is
+// the caller's business); returns true when an edge was added: left = true -> *first moved down by one and *offset grown.
+template <int K>
+__device__ bool extend_path(const PathGraph& G, int32_t* __restrict__ path, int32_t* first, int32_t* count, int32_t* offset,
+                            const uint8_t* __restrict__ read, const uint8_t* __restrict__ q, uint32_t n, bool left)
+{
+    if (*count == 0) return false;
+    int64_t hang;
+    if (left) {
+        if (*offset >= 0) return false;
+        hang = -(int64_t)*offset;
+    } else {
+        int32_t h = (int32_t)n + *offset;
+        for (int32_t i = 0; i < *count; ++i) h -= hbv_kmers(G, path[*first + i]);
+        h -= K - 1;
+        hang = h;
+    }
+    if (hang < 10) return false;
+    const int32_t v = left ? G.he_left[path[*first]] : G.he_right[path[*first + *count - 1]];
+    const uint32_t c0 = left ? G.to_start[v] : G.from_start[v], c1 = left ? G.to_start[v + 1] : G.from_start[v + 1];
+    const int32_t* __restrict__ cand = left ? G.to_edge : G.from_edge;
+    const int32_t* __restrict__ far = left ? G.to_vtx : G.from_vtx;
+    const uint32_t nc = c1 - c0;
+    auto dead_end = [&](int32_t w) { return left ? (to_size(G, w) == 0 && from_size(G, w) == 1) : (from_size(G, w) == 0 && to_size(G, w) == 1); };
+    // short edges (they cannot take the whole overhang) that do not hang are followed only when there is nothing longer,
+    // they all lead to one vertex and that vertex has one way on
+    if (nc != 1) {
+        uint32_t n_reach = 0, n_short = 0;
+        int32_t short_to = -1;
+        bool one_dest = true;
+        for (uint32_t i = c0; i < c1; ++i) {
+            const bool hanging = dead_end(far[i]);
+            const bool reaches = (int64_t)hbv_kmers(G, cand[i]) >= hang;             // edge bases - (K-1) >= overhang
+            n_reach += reaches;
+            if (!reaches && !hanging) { if (n_short && far[i] != short_to) one_dest = false; short_to = far[i]; ++n_short; }
+        }
+        if (n_short) {
+            if (n_reach) return false;
+            if (!one_dest) return false;
+            if ((left ? to_size(G, short_to) : from_size(G, short_to)) != 1u) return false;
+        }
+    }
+    int32_t best = -1;
+    uint32_t least = 0xFFFFFFFFu;
+    for (uint32_t i = c0; i < c1; ++i)
+        if (nc == 1 || !dead_end(far[i])) {
+            const uint32_t s = score_overlap(read, q, n, (uint32_t)hang, hbv_edge_view<K>(G, cand[i]), (uint32_t)K, left);
+            if (s < least) { least = s; best = cand[i]; }
+        }
+    if (best == -1 || (uint64_t)least > (uint64_t)hang * 10u) return false;
+    if (left) { --*first; path[*first] = best; *offset += hbv_kmers(G, best); }
+    else path[*first + *count] = best;
+    ++*count;
+    return true;
+}
+
+// Slots: a read of L bases has s = max(1, L-K+1) slots; its parts (<= s), its path (room for 2s+2 edge ids: the path of the
+// parts starts in the middle, leftward extensions grow down, rightward ones up; a path never holds more than s edges) and
+// its decoded qualities (s+K >= L bytes) live in per-batch scratch arrays addressed by the exclusive scan of the slots.
+__global__ void __launch_bounds__(256)
+k_path_slots(const uint32_t* __restrict__ read_len, uint64_t r0, uint64_t nb, uint32_t K, uint64_t* __restrict__ slots)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t L = read_len[r0 + i];
+        slots[i] = L >= K ? L - K + 1 : 1;
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_path_reads(PartTable pt, const uint32_t* __restrict__ index, uint64_t mask, PathGraph G,
+             const uint8_t* __restrict__ packed, const uint64_t* __restrict__ base_off, const uint32_t* __restrict__ read_len,
+             const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, uint64_t r0, uint64_t nb,
+             const uint64_t* __restrict__ slot_off, PartD* __restrict__ parts_all, int32_t* __restrict__ path_all, uint8_t* __restrict__ qual_all,
+             int32_t* __restrict__ out_offset, uint32_t* __restrict__ out_len, uint32_t* __restrict__ out_first,
+             unsigned long long* __restrict__ stats /* [0] reads placed, [1] path edges */, unsigned int* __restrict__ bad)
+{
+    unsigned long long placed = 0, n_edges = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = r0 + i, so = slot_off[i];
+        const uint32_t n = read_len[r], s = (uint32_t)(slot_off[i + 1] - so);
+        const uint8_t* read = packed + base_off[r];
+        PartD* parts = parts_all + so;
+        int32_t* path = path_all + 2 * so + 2 * i;
+        uint8_t* q = qual_all + so + i * K;
+        uint32_t np = path_parts<K>(pt, index, mask, G, read, n, parts, bad);
+        if (np > s) atomicOr(bad, 8u);                                            // (cannot happen: every part covers a k-mer position of its own)
+        np = edit_parts<K>(G, parts, np);
+        // pathPartsToReadPath
+        int32_t first = (int32_t)s + 1, count = 0, offset = 0;
+        {
+            int32_t last = -1;
+            for (uint32_t j = 0; j < np; ++j) {
+                const PartD p = parts[j];
+                if (part_gap(p) || (last >= 0 && part_same_edge(parts[last], p))) continue;
+                path[first + count++] = part_hbv_edge(G, p); last = (int32_t)j;
+            }
+            if (count) offset = !part_gap(parts[0]) ? (int32_t)part_off(parts[0]) : (int32_t)part_off(parts[1]) - (int32_t)parts[0].len;
+        }
+        // consecutive edges must meet at a vertex
+        for (int32_t j = 0; j + 1 < count; ++j)
+            if (G.he_right[path[first + j]] != G.he_left[path[first + j + 1]]) { count = j + 1; break; }
+        if (count) {
+            // the qualities are needed by the extension scores only: decoded once an extension can be attempted at all
+            bool have_q = false;
+            for (int side = 0; side < 2; ++side) {
+                const bool left = side == 0;
+                for (;;) {
+                    int32_t h;
+                    if (left) h = -offset;
+                    else { h = (int32_t)n + offset - (K - 1); for (int32_t j = 0; j < count; ++j) h -= hbv_kmers(G, path[first + j]); }
+                    if (h < 10) break;
+                    // (a path never holds more edges than the read has k-mers: every edge of it covers a k-mer position of
+                    // its own.  That bounds the scratch; an overhang of ten k-mers beside a full path would disprove it.)
+                    if (count >= (int32_t)s) { atomicOr(bad, 8u); break; }
+                    if (!have_q) {
+                        have_q = true;
+                        if (!decode_quals(pq, pq_off[r], pq_off[r + 1], q, n)) { atomicOr(bad, 16u); side = 2; break; }
+                    }
+                    if (!extend_path<K>(G, path, &first, &count, &offset, read, q, n, left)) break;
+                }
+            }
+        }
+        out_offset[i] = offset; out_len[i] = (uint32_t)count; out_first[i] = (uint32_t)first;
+        placed += count != 0; n_edges += (unsigned long long)count;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { placed += __shfl_down(placed, d, 64); n_edges += __shfl_down(n_edges, d, 64); }
+    if ((threadIdx.x & 63) == 0 && (placed | n_edges)) { atomicAdd(&stats[0], placed); atomicAdd(&stats[1], n_edges); }
+}
+
+// a.paths element sizes (ReadPath::writeFeudal, paths/long/ReadPath.h:56-58: i32 offset, u32 lastSkip, the edge ids)
+__global__ void __launch_bounds__(256)
+k_path_sizes(const uint32_t* __restrict__ out_len, uint64_t nb, uint64_t* __restrict__ sizes)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) sizes[i] = 8ull + 4ull * out_len[i];
+}
+
+// the batch's share of the file's variable-length data, and every element's absolute file offset
+__global__ void __launch_bounds__(256)
+k_path_emit(const uint64_t* __restrict__ size_off, const uint64_t* __restrict__ slot_off, const int32_t* __restrict__ path_all,
+            const int32_t* __restrict__ out_offset, const uint32_t* __restrict__ out_len, const uint32_t* __restrict__ out_first,
+            uint64_t nb, uint64_t file_base, uint32_t* __restrict__ var, uint64_t* __restrict__ elem_off)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t at = size_off[i];
+        elem_off[i] = file_base + at;
+        uint32_t* o = var + (at >> 2);
+        o[0] = (uint32_t)out_offset[i]; o[1] = 0u;                               // mLastSkip: never set (ReadPath.h:27-29)
+        const int32_t* p = path_all + 2 * slot_off[i] + 2 * i + out_first[i];
+        for (uint32_t j = 0; j < out_len[i]; ++j) o[2 + j] = (uint32_t)p[j];
+    }
+}
+
+} // namespace dfk

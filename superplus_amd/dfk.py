@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DFK_LIB") or os.path.join(_HERE, "libdfk.so")      # DFK_LIB: a developer's timing variant (tools/)
 ABI_VERSION = 1
 F_KEEP_PRE_ADJ = 1
+F_KEEP_INPUTS = 2
 
 ENTRY_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("edge_id", "<u4"), ("count_ctx", "<u4"),
                         ("bc", "<i4"), ("pad", "<u4")])
@@ -24,6 +25,7 @@ EXPORTS = [
     "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
     "dfk_write_kvec", "dfk_write_kvec_part", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_begin_host", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_partition_begin", "dfk_shard_partition_end", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
+    "dfk_paths_build", "dfk_paths_build_device", "dfk_paths_stats", "dfk_paths_write", "dfk_paths_fetch",
 ]
 
 
@@ -52,6 +54,7 @@ class Stats(C.Structure):
     def asdict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
         d["n_passes"] = int(self.reserved[0])
+        d["us_graph_device"], d["us_graph_host"], d["us_paths"] = int(self.reserved[1]), int(self.reserved[2]), int(self.reserved[3])
         return d
 
 
@@ -89,10 +92,10 @@ class Dfk:
     torch tensors already on this context's device."""
 
     def __init__(self, K=48, min_qual=7, min_freq=3, min_bc=2, ign_bc_below=0, device=0, hbm_budget_bytes=0,
-                 minimizer_len=0, keep_pre_adjacency=False, inst_per_item=0, passes=0):
+                 minimizer_len=0, keep_pre_adjacency=False, inst_per_item=0, passes=0, keep_inputs=False):
         cfg = Config(abi_version=ABI_VERSION, K=K, min_qual=min_qual, min_freq=min_freq, min_bc=min_bc, device=device,
                      ign_bc_below=ign_bc_below, hbm_budget_bytes=hbm_budget_bytes, minimizer_len=minimizer_len,
-                     flags=F_KEEP_PRE_ADJ if keep_pre_adjacency else 0, inst_per_item=inst_per_item)
+                     flags=(F_KEEP_PRE_ADJ if keep_pre_adjacency else 0) | (F_KEEP_INPUTS if keep_inputs else 0), inst_per_item=inst_per_item)
         cfg.reserved[0] = passes          # forced number of bucket-range passes; 0 = sized from the free HBM
         self._ctx = C.c_void_p()
         _check(lib().dfk_create(C.byref(cfg), C.byref(self._ctx)))
@@ -183,6 +186,43 @@ class Dfk:
     def graph_write(self, directory):
         """a.k, a.hbv, a.hbx, a.to_left, a.to_right, a.inv, a.fastb, a.kmers into `directory` (which must exist)."""
         _check(lib().dfk_graph_write(self._ctx, directory.encode()))
+
+    def paths_build(self, packed=None, base_off=None, read_len=None, pq_bytes=None, pq_off=None):
+        """Path every read onto the graph (dfk_graph_build first).  numpy host arrays as for count(); none at all = the reads
+        the last count() uploaded and kept (keep_inputs=True)."""
+        if packed is None:
+            _check(lib().dfk_paths_build(self._ctx, None, None, None, None, None, C.c_uint64(0)))
+        else:
+            packed = np.ascontiguousarray(packed, np.uint8); base_off = np.ascontiguousarray(base_off, np.uint64)
+            read_len = np.ascontiguousarray(read_len, np.uint32); pq_bytes = np.ascontiguousarray(pq_bytes, np.uint8)
+            pq_off = np.ascontiguousarray(pq_off, np.uint64)
+            _check(lib().dfk_paths_build(self._ctx, _p(packed), _p(base_off), _p(read_len), _p(pq_bytes), _p(pq_off), C.c_uint64(len(read_len))))
+        return self.paths_stats()
+
+    def paths_build_device(self, packed, base_off, read_len, pq_bytes, pq_off):
+        """torch tensors on the GPU, as for count_device()."""
+        def dp(t):
+            return C.c_void_p(t.data_ptr())
+        _check(lib().dfk_paths_build_device(self._ctx, dp(packed), C.c_uint64(packed.numel()), dp(base_off), dp(read_len),
+                                            dp(pq_bytes), C.c_uint64(pq_bytes.numel()), dp(pq_off), C.c_uint64(read_len.numel())))
+        return self.paths_stats()
+
+    def paths_stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().dfk_paths_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_reads=a.value, n_placed=b.value, n_path_edges=c.value)
+
+    def paths_write(self, path):
+        """a.paths (feudal file of ReadPath) as WriteAssemblyFiles writes it."""
+        _check(lib().dfk_paths_write(self._ctx, path.encode()))
+
+    def paths(self):
+        """-> (offsets i32[n], first_edge u64[n+1], edges i32[...])"""
+        st = self.paths_stats()
+        off = np.zeros(st["n_reads"], np.int32); first = np.zeros(st["n_reads"] + 1, np.uint64)
+        edges = np.zeros(max(1, st["n_path_edges"]), np.int32)
+        _check(lib().dfk_paths_fetch(self._ctx, _p(off), _p(first), _p(edges), C.c_uint64(len(edges))))
+        return off, first, edges[: st["n_path_edges"]]
 
     def stats(self):
         s = Stats()

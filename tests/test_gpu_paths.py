@@ -1,0 +1,82 @@
+"""SURVEY 8(f)-2 on the GPU: every read pathed on the device (dfk_paths_build) and a.paths written through the ABI, byte
+for byte against (a) the files the reference's own classes produced (tests/golden/graph_*/a.paths; the pathy input reaches
+every rule of algorithmTwo and of the two extensions, tests/golden/pathy_rules.txt) and (b) the Python oracle on seeded reads."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.test_paths_oracle import CASES, decode_paths, load_reads
+
+pytestmark = pytest.mark.gpu
+
+KW = {"graph_k48": dict(min_bc=2), "graph_k40_nobc": dict(min_bc=0, nobc=True), "graph_k60_nobc": dict(min_bc=0, nobc=True),
+      "graph_hot_k48_minfreq2": dict(min_freq=2), "graph_special_k48": dict(min_bc=0, nobc=True), "graph_pathy_k48": dict(min_bc=2)}
+
+
+def explain(got, exp):
+    g, w = decode_paths(got), decode_paths(exp)
+    bad = [i for i, (a, b) in enumerate(zip(g, w)) if a != b]
+    return f"{len(bad)} of {len(w)} reads differ (sizes {len(got)} / {len(exp)}), first {bad[:5]}: got {[g[i] for i in bad[:3]]} want {[w[i] for i in bad[:3]]}"
+
+
+@pytest.mark.parametrize("case,K,npz,which", CASES)
+def test_paths_file_matches_reference_fixture(golden_dir, tmp_path, case, K, npz, which):
+    from superplus_amd.dfk import Dfk
+    rs = load_reads(golden_dir, which)
+    kw = dict(KW[case]); nobc = kw.pop("nobc", False)
+    exp = open(os.path.join(golden_dir, case, "a.paths"), "rb").read()
+    for extra in (dict(), dict(passes=3, inst_per_item=1500, keep_inputs=True)):      # one part / several parts; reads re-uploaded / kept
+        d = Dfk(K=K, **kw, **extra)
+        d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], None if nobc else rs["bc"])
+        d.graph_build()
+        st = d.paths_build() if extra else d.paths_build(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"])
+        out = os.path.join(tmp_path, "a.paths")
+        d.paths_write(out)
+        got = open(out, "rb").read()
+        assert got == exp, f"{case} {extra}: " + explain(got, exp)
+        want = decode_paths(exp)
+        assert st["n_reads"] == len(want) and st["n_placed"] == sum(1 for _, p in want if p) and st["n_path_edges"] == sum(len(p) for _, p in want)
+        off, first, edges = d.paths()
+        assert [(int(o), [int(e) for e in edges[int(a):int(b)]]) for o, a, b in zip(off, first[:-1], first[1:])] == want
+        d.close()
+
+
+@pytest.mark.parametrize("K,seed,G,pairs,kw", [(48, 401, 60000, 4000, dict()), (48, 402, 150000, 15000, dict(passes=4)),
+                                               (40, 403, 80000, 8000, dict()), (60, 404, 80000, 10000, dict())])
+def test_paths_match_oracle_on_synthetic_reads(oracle, tmp_path, K, seed, G, pairs, kw):
+    """reads -> C oracle dictionary -> graph oracle -> paths oracle, against the product's a.paths."""
+    from oracle import graph_oracle, paths_oracle
+    from superplus_amd.dfk import Dfk
+    rs = util.make_set(seed, G, pairs)
+    dkw = dict(kw); passes = dkw.pop("passes", 0)
+    ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=K, **dkw)
+    g = graph_oracle.run(ref["solid"], K)
+    reads, quals = paths_oracle.unpack_reads(rs)
+    exp = paths_oracle.run(reads, quals, g, K)["file"]
+    d = Dfk(K=K, passes=passes, keep_inputs=True, **dkw)
+    d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    d.graph_build()
+    d.paths_build()
+    out = os.path.join(tmp_path, "a.paths")
+    d.paths_write(out)
+    got = open(out, "rb").read()
+    assert got == exp, explain(got, exp)
+    d.close()
+
+
+def test_paths_need_a_graph(oracle):
+    from superplus_amd.dfk import Dfk, DfkError
+    rs = util.make_set(411, 60000, 3000)
+    d = Dfk(K=48)
+    d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    with pytest.raises(DfkError):
+        d.paths_build(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"])     # no graph yet
+    d.graph_build()
+    with pytest.raises(DfkError):
+        d.paths_build()                                                                             # nothing kept: keep_inputs was not set
+    with pytest.raises(DfkError):
+        d.paths_write("/tmp/never")                                                                 # nothing built
+    d.paths_build(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"])
+    d.close()
