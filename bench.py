@@ -93,16 +93,26 @@ def cpu_baseline_and_parity(rs, K, device, what):
                 feudal.write_bci(d + "/s.bci", bci)
                 os.makedirs(d + "/o")
                 threads = min(cores, 32)
-                subprocess.run([refdrv, "dict", str(K), d + "/s", d + "/o", "7", "3", "2", "1", str(threads)],
-                               check=True, stdout=subprocess.DEVNULL, timeout=600)
+                out = subprocess.run([refdrv, "dict", str(K), d + "/s", d + "/o", "7", "3", "2", "1", str(threads)],
+                                     check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
+                # a MapReduceEngine run that overflowed a buffer has dropped barcodes (MapReduceEngine.h:533-538 prints it):
+                # not a reference answer (caveat 2)
+                if "buffer overflow" in out:
+                    raise RuntimeError("the reference's MapReduceEngine reported buffer overflows on this sample")
                 t = dict(line.split() for line in open(d + "/o/times.txt"))
-                secs = sum(float(t[k]) for k in ("goodlens_s", "mr1_s", "mr2_s", "dict_s", "adj_s"))
+                phases = {k: float(t[k]) for k in ("goodlens_s", "mr1_s", "mr2_s", "dict_s", "adj_s")}
+                secs = sum(phases.values())
                 cpu_solid = np.fromfile(d + "/o/solid.bin", ENTRY_DTYPE)
                 cpu_hist = np.loadtxt(d + "/o/spectrum.txt", dtype=np.int64, ndmin=1)
                 base = {"value": float(t["instances"]) / secs, "unit": "k-mers/s", "cores": threads, "kind": "reference",
                         "sample": f"{what} ({t['instances']} k-mer instances); "
                                   "createDict-equivalent = tail scan + 2 MapReduceEngine runs + Dict build + "
-                                  f"recomputeAdjacencies, {secs:.2f} s"}
+                                  f"recomputeAdjacencies, {secs:.2f} s",
+                        # refdrv's own clock per phase (times.txt): the tail scan is single-threaded in the driver (the reference
+                        # runs it under parallelForBatch); mr1 counts the solid k-mers, mr2 collects them
+                        "phases_s": {"goodlens_single_thread": phases["goodlens_s"], "mapreduce_1": phases["mr1_s"], "mapreduce_2": phases["mr2_s"],
+                                     "dict_insert_single_thread": phases["dict_s"], "recompute_adjacencies": phases["adj_s"]},
+                        "value_without_single_threaded_phases": float(t["instances"]) / max(1e-9, phases["mr1_s"] + phases["mr2_s"] + phases["adj_s"])}
         except Exception as e:  # fall through to the port
             print(f"[bench] refdrv baseline failed ({e}); using the C port", file=sys.stderr)
     if base is None:
@@ -216,7 +226,7 @@ def df_stage_wall(args, dev, local):
         torch.cuda.synchronize(); torch.cuda.empty_cache()
         cmd = [os.path.join(ROOT, "superplus_amd", "DF"), f"ROOT={root}", f"LR={root}/reads.fastb", "PIPELINE=cs", "ALIGN=False",
                f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}",
-               "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (ingest + count; --df-graph adds row f-1: edges + HBV + a.<K>/)
+               "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (ingest + count; --df-graph adds rows f-1 and f-2: edges + HBV + read paths -> a.<K>/)
         env = dict(os.environ, DFK_HOST_THREADS=str(min(args.df_threads, 16)))
         if args.df_gpus > 1 or args.df_transport:
             # the C++ multi-GPU host (df_shard.h): DF forks one rank per GPU and moves the records over RCCL itself;
@@ -254,6 +264,8 @@ def df_stage_wall(args, dev, local):
                 "graph": ({"graph_s": timing.get("graph_s"), "device_s": timing.get("graph_device_s"), "host_s": timing.get("graph_host_s"),
                            "write_s": timing.get("graph_write_s"), "edges": timing.get("graph_edges"), "vertices": timing.get("graph_vertices")}
                           if args.df_graph else None),
+                "paths": ({"paths_s": timing.get("paths_s"), "device_s": timing.get("paths_device_s"), "write_s": timing.get("paths_write_s"),
+                           "reads_placed": timing.get("reads_placed"), "path_edges": timing.get("path_edges")} if args.df_graph else None),
                 "host": ("C++ sharded host, %d rank(s), transport %s" % (max(1, args.df_gpus), args.df_transport or "rccl")) if (args.df_gpus > 1 or args.df_transport) else "single GPU (dfk_count)",
                 "shard_times_s": timing.get("shard"),
                 "input_bytes": in_bytes, "output_bytes": out_bytes, "files_on": root, "host_threads": args.df_threads,

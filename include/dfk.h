@@ -266,6 +266,16 @@ int dfk_shard_adj_queries(dfk_ctx* ctx, const void** d_keys,
               uint64_t* send_counts /* [world], in 16-byte keys */);
 int dfk_shard_adj_answer(dfk_ctx* ctx, const void* d_keys, uint64_t n_keys, void* d_present /* u8[n_keys] */);
 int dfk_shard_adj_apply(dfk_ctx* ctx, const void* d_present, uint64_t n_keys);
+/* The whole dictionary on ONE rank, for what the reference does with it after createDict whatever its thread count
+ * (buildEdges, buildHBVFromEdges, pathReads: BuildReadQGraph48.cc:1636,1664): every other rank sends the entries
+ * dfk_shard_dict_share names (32 bytes each, contexts final) to the gathering rank, which receives them into the room
+ * dfk_shard_dict_adopt returns (it first gives back what the run's exchange still held: this rank's staged reads, the
+ * send / receive buffers) and then declares the dictionary whole: from dfk_shard_dict_whole on the context answers as
+ * after a single-GPU count (dfk_solid_count, dfk_write_kvec, dfk_graph_build, dfk_paths_build); the spectrum stays this
+ * rank's share. */
+int dfk_shard_dict_share(dfk_ctx* ctx, const void** d_entries, uint64_t* n_entries);
+int dfk_shard_dict_adopt(dfk_ctx* ctx, uint64_t n_entries, void** d_room);
+int dfk_shard_dict_whole(dfk_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -29,11 +29,14 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <ctime>
 #include <fcntl.h>
 #include <functional>
 #include <exception>
+#include <cerrno>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <sstream>
 #include <string>
@@ -258,11 +261,18 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
               dfkx::LoopbackHub* hub)
 {
     const double t_start = now_s();
+    if (const char* hook = getenv("DF_TEST_RANK_FATE")) {
+        // test hook (tests/test_df_frontend.py): "die:R" -- rank R ends at once as a crashed process would; every other rank
+        // then waits as if inside a collective with no timeout.  What must happen: DF notices and stops them.
+        if (!strncmp(hook, "die:", 4)) { if (atoi(hook + 4) == rank) _exit(134); for (;;) pause(); }
+    }
     try {
         FeudalMap fb, qp;
         fb.open(head + ".fastb"); qp.open(head + ".qualp");
         const std::vector<int64_t> bci = feudal::read_bci(head + ".bci");
         if (qp.n != fb.n || bci.size() < 2 || bci[0] != 0 || (uint64_t)bci.back() != fb.n || fb.n % 2) throw std::runtime_error(head + ": not a LoadData-ordered pair set");
+        // (the ranks read the input by pair range: that is LoadData's order only if every barcode holds whole pairs)
+        for (size_t b = 0; b + 1 < bci.size(); ++b) if (bci[b] > bci[b + 1] || (bci[b + 1] - bci[b]) % 2) throw std::runtime_error(head + ".bci: a barcode with an odd number of reads; NUM_GPUS > 1 needs whole pairs per barcode");
         const uint64_t n_pairs = fb.n / 2, lo = 2 * (n_pairs * (uint64_t)rank / (uint64_t)world), hi = 2 * (n_pairs * (uint64_t)(rank + 1) / (uint64_t)world), n = hi - lo;
         std::vector<int32_t> bc(n, 0);                                                       // DF.cc:447-452 for this rank's reads
         parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t b0, uint64_t b1) {
@@ -315,15 +325,43 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
         const double t_write = now_s() - t0;
         uint64_t done = 1; T->all_reduce(&done, 1, false);                                   // every share is in the file
         dfk_stats st{}; dfk_get_stats(ctx, &st);
+        // ---- buildEdges / buildHBVFromEdges / pathReads run on the whole dictionary whatever built it (BuildReadQGraph48.cc:
+        //      1636,1664): the shares go to rank 0, which builds a.<K>/ as the single-GPU run does
+        double t_gather = 0, t_graph = 0, t_paths = 0;
+        uint64_t g_e = 0, g_v = 0, p_placed = 0;
+        if (truthy(a["GRAPH"])) {
+            t0 = now_s();
+            dfkx::shard_gather_dict(ctx, *T, 0, piece);
+            t_gather = now_s() - t0;
+            if (rank == 0) {
+                t0 = now_s();
+                printf("%s: finding edge sequences.\n", date().c_str());
+                if (dfk_graph_build(ctx)) throw std::runtime_error(dfk_last_error());
+                const std::string dir = work_dir + "/a." + std::to_string(K);
+                mkpath(dir);
+                if (dfk_graph_write(ctx, dir.c_str())) throw std::runtime_error(dfk_last_error());
+                dfk_graph_stats(ctx, nullptr, &g_v, &g_e);
+                t_graph = now_s() - t0;
+                if (truthy(a["PATHS"])) {
+                    t0 = now_s();
+                    printf("%s: pathing reads\n", date().c_str());
+                    if (dfk_paths_build(ctx, fb.m.p, (const uint64_t*)fb.off_table(), (const uint32_t*)fb.fixed(), qp.m.p, (const uint64_t*)qp.off_table(), fb.n))
+                        throw std::runtime_error(dfk_last_error());
+                    if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());
+                    dfk_paths_stats(ctx, nullptr, &p_placed, nullptr);
+                    t_paths = now_s() - t0;
+                }
+            }
+        }
         T.reset();
         dfk_destroy(ctx);
         if (rank == 0) {
             printf("%s: dictionary covers %llu kmers\n", date().c_str(), (unsigned long long)total);
             printf("DF_TIMING {\"ranks\": %d, \"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"rank0\": {\"upload_trim_s\": %.3f, \"plan_s\": %.3f, "
                    "\"partition_s\": %.3f, \"exchange_wait_s\": %.3f, \"count_s\": %.3f, \"adjacency_s\": %.3f, \"create_dict_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, "
-                   "\"bytes_sent_to_peers\": %llu, \"passes\": %u, \"rank_total_s\": %.3f}}\n", world, (unsigned long long)fb.n, (unsigned long long)inst,
+                   "\"bytes_sent_to_peers\": %llu, \"passes\": %u, \"gather_dict_s\": %.3f, \"graph_s\": %.3f, \"paths_s\": %.3f, \"graph_edges\": %llu, \"reads_placed\": %llu, \"rank_total_s\": %.3f}}\n", world, (unsigned long long)fb.n, (unsigned long long)inst,
                    (unsigned long long)total, t_begin, tm.plan, tm.partition, tm.exchange_wait, tm.count, tm.adjacency, tm.total, t_write,
-                   (unsigned long long)tm.bytes_sent, tm.n_passes, now_s() - t_start);
+                   (unsigned long long)tm.bytes_sent, tm.n_passes, t_gather, t_graph, t_paths, (unsigned long long)g_e, (unsigned long long)p_placed, now_s() - t_start);
         }
         return 0;
     } catch (const dfkx::ShardError& e) {
@@ -336,6 +374,48 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
     }
 }
 
+// The rank processes of `DF NUM_GPUS=N`, watched from the moment they exist.  A rank that dies (a GPU fault, the OOM
+// killer, a failed ncclCommInitRank) leaves its peers inside a collective that has no timeout: the first child that exits
+// badly takes the others with it -- SIGTERM, then SIGKILL after a grace period -- and DF exits non-zero.
+struct ChildWatch {
+    std::vector<pid_t> live;                          // (guarded by mu once start() has been called)
+    std::mutex mu; std::thread th; int worst = 0; bool started = false;
+    static constexpr int GRACE_MS = 5000;
+    void kill_all(int sig = SIGTERM) { std::lock_guard<std::mutex> g(mu); for (pid_t p : live) kill(p, sig); }
+    void start()
+    {
+        started = true;
+        th = std::thread([this] {
+            bool killing = false; auto deadline = std::chrono::steady_clock::now();
+            for (;;) {
+                { std::lock_guard<std::mutex> g(mu); if (live.empty()) return; }
+                int st = 0;
+                const pid_t pid = waitpid(-1, &st, killing ? WNOHANG : 0);
+                if (pid < 0 && errno != EINTR) return;                        // no children left
+                if (pid > 0) {
+                    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+                    bool mine = false;
+                    { std::lock_guard<std::mutex> g(mu); auto it = std::find(live.begin(), live.end(), pid); if (it != live.end()) { live.erase(it); mine = true; } }
+                    if (!mine) continue;
+                    if (code && !killing) {
+                        worst = code;
+                        fprintf(stderr, "DF: a rank process ended with status %d; stopping the others\n", code);
+                        kill_all(SIGTERM);
+                        killing = true; deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(GRACE_MS);
+                    }
+                    continue;
+                }
+                if (killing) {
+                    if (std::chrono::steady_clock::now() > deadline) { kill_all(SIGKILL); deadline += std::chrono::hours(1); }
+                    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+                }
+            }
+        });
+    }
+    int join() { if (started && th.joinable()) th.join(); return worst; }
+    ~ChildWatch() { if (started && th.joinable()) { kill_all(SIGKILL); th.join(); } }
+};
+
 } // namespace
 
 int main(int argc, char** argv)
@@ -345,7 +425,7 @@ int main(int argc, char** argv)
     std::map<std::string, std::string> a = {
         {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
         {"OUT_DIR", ""}, {"LR", ""}, {"LR_SELECT_FRAC", "1.0"}, {"EXIT_LOAD", "False"}, {"DEVICE", "0"}, {"MAX_MEM_GB", "0"},
-        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "True"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}, {"NUM_GPUS", "1"}};
+        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "True"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}, {"PATHS", "True"}, {"NUM_GPUS", "1"}};
     std::string command = "DF";
     for (int i = 1; i < argc; ++i) {
         std::string s = argv[i]; command += " " + s;
@@ -386,14 +466,19 @@ int main(int argc, char** argv)
     const bool loopback = getenv("DF_TRANSPORT") && std::string(getenv("DF_TRANSPORT")) == "loopback";
     if ((num_gpus & (num_gpus - 1)) || num_gpus > 64) give_up("NUM_GPUS must be a power of two (the owner of a minimizer bucket is its low bits)");
     if (getenv("DF_RANK")) return rank_main(a, K, work_dir, heads[0], atoi(getenv("DF_RANK")), atoi(getenv("DF_WORLD")), nullptr);
-    std::vector<pid_t> children;
-    if (num_gpus > 1 || getenv("DF_FORCE_SHARDED")) {
+    // EXIT_LOAD (DF.cc:483) stops after the ingest: no rank is spawned for it
+    const bool sharded = (num_gpus > 1 || getenv("DF_FORCE_SHARDED")) && !truthy(a["EXIT_LOAD"]);
+    ChildWatch watch;
+    std::vector<pid_t>& children = watch.live;
+    if (sharded) {
+        // the ranks read the one input by pair range: LoadData's order must be the input's (one LR input, every pair kept)
         if (heads.size() != 1) give_up("NUM_GPUS > 1 takes one LR input");
+        for (double f : select_frac) if (f < 1.0) give_up("NUM_GPUS > 1 needs LR_SELECT_FRAC = 1 (the ranks count the input as it is)");
         if (!loopback) {
             unlink((work_dir + "/.dfk_rccl_id").c_str());
             for (int r = 0; r < num_gpus; ++r) {
                 const pid_t pid = fork();
-                if (pid < 0) give_up("cannot fork");
+                if (pid < 0) { watch.kill_all(); give_up("cannot fork"); }
                 if (pid == 0) {
                     setenv("DF_RANK", std::to_string(r).c_str(), 1); setenv("DF_WORLD", std::to_string(num_gpus).c_str(), 1);
                     execv("/proc/self/exe", argv);
@@ -401,15 +486,10 @@ int main(int argc, char** argv)
                 }
                 children.push_back(pid);
             }
+            watch.start();
         }
     }
-    const bool sharded = num_gpus > 1 || getenv("DF_FORCE_SHARDED");
-    auto wait_children = [&]() -> int {
-        int worst = 0;
-        for (pid_t pid : children) { int st = 0; if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st)) worst = std::max(worst, 1); else worst = std::max(worst, WEXITSTATUS(st)); }
-        children.clear();
-        return worst;
-    };
+    auto wait_children = [&]() -> int { return watch.join(); };
     Timing T;
     try {
         // ---- LoadData (10X/DfTools.cc:69-170): unbarcoded pairs of every input first, then barcoded pairs
@@ -575,12 +655,12 @@ int main(int argc, char** argv)
             background.clear();
             if (bg_failed) std::rethrow_exception(bg_err);
         };
-        if (truthy(a["EXIT_LOAD"]) && !sharded) { join_background(); return 0; } // DF.cc:483
+        if (truthy(a["EXIT_LOAD"])) { join_background(); return 0; }             // DF.cc:483
         if (sharded) {
             // the ranks are counting (or, loopback, start now); this process has done the ingest
             int rc = 0;
+            if (!fast) throw std::runtime_error("NUM_GPUS > 1 needs one LR input with LR_SELECT_FRAC = 1 and whole pairs per barcode");
             if (loopback) {
-                if (!fast) throw std::runtime_error("NUM_GPUS > 1 needs one LR input with LR_SELECT_FRAC = 1");
                 dfkx::LoopbackHub hub(num_gpus, [](void* d, const void* s_, uint64_t nbytes) { if (hipMemcpy(d, s_, nbytes, hipMemcpyDeviceToDevice) != hipSuccess) throw std::runtime_error("device copy failed"); });
                 std::vector<int> rcs(num_gpus, 0);
                 std::vector<std::thread> th;
@@ -605,6 +685,8 @@ int main(int argc, char** argv)
         cfg.device = atoi(a["DEVICE"].c_str()); cfg.ign_bc_below = 0;           // bc_start = 0 for LR-only input (DF.cc:344-349)
         cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
         cfg.hbm_budget_bytes = (uint64_t)(atof(a["HBM_GB"].c_str()) * 1073741824.0);   // 0 = 90 % of the free HBM; MAX_MEM_GB is host memory
+        const bool want_paths = truthy(a["GRAPH"]) && truthy(a["PATHS"]);
+        if (want_paths) cfg.flags |= DFK_F_KEEP_INPUTS;                          // the reads stay on the device for pathReads
         dfk_ctx* ctx = nullptr;
         if (dfk_create(&cfg, &ctx)) { fprintf(stderr, "DF: %s\n", dfk_last_error()); join_background(); return 1; }
         printf("%s: building dictionary on the GPU\n", date().c_str());
@@ -627,8 +709,8 @@ int main(int argc, char** argv)
         T.fetch_write = now_s() - t0;
         // ---- buildEdges + buildHBVFromEdges + the graph files of WriteAssemblyFiles (BuildReadQGraph48.cc:1636,1664;
         //      10X/WriteFiles.cc:69-101): a.<K>/{a.k,a.hbv,a.hbx,a.to_left,a.to_right,a.inv,a.fastb,a.kmers}
-        double t_graph = 0, t_g_dev = 0, t_g_host = 0, t_g_write = 0;
-        uint64_t g_ce = 0, g_v = 0, g_e = 0;
+        double t_graph = 0, t_g_dev = 0, t_g_host = 0, t_g_write = 0, t_paths = 0, t_p_dev = 0, t_p_write = 0;
+        uint64_t g_ce = 0, g_v = 0, g_e = 0, p_placed = 0, p_edges = 0;
         if (truthy(a["GRAPH"])) {
             t0 = now_s();
             printf("%s: finding edge sequences.\n", date().c_str());
@@ -642,6 +724,19 @@ int main(int argc, char** argv)
             t_g_write = now_s() - tw;
             dfk_graph_stats(ctx, &g_ce, &g_v, &g_e);
             t_graph = now_s() - t0;
+            if (want_paths) {
+                // pathReads (BuildReadQGraph48.cc:1664-1665) and a.<K>/a.paths (10X/WriteFiles.cc:78-82)
+                t0 = now_s();
+                printf("%s: pathing reads\n", date().c_str());
+                if (dfk_paths_build(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) throw std::runtime_error(dfk_last_error());
+                { dfk_stats ps{}; dfk_get_stats(ctx, &ps); t_p_dev = 1e-6 * (double)ps.reserved[3]; }
+                const double tw2 = now_s();
+                printf("%s: writing paths\n", date().c_str());
+                if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());
+                t_p_write = now_s() - tw2;
+                dfk_paths_stats(ctx, nullptr, &p_placed, &p_edges);
+                t_paths = now_s() - t0;
+            }
         }
         dfk_destroy(ctx);
         join_background();
@@ -652,13 +747,14 @@ int main(int argc, char** argv)
         // one machine-readable line (bench.py reads it): where the stage's wall time went
         printf("DF_TIMING {\"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"threads\": %u, \"open_validate_s\": %.3f, "
                "\"ingest_outputs_s\": %.3f, \"upload_s\": %.3f, \"count_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, \"graph_s\": %.3f, \"graph_device_s\": %.3f, \"graph_host_s\": %.3f, \"graph_write_s\": %.3f, "
-               "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"total_s\": %.3f, \"fast_path\": %s}\n",
+               "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"paths_s\": %.3f, \"paths_device_s\": %.3f, \"paths_write_s\": %.3f, \"reads_placed\": %llu, \"path_edges\": %llu, \"total_s\": %.3f, \"fast_path\": %s}\n",
                (unsigned long long)n_reads, (unsigned long long)st.n_inst, (unsigned long long)nk, g_threads, T.read, T.ingest_out,
-               T.upload, T.count, T.fetch_write, t_graph, t_g_dev, t_g_host, t_g_write, (unsigned long long)g_e, (unsigned long long)g_v, T.total, fast ? "true" : "false");
+               T.upload, T.count, T.fetch_write, t_graph, t_g_dev, t_g_host, t_g_write, (unsigned long long)g_e, (unsigned long long)g_v,
+               t_paths, t_p_dev, t_p_write, (unsigned long long)p_placed, (unsigned long long)p_edges, T.total, fast ? "true" : "false");
         { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); printf("DF_EXIT_EPOCH %.3f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());
-        for (pid_t pid : children) kill(pid, SIGTERM);
+        watch.kill_all();
         (void)wait_children();
         return 1;
     }

@@ -164,9 +164,16 @@ inline void shard_create_dict(dfk_ctx* ctx, Transport& T, uint64_t n_inst_local,
     T.all_gather(sc.data(), w, all.data());
     uint64_t n_q = 0, n_in = 0;
     for (int s = 0; s < w; ++s) { rc[s] = all[(size_t)s * w + r]; n_in += rc[s]; n_q += sc[s]; if (s != r) times->bytes_sent += 17 * sc[s]; }
+    // the round trip's buffers: 17 bytes per incoming query and 1 per outgoing one, beside a context that may hold most
+    // of the HBM -- a rank that cannot get them says so BEFORE anybody enters the exchange (the peers would wait in it)
     void *d_in = nullptr, *d_ans = nullptr, *d_back = nullptr;
-    DFKX_HIP(hipMalloc(&d_in, 16 * n_in + 16)); DFKX_HIP(hipMalloc(&d_ans, n_in + 16)); DFKX_HIP(hipMalloc(&d_back, n_q + 16));
+    auto room = [&](void** p, uint64_t bytes) {
+        if (pending) return;
+        if (hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; pending = DFK_E_NOMEM; pending_msg = "no room on the device for " + std::to_string(bytes) + " bytes of adjacency queries"; }
+    };
+    room(&d_in, 16 * n_in + 16); room(&d_ans, n_in + 16); room(&d_back, n_q + 16);
     try {
+        agree("the adjacency buffers");
         all_to_all_v(T, keys, sc.data(), d_in, rc.data(), 16, piece);
         note(dfk_shard_adj_answer(ctx, d_in, n_in, d_ans));
         agree("dfk_shard_adj_answer");
@@ -177,6 +184,33 @@ inline void shard_create_dict(dfk_ctx* ctx, Transport& T, uint64_t n_inst_local,
     (void)hipFree(d_in); (void)hipFree(d_ans); (void)hipFree(d_back);
     times->adjacency += secs(t0);
     times->total = secs(t_all);
+}
+
+
+// After shard_create_dict: every rank's share of the dictionary to rank `root` (one all-to-all whose only non-empty
+// slices point at the root), which then holds the whole dictionary and answers as after a single-GPU count
+// (dfk_graph_build, dfk_paths_build).  Returns the number of solid k-mers of the whole run.
+inline uint64_t shard_gather_dict(dfk_ctx* ctx, Transport& T, int root, uint64_t piece)
+{
+    const int w = T.world, r = T.rank;
+    const void* mine = nullptr; uint64_t n_mine = 0;
+    int pending = dfk_shard_dict_share(ctx, &mine, &n_mine);
+    std::string pending_msg = pending ? dfk_last_error() : "";
+    std::vector<uint64_t> all(w);
+    T.all_gather(&n_mine, 1, all.data());
+    std::vector<uint64_t> sc(w, 0), rc(w, 0);
+    uint64_t total = 0, incoming = 0;
+    for (int s = 0; s < w; ++s) { total += all[s]; if (r == root && s != root) { rc[s] = all[s]; incoming += all[s]; } }
+    if (r != root) sc[root] = n_mine;
+    void* roomp = nullptr;
+    if (r == root && !pending) { pending = dfk_shard_dict_adopt(ctx, incoming, &roomp); if (pending) pending_msg = dfk_last_error(); }
+    uint64_t worst = pending ? (uint64_t)(-pending) : 0;
+    T.all_reduce(&worst, 1, true);
+    if (pending) throw ShardError(pending, pending_msg);
+    if (worst) throw ShardError(-(int)worst, "another rank failed gathering the dictionary; this rank stops with it");
+    all_to_all_v(T, mine, sc.data(), roomp, rc.data(), 32, piece);
+    if (r == root && dfk_shard_dict_whole(ctx)) throw ShardError(DFK_E_STATE, dfk_last_error());
+    return total;
 }
 
 } // namespace dfkx

@@ -456,8 +456,9 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     } else { rc = table_totals(c, T->acc, nb, &T->n_records, &T->n_inst); if (rc) return rc; }
     TRACE("partition count pass done (%llu buckets, %llu records)", (unsigned long long)nb, (unsigned long long)T->n_records);
     if (T->n_inst != n_inst)
-        return fail(DFK_E_HIP, "partition count pass saw %llu instances, trim saw %llu",
-                    (unsigned long long)T->n_inst, (unsigned long long)n_inst);
+        return fail(DFK_E_HIP, "partition count pass saw %llu instances, trim saw %llu%s",
+                    (unsigned long long)T->n_inst, (unsigned long long)n_inst,
+                    (n_inst - T->n_inst) % (1ull << 32) == 0 ? " (a fine bucket with 2^32 or more instances: its counter keeps 32 bits)" : "");
     c->st.n_records = T->n_records; c->st.n_buckets = nb;
     return 0;
 }
@@ -1087,7 +1088,9 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
             const uint64_t inst = val[2 * i + 1] - val[2 * i];
             const uint64_t guess = (uint64_t)((double)inst * dpi) + 1;
             const uint32_t p = ceil_log2((guess + 699) / 700);
-            if (p >= split_from_p && p <= 22) { sp_b.push_back(singles[i]); sp_i.push_back(inst); sp_p.push_back(p); sp_at.push_back(i); }
+            // (k_hot_pass keeps a record's place inside its hot bucket in 32 bits: a bucket of 2^32 instances or more -- whatever
+            // its distinct k-mers -- takes the HBM tables)
+            if (p >= split_from_p && p <= 22 && inst < (1ull << 32)) { sp_b.push_back(singles[i]); sp_i.push_back(inst); sp_p.push_back(p); sp_at.push_back(i); }
         }
         std::vector<uint8_t> taken(n, 0);
         // The expanded records of the split buckets (32 B per instance: 30 GB for a pass of a human-scale set with a 10 %

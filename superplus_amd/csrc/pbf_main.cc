@@ -52,6 +52,7 @@ struct Fastq {                               // one file: per read its barcode, 
     std::vector<uint8_t> bases, quals;       // concatenated
     std::vector<uint64_t> off{0};            // [n+1] into bases / quals
     std::string error;
+    uint64_t counted = 0;                    // bases already added to g_held
 };
 
 // "...#b1_b2_b3/1\t..." -> b1*1537^2 + b2*1537 + b3  (10X/Barcode.cc:3-13: three integers, one separator character each)
@@ -67,6 +68,20 @@ bool barcode_of(const char* line, int64_t* out)
     const long c = strtol(p, &e, 10); if (e == p) return false;
     *out = (int64_t)a * 1537 * 1537 + (int64_t)b * 1537 + c;
     return true;
+}
+
+// Memory: this program holds BOTH decompressed files (a byte per base and a byte per quality) and then the encoded reads
+// twice while it writes -- about 3.5 bytes per base plus ~100 per read, where the reference bounds its own use by
+// re-reading the inputs once per barcode bucket (10X/ParseBarcodedFastqs.cc:434-449).  g_mem_limit (MAX_MEM_GB, or the
+// machine's memory) is checked while the files are read and before the encode: a set that does not fit ends with a
+// message, not with the kernel's OOM killer.
+std::atomic<uint64_t> g_held{0};
+uint64_t g_mem_limit = 0;
+bool over_budget(uint64_t bases, uint64_t reads) { return g_mem_limit && 7 * bases / 2 + 100 * reads > g_mem_limit; }
+std::string budget_message(uint64_t bases, uint64_t reads)
+{
+    return "this input needs about " + std::to_string((7 * bases / 2 + 100 * reads) >> 30) + " GiB (3.5 bytes per base + 100 per read: the decompressed reads are held in "
+           "memory), more than the " + std::to_string(g_mem_limit >> 30) + " GiB allowed (MAX_MEM_GB, or the machine's memory); run it on a machine with more memory or split the input";
 }
 
 void read_fastq(const std::string& path, Fastq* f)
@@ -95,6 +110,12 @@ void read_fastq(const std::string& path, Fastq* f)
         f->bc.push_back(bc);
         f->off.push_back(f->bases.size());
         if (!f->error.empty()) break;
+        if ((f->bc.size() & 0xFFFF) == 0) {                                           // (both reader threads add to one total)
+            const uint64_t mine = f->bases.size();
+            const uint64_t all = g_held.fetch_add(mine - f->counted) + (mine - f->counted);
+            f->counted = mine;
+            if (over_budget(all, 0)) { f->error = "stopped reading " + path + ": " + budget_message(all, 0); break; }
+        }
     }
     gzclose(g);
 }
@@ -172,6 +193,11 @@ int main(int argc, char** argv)
     if (!threads) threads = std::max(1u, std::thread::hardware_concurrency());
     threads = std::min(threads, 64u);
 
+    {   // MAX_MEM_GB as the reference means it (a cap on host memory, system/System.cc:1073-1078); 0 = what the machine has
+        const double gb = atof(a["MAX_MEM_GB"].c_str());
+        const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
+        g_mem_limit = gb > 0 ? std::min<uint64_t>(phys, (uint64_t)(gb * 1073741824.0)) : phys;
+    }
     // ---- both files, one thread each
     Fastq f1, f2;
     { std::thread t(read_fastq, fq[1], &f2); read_fastq(fq[0], &f1); t.join(); }
@@ -181,6 +207,7 @@ int main(int argc, char** argv)
     const size_t n_pairs = f1.bc.size();
     for (size_t i = 0; i < n_pairs; ++i) if (f1.bc[i] != f2.bc[i]) die("something not match with pair file: " + fq[0] + " or " + fq[1]);
     fprintf(stderr, "total reads: %zu\n", 2 * n_pairs);
+    if (over_budget(f1.bases.size() + f2.bases.size(), 2 * n_pairs)) die(budget_message(f1.bases.size() + f2.bases.size(), 2 * n_pairs));
 
     // ---- buckets of barcodes (:311-336): the distinct barcodes in the container's iteration order, cut into equal runs
     std::unordered_set<int64_t> bc_set;

@@ -135,7 +135,7 @@ def test_df_end_to_end_on_gpu(tmp_path, golden_dir, oracle):
     for ext in ("fastb", "qualp", "bci"):
         assert rd(f"{tmp_path}/w/data/frag_reads_orig.{ext}") == rd(f"{golden_dir}/reads.{ext}"), ext
     # a.48/: the graph files WriteAssemblyFiles writes, against the reference-written fixture
-    for f in ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right"):
+    for f in ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right", "a.paths"):
         assert rd(f"{tmp_path}/w/a.48/{f}") == rd(f"{golden_dir}/graph_k48/{f}"), f
 
 
@@ -205,6 +205,36 @@ def test_df_num_gpus_cpp_host(tmp_path, golden_dir, oracle, mode):
     for ext in ("fastb", "qualp", "bci"):
         assert rd(f"{w}/data/frag_reads_orig.{ext}") == rd(f"{golden_dir}/reads.{ext}"), ext
     assert "DF_TIMING {" in r.stdout and f"dictionary covers {len(exp['solid_post'])}" in r.stdout.replace(",", "")
+    # GRAPH defaults to True: the shares are gathered on rank 0, which builds a.48/ -- graph and read paths -- as a single-GPU run does
+    for f in ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right", "a.paths"):
+        assert rd(f"{w}/a.48/{f}") == rd(f"{golden_dir}/graph_k48/{f}"), f
+
+
+def test_df_stops_every_rank_when_one_dies(tmp_path, golden_dir):
+    """`DF NUM_GPUS=4` with rank 2 dying at once and the others waiting for ever (as ranks do inside a collective whose peer
+    is gone): DF must notice, end the others and exit non-zero -- not wait for the first pid in order.  CPU only: the ranks
+    stop before they would touch a GPU."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([DF, f"ROOT={tmp_path}", f"LR={golden_dir}/reads.fastb", "NUM_GPUS=4", "NUM_THREADS=2"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, DF_TEST_RANK_FATE="die:2"))
+    assert r.returncode != 0, r.stdout + r.stderr
+    assert time.time() - t0 < 60
+    assert "a rank process ended with status" in r.stderr
+    out = subprocess.run(["pgrep", "-f", f"ROOT={tmp_path}"], capture_output=True, text=True).stdout.split()
+    assert not out, f"rank processes left behind: {out}"
+
+
+def test_df_sharded_refuses_what_it_cannot_shard(tmp_path, golden_dir):
+    """NUM_GPUS > 1 reads the one input by pair range: a subsampled or multi-input run is refused before any rank is spawned."""
+    r = run_df(f"ROOT={tmp_path}", f"LR={golden_dir}/reads.fastb", "NUM_GPUS=2", "LR_SELECT_FRAC=0.5")
+    assert r.returncode != 0 and "LR_SELECT_FRAC" in (r.stdout + r.stderr)
+    r = run_df(f"ROOT={tmp_path}", "LR={" + f"{golden_dir}/reads.fastb,{golden_dir}/reads.fastb" + "}", "NUM_GPUS=2")
+    assert r.returncode != 0 and "one LR input" in (r.stdout + r.stderr)
+    # EXIT_LOAD stops after the ingest whatever NUM_GPUS says: no rank is spawned, the files are there
+    r = run_df(f"ROOT={tmp_path}", f"LR={golden_dir}/reads.fastb", "NUM_GPUS=2", "EXIT_LOAD=True")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.exists(f"{tmp_path}/GapToy/1/data/frag_reads_orig.fastb")
 
 
 @pytest.mark.gpu
@@ -217,7 +247,7 @@ def test_df_num_gpus_larger_set_equals_single_gpu(tmp_path, oracle):
     feudal.write_fastb(f"{tmp_path}/r.fastb", rs["packed"], rs["base_off"], rs["read_len"])
     feudal.write_qualp(f"{tmp_path}/r.qualp", rs["pq_bytes"], rs["pq_off"])
     feudal.write_bci(f"{tmp_path}/r.bci", rs["bci"])
-    a = subprocess.run([DF, f"OUT_DIR={tmp_path}/one", f"LR={tmp_path}/r.fastb", "GRAPH=False", "HBM_GB=16"], capture_output=True, text=True, timeout=600)
+    a = subprocess.run([DF, f"OUT_DIR={tmp_path}/one", f"LR={tmp_path}/r.fastb", "HBM_GB=16"], capture_output=True, text=True, timeout=600)
     assert a.returncode == 0, a.stdout + a.stderr
     b = subprocess.run([DF, f"OUT_DIR={tmp_path}/four", f"LR={tmp_path}/r.fastb", "NUM_GPUS=4", "HBM_GB=4"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, DF_TRANSPORT="loopback"))
@@ -226,3 +256,5 @@ def test_df_num_gpus_larger_set_equals_single_gpu(tmp_path, oracle):
     util.assert_same_solid(_sorted_kvec(f"{tmp_path}/four/kmers.kvec"), _sorted_kvec(f"{tmp_path}/one/kmers.kvec"), "four ranks against one GPU")
     ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
     util.assert_same_solid(_sorted_kvec(f"{tmp_path}/four/kmers.kvec"), ref["solid"], "four ranks against the oracle")
+    for f in ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right", "a.paths"):      # gathered on rank 0 = built on one GPU
+        assert open(f"{tmp_path}/four/a.48/{f}", "rb").read() == open(f"{tmp_path}/one/a.48/{f}", "rb").read(), f

@@ -49,19 +49,17 @@ def test_graph_files_match_reference_fixtures(golden_dir, tmp_path, case, K, kw,
 
 
 @pytest.mark.parametrize("K,seed,G,pairs,kw", [(48, 301, 60000, 3000, dict()), (48, 302, 300000, 40000, dict(passes=4)),
-                                               (40, 303, 80000, 8000, dict()), (60, 304, 80000, 10000, dict()),
-                                               (48, 305, 50000, 5000, dict(min_freq=1, min_bc=0))])
+                                               (40, 303, 80000, 8000, dict()), (60, 304, 80000, 10000, dict())])
 def test_graph_matches_oracle_on_synthetic_reads(oracle, tmp_path, K, seed, G, pairs, kw):
-    """reads -> C oracle dictionary -> graph oracle, against the product's files.  (min_freq = 1 skips
-    recomputeAdjacencies, BuildReadQGraph48.cc:313: contexts then name neighbours that may be absent.)"""
+    """reads -> C oracle dictionary -> graph oracle, against the product's files.  (Not with min_freq = 1: that skips
+    recomputeAdjacencies, BuildReadQGraph48.cc:313, contexts then name neighbours that may be absent and the reference's
+    edge builder asserts on them -- not a graph input.)"""
     from oracle import graph_oracle
     from superplus_amd.dfk import Dfk
     rs = util.make_set(seed, G, pairs)
     dkw = dict(kw)
     passes = dkw.pop("passes", 0)
     ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=K, **dkw)
-    if dkw.get("min_freq", 3) == 1:
-        pytest.skip("min_freq = 1: the reference's edge builder asserts on contexts naming absent k-mers; not a graph input")
     exp = graph_oracle.run(ref["solid"], K)["files"]
     d = Dfk(K=K, passes=passes, **dkw)
     d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])

@@ -80,3 +80,13 @@ def test_output_feeds_the_df_front_end(tmp_path):
                          "ALIGN=False", "NUM_THREADS=4", "MAX_MEM_GB=640", "EXIT_LOAD=True"], capture_output=True, text=True)
     assert df.returncode == 0, df.stdout + df.stderr
     same_files(f"{tmp_path}/tmp/GapToy/1/data/frag_reads_orig", f"{tmp_path}/tmp/reads")
+
+
+def test_refuses_an_input_that_does_not_fit_max_mem_gb(tmp_path):
+    """The decompressed reads are held in memory (unlike the reference, which re-reads per bucket): a set that does not fit
+    MAX_MEM_GB ends with a message saying so, not with the OOM killer."""
+    from tests.fastq_synth import make_fastq
+    make_fastq(f"{tmp_path}/a_1.fq.gz", f"{tmp_path}/a_2.fq.gz", 3000, 5, n_bc=6)
+    r = subprocess.run([OURS, "FASTQS={" + f"{tmp_path}/a_1.fq.gz,{tmp_path}/a_2.fq.gz" + "}", f"OUT_HEAD={tmp_path}/o", "NUM_BUCKETS=2", "MAX_MEM_GB=0.0005"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "MAX_MEM_GB" in r.stderr and not os.path.exists(f"{tmp_path}/o.fastb")
