@@ -15,6 +15,11 @@ What it restates (all reference paths relative to lib/assembly/src):
   paths/long/ReadPath.h:56-63                 the a.paths element: i32 offset, u32 lastSkip (always 0), i32 edge ids
   10X/WriteFiles.cc:78-82                     a.paths = ReadPathVec::WriteAll (feudal file, header bytes 0/24/4)
 
+  10X/PathsIndex.cc:23-146                    writePathsIndex: a.paths.inv (per edge the reads whose path holds it, ascending; a read
+                                              that crosses the edge twice is listed twice) and a.countsb (reads per edge, an edge
+                                              and its involution summed)
+  10X/SecretOps.cc:410-566                    MarkDups: a.dup
+
 Pinned by tests/golden/*/a.paths (written by oracle/_ref/refdrv graph: the reference's KmerDict::findEntry, KMer,
 CF<K>::isRC, bvec iterators, digraphE<basevector> and the ReadPathVec feudal writer; glue restated in
 oracle/ref_driver.cc and oracle/ref_graph.cc) in tests/test_paths_oracle.py.
@@ -298,3 +303,50 @@ def run(reads, quals, graph, K):
     p = Pather(graph, K)
     paths = [p.read_path(r, q) for r, q in zip(reads, quals)]
     return dict(paths=paths, file=paths_file(paths))
+
+
+# ----------------------------------------------------------------------------------------------- row f-4
+def paths_index(paths, inv):
+    """writePathsIndex (10X/PathsIndex.cc:23-146) -> {"a.paths.inv": bytes, "a.countsb": bytes}.  inv = the graph's
+    involution (a.inv).  (The reference walks the edges in 30 chunks and overruns below ~870 edges; this is what it writes
+    when it does not.)"""
+    n_edges = len(inv)
+    pairs = sorted((e, i) for i, (_, p) in enumerate(paths) for e in p)
+    lists = [[] for _ in range(n_edges)]
+    for e, i in pairs:
+        lists[e].append(i)
+    var = b"".join(np.asarray(l, "<u8").tobytes() for l in lists)
+    offs = np.concatenate([[0], np.cumsum([8 * len(l) for l in lists])]).astype(np.uint64) + np.uint64(24)
+    var_tab = 24 + len(var)
+    head = struct.pack("<IBBBBQQ", n_edges, 1, 0, 16, 8, var_tab, var_tab + 8 * (n_edges + 1))       # feudal file of SerfVec<unsigned long>
+    counts = [len(l) for l in lists]
+    for e in range(n_edges):
+        if e < inv[e]:
+            counts[e] = counts[inv[e]] = counts[e] + counts[inv[e]]
+    countsb = b"BINWRITE" + struct.pack("<QQ", 1, n_edges) + np.asarray(counts, "<i4").tobytes()       # vec<vec<int>> with one row
+    return {"a.paths.inv": head + var + offs.astype("<u8").tobytes(), "a.countsb": countsb}
+
+
+def mark_dups(paths, reads, quals):
+    """MarkDups (10X/SecretOps.cc:410-566) -> bytes of a.dup (vec<Bool>, one per PAIR).  Reads with the same first edge, the
+    same offset on it and the same first five bases of their MATE are one group; the member whose pair has the largest
+    quality sum stays (the lowest read id among equals), the pairs of the others are marked."""
+    n = len(paths)
+    groups = {}
+    for i, (off, p) in enumerate(paths):
+        if not p:
+            continue
+        head = 0
+        for b in reads[i ^ 1][:5]:
+            head = 4 * head + b
+        groups.setdefault((p[0], off, head), []).append(i)
+    dup = np.zeros(n // 2, np.uint8)
+    qsum = lambda i: int(np.asarray(quals[i], np.int64).sum() + np.asarray(quals[i ^ 1], np.int64).sum())
+    for ids in groups.values():
+        if len(ids) < 2:
+            continue
+        best = max(ids, key=lambda i: (qsum(i), -i))
+        for i in ids:
+            if i != best:
+                dup[i // 2] = 1
+    return b"BINWRITE" + struct.pack("<Q", n // 2) + dup.tobytes()

@@ -20,12 +20,24 @@
 //                                               10X/runstages/RunStages.cc:389-390)
 //   paths/long/BuildReadQGraph48.cc:657-666,796-803,1365-1402   isConformingCapturedGap, isJoinable, pathPartsToReadPath
 //   paths/long/ExtendReadPath.cc:15-333         the two overlap scorers and the left / right extension
+// Row f-4 follows on the same ReadPathVec: the inverted paths index and the duplicate marks, written by the real
+// IncrementalWriter<ULongVec> (feudal/IncrementalWriter.h) and BinaryWriter; restated glue:
+//   10X/PathsIndex.cc:23-146      writePathsIndex: (edge, read) pairs sorted, one list of read ids per edge in edge order
+//                                 (a.paths.inv); reads per edge, summed with the involuted edge's (a.countsb).  The
+//                                 reference walks the edges in PI_CHUNKS = 30 chunks and overruns when the graph has fewer
+//                                 than ~870 edges (`e != emax` with i * chunk_size > num_edges, SURVEY 8c caveat 1); what it
+//                                 writes when it does not crash is what is written here, for any number of edges.
+//   10X/SecretOps.cc:410-566      MarkDups: reads with the same first edge, offset and first five bases of the MATE are
+//                                 duplicates of each other; the one whose pair has the highest quality sum (the lowest
+//                                 read id among equals) stays, the others' pairs are marked (a.dup)
 // Input: the canonical unipath edges (edges.fastb, written by ref_driver.cc's buildEdges glue through the real Dict).
 #include "Basevector.h"
 #include "feudal/BinaryStream.h"
 #include "graph/Digraph.h"
 #include "graph/DigraphTemplate.h"
 #include "paths/long/ReadPath.h"
+#include "feudal/IncrementalWriter.h"
+#include "Intvector.h"
 #include "feudal/PQVec.h"
 #include "Qualvector.h"
 #include "math/Hash.h"
@@ -216,7 +228,7 @@ struct PathGlue
 };
 
 int paths_main( digraphE<basevector> const& g, vecbvec const& canon, vec<int> const& fwd, vec<int> const& rev, unsigned K,
-                std::string const& readsHead, std::string const& partsFile, std::string const& dir )
+                std::string const& readsHead, std::string const& partsFile, std::string const& dir, vec<int> const* pInv )
 {
     vecbvec reads; reads.ReadAll((readsHead+".fastb").c_str());
     VecPQVec quals; quals.ReadAll((readsHead+".qualp").c_str());
@@ -234,6 +246,48 @@ int paths_main( digraphE<basevector> const& g, vecbvec const& canon, vec<int> co
       placed += path.size() != 0; nEdges += path.size();
       paths.push_back(path); }
     paths.WriteAll((dir+"/a.paths").c_str());                               // WriteFiles.cc:78-82
+    {   // ---- writePathsIndex (10X/PathsIndex.cc:23-146), as DF.cc:550 calls it on the paths StageBuildGraph returned
+        int const nEdges = g.EdgeObjectCount();
+        std::vector<std::pair<int,unsigned long>> where;
+        for ( uint64_t id = 0; id != n; ++id ) for ( int e : paths[id] ) where.push_back(std::make_pair(e,(unsigned long)id));
+        std::sort(where.begin(),where.end());
+        vec<vec<int>> counts(1,vec<int>(nEdges,0));
+        {   IncrementalWriter<ULongVec> w((dir+"/a.paths.inv").c_str());
+            size_t j = 0;
+            for ( int e = 0; e != nEdges; ++e )
+            { ULongVec ids;
+              while ( j != where.size() && where[j].first == e ) ids.push_back(where[j++].second);
+              w.add(ids); counts[0][e] = ids.size(); }
+            w.close(); }
+        vec<int> const& inv = *pInv;
+        for ( int e = 0; e != nEdges; ++e )
+          if ( e < inv[e] ) { int both = counts[0][e]+counts[0][inv[e]]; counts[0][e] = both; counts[0][inv[e]] = both; }
+        BinaryWriter::writeFile((dir+"/a.countsb").c_str(),counts); }
+    {   // ---- MarkDups (10X/SecretOps.cc:410-566); `art`, the share of artifactual duplicates, is a statistic and not a file
+        struct X { int e, off, head; int64_t id; };
+        std::vector<X> xs(n);
+        for ( uint64_t id = 0; id != n; ++id )
+        { uint64_t mate = id^1ul;
+          if ( paths[id].size() == 0 ) { xs[id] = X{-1,-1,-1,-1}; continue; }
+          int head = 0; for ( int j = 0; j != 5; ++j ) head = 4*head+reads[mate][j];
+          xs[id] = X{paths[id][0],paths[id].getOffset(),head,int64_t(id)}; }
+        std::sort(xs.begin(),xs.end(),[]( X const& a, X const& b )
+          { if ( a.e != b.e ) return a.e < b.e; if ( a.off != b.off ) return a.off < b.off; if ( a.head != b.head ) return a.head < b.head; return a.id < b.id; });
+        auto qsumOf = [&]( int64_t id ) { int s = 0; quals[id].unpack(&q); for ( unsigned char v : q ) s += v; quals[id^1].unpack(&q); for ( unsigned char v : q ) s += v; return s; };
+        vec<Bool> dup(n/2,False);
+        size_t groups = 0;
+        for ( size_t j = 0; j < xs.size(); )
+        { size_t k = j+1;
+          while ( k < xs.size() && xs[k].e == xs[j].e && xs[k].off == xs[j].off && xs[k].head == xs[j].head ) ++k;
+          if ( xs[j].e >= 0 && k-j > 1 )
+          { ++groups;
+            size_t best = j; int top = qsumOf(xs[j].id);
+            for ( size_t l = j+1; l != k; ++l ) { int s = qsumOf(xs[l].id); if ( s > top ) { top = s; best = l; } }     // ties: the earlier (lower id) stays
+            for ( size_t l = j; l != k; ++l ) if ( l != best ) dup[xs[l].id/2] = True; }
+          j = k; }
+        BinaryWriter::writeFile((dir+"/a.dup").c_str(),dup);
+        size_t nd = 0; for ( Bool b : dup ) nd += b;
+        printf("dups: %zu groups, %zu of %lu pairs marked\n",groups,nd,(unsigned long)(n/2)); }
     printf("paths: %lu reads, %zu placed, %zu path edges\n",(unsigned long)n,placed,nEdges);
     static char const* what[16] = { "seed on a hanging edge dropped", "gaps merged", "captured gap accepted", "captured gap not joinable", "captured gap not conforming",
         "... cut with the seed before it", "... cut after it", "short last seed before a gap dropped", "short last seed dropped", "path cut at a non-adjacent edge",
@@ -327,6 +381,6 @@ int graph_main( unsigned K, std::string const& edgesFile, std::string const& dir
     BinaryWriter::writeFile((dir + "/fwd_xlat").c_str(), fwd);
     BinaryWriter::writeFile((dir + "/rev_xlat").c_str(), rev);
     printf("graph: %zu canonical edges -> %d vertices, %d edges\n", nE, g.N(), E);
-    if ( !readsHead.empty() ) return paths_main(g, edges, fwd, rev, K, readsHead, partsFile, dir);
+    if ( !readsHead.empty() ) return paths_main(g, edges, fwd, rev, K, readsHead, partsFile, dir, &inv);
     return 0;
 }

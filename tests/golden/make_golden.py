@@ -188,14 +188,49 @@ def make_pathy(seed, G=9000, n_pairs=2600):
     return reads, quals, bci
 
 
-def run_graph(head, out, K, use_bc, min_bc, min_freq, dest):
+def make_frag(seed, G=26000, n_pairs=3000):
+    """A fragmented graph (a SNP every ~70 bases of a diploid genome: more than 870 HBV edges, below which the reference's
+    writePathsIndex overruns) read by PAIRS of 100 bases with inserts of 250-400, a tenth of the pairs PCR duplicates of an
+    earlier pair: same bases, qualities drawn again (so the pair with the higher quality sum stays) or kept (a tie: the
+    earlier pair stays)."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 4, G, dtype=np.uint8)
+    b = a.copy()
+    pos = 200
+    while pos < G - 200:
+        b[pos] = (b[pos] + rng.integers(1, 4)) & 3
+        pos += int(rng.choice([30, 50, 70, 90, 140]))
+    haps = (a, b)
+    reads, quals = [], []
+    for p in range(n_pairs):
+        if p > 10 and rng.random() < 0.10:                               # a duplicate of an earlier pair
+            k = int(rng.integers(0, p))
+            r1, r2 = reads[2 * k].copy(), reads[2 * k + 1].copy()
+            if rng.random() < 0.3: q1, q2 = quals[2 * k].copy(), quals[2 * k + 1].copy()
+            else: q1, q2 = (np.full(100, rng.choice([37, 35, 30, 25]), np.uint8) for _ in range(2))
+        else:
+            ins = int(rng.integers(250, 400)); start = int(rng.integers(0, G - ins)); h = haps[int(rng.integers(0, 2))]
+            r1 = h[start:start + 100].copy(); r2 = (3 - h[start + ins - 100:start + ins][::-1]).astype(np.uint8)
+            if rng.random() < 0.5: r1, r2 = r2, r1
+            q1, q2 = (np.full(100, rng.choice([37, 37, 35, 30]), np.uint8) for _ in range(2))
+            for r, q in ((r1, q1), (r2, q2)):
+                err = rng.random(100) < 0.004
+                r[err] = (r[err] + rng.integers(1, 4, int(err.sum()))) & 3; q[err] = 12
+        reads += [r1, r2]; quals += [q1, q2]
+    n_unbar = n_pairs // 10
+    bcs = np.sort(np.concatenate([np.zeros(n_unbar, int), rng.integers(1, 31, n_pairs - n_unbar)]))
+    bci = np.concatenate([[0], np.cumsum(np.bincount(bcs, minlength=31) * 2)]).astype(np.int64)
+    return reads, quals, bci
+
+
+def run_graph(head, out, K, use_bc, min_bc, min_freq, dest, extra=()):
     """refdrv graph: dict, then the unipath edges through the real KmerDict, a.<K>/ through the real digraphE, and a.paths:
     every read pathed through the real KmerDict / digraphE and written by the real ReadPathVec writer (row f-2)."""
     os.makedirs(out, exist_ok=True)
     log = refdrv("graph", K, head, out, 7, min_freq, min_bc, use_bc, 4, 0)
-    print("   ", " | ".join(l.strip() for l in log.splitlines() if l.startswith("paths:") and not l.startswith("paths:  ")))
+    print("   ", " | ".join(l.strip() for l in log.splitlines() if l.startswith(("paths:", "dups:")) and not l.startswith("paths:  ")))
     os.makedirs(dest, exist_ok=True)
-    for f in GRAPH_FILES:
+    for f in GRAPH_FILES + tuple(extra):
         open(os.path.join(dest, f), "wb").write(open(os.path.join(out, f"a.{K}", f), "rb").read())
     post = np.fromfile(out + "/solid.bin", ENTRY)
     n_edges = int(np.frombuffer(open(os.path.join(dest, "a.kmers"), "rb").read()[8:16], "<u8")[0])
@@ -320,6 +355,19 @@ def main():
     post, ne = run_graph(pa, os.path.join(HERE, "tmp_gpa"), 48, 1, 2, 3, os.path.join(HERE, "graph_pathy_k48"))
     np.savez_compressed(os.path.join(HERE, "expect_pathy_k48.npz"), solid_post=post)
     print("graph pathy: solid", len(post), "HBV edges", ne)
+    # Row f-4: a fragmented graph (more than 870 edges: below that the reference's writePathsIndex overruns, SURVEY 8c caveat 1)
+    # read by pairs with PCR duplicates: a.paths.inv, a.countsb, a.dup
+    reads, quals, bci = make_frag(9, 26000, 3000)
+    raw = os.path.join(HERE, "frag.raw")
+    write_raw(raw, reads, quals)
+    fr = os.path.join(HERE, "frag")
+    subprocess.check_call([REFDRV, "mkreads", raw, fr], stdout=subprocess.DEVNULL)
+    os.remove(raw)
+    feudal.write_bci(fr + ".bci", bci)
+    post, ne = run_graph(fr, os.path.join(HERE, "tmp_gfr"), 48, 1, 2, 3, os.path.join(HERE, "graph_frag_k48"), extra=("a.paths.inv", "a.countsb", "a.dup"))
+    np.savez_compressed(os.path.join(HERE, "expect_frag_k48.npz"), solid_post=post)
+    assert ne >= 870
+    print("graph frag: solid", len(post), "HBV edges", ne)
 
 
 if __name__ == "__main__":

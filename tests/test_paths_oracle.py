@@ -14,7 +14,8 @@ from tests.test_oracle_golden import load_hot, load_inputs
 # (fixture dir, K, expected dictionary, which reads)
 CASES = [("graph_k48", 48, "expect_k48.npz", "reads"), ("graph_k40_nobc", 40, "expect_k40_nobc.npz", "reads"),
          ("graph_k60_nobc", 60, "expect_k60_nobc.npz", "reads"), ("graph_hot_k48_minfreq2", 48, "expect_hot_k48_minfreq2.npz", "hot"),
-         ("graph_special_k48", 48, "expect_special_k48_nobc.npz", "special"), ("graph_pathy_k48", 48, "expect_pathy_k48.npz", "pathy")]
+         ("graph_special_k48", 48, "expect_special_k48_nobc.npz", "special"), ("graph_pathy_k48", 48, "expect_pathy_k48.npz", "pathy"),
+         ("graph_frag_k48", 48, "expect_frag_k48.npz", "frag")]
 
 
 def load_named(golden_dir, name):
@@ -78,3 +79,20 @@ def test_score_truncates_like_unsigned_minus_double():
         edge2 = bytes([1, 0, 1] + [0] * 60)
         q2 = np.array([q0, 30, 10] + [30] * 17, np.uint8)
         assert paths_oracle.Pather.score(read, q2, 20, edge2, 1, False) == q0 + after + 10
+
+
+def test_paths_index_and_dups_match_reference_files(golden_dir):
+    """Row f-4 on the fragmented fixture (1816 edges: the reference's own writePathsIndex needs more than ~870): a.paths.inv
+    and a.countsb as IncrementalWriter<ULongVec> / BinaryWriter wrote them, a.dup as BinaryWriter wrote it."""
+    solid = np.load(os.path.join(golden_dir, "expect_frag_k48.npz"))["solid_post"]
+    g = graph_oracle.run(solid, 48)
+    reads, quals = paths_oracle.unpack_reads(load_reads(golden_dir, "frag"))
+    r = paths_oracle.run(reads, quals, g, 48)
+    inv = g["hbv"].involution()
+    assert len(inv) >= 870
+    files = paths_oracle.paths_index(r["paths"], inv)
+    files["a.dup"] = paths_oracle.mark_dups(r["paths"], reads, quals)
+    for f, b in files.items():
+        assert b == open(os.path.join(golden_dir, "graph_frag_k48", f), "rb").read(), f
+    d = np.frombuffer(files["a.dup"], np.uint8, offset=16)
+    assert 100 < d.sum() < len(d) // 2                         # the fixture really holds duplicate pairs
