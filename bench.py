@@ -265,7 +265,8 @@ def df_stage_wall(args, dev, local):
                            "write_s": timing.get("graph_write_s"), "edges": timing.get("graph_edges"), "vertices": timing.get("graph_vertices")}
                           if args.df_graph else None),
                 "paths": ({"paths_s": timing.get("paths_s"), "device_s": timing.get("paths_device_s"), "write_s": timing.get("paths_write_s"),
-                           "reads_placed": timing.get("reads_placed"), "path_edges": timing.get("path_edges")} if args.df_graph else None),
+                           "reads_placed": timing.get("reads_placed"), "path_edges": timing.get("path_edges"),
+                           "paths_index_s": timing.get("paths_index_s"), "mark_dups_s": timing.get("mark_dups_s"), "dup_pairs": timing.get("dup_pairs")} if args.df_graph else None),
                 "host": ("C++ sharded host, %d rank(s), transport %s" % (max(1, args.df_gpus), args.df_transport or "rccl")) if (args.df_gpus > 1 or args.df_transport) else "single GPU (dfk_count)",
                 "shard_times_s": timing.get("shard"),
                 "input_bytes": in_bytes, "output_bytes": out_bytes, "files_on": root, "host_threads": args.df_threads,

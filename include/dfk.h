@@ -208,6 +208,17 @@ int dfk_paths_stats(dfk_ctx* ctx, uint64_t* n_reads, uint64_t* n_placed, uint64_
 int dfk_paths_write(dfk_ctx* ctx, const char* path);
 int dfk_paths_fetch(dfk_ctx* ctx, int32_t* offsets, uint64_t* first_edge, int32_t* edges, uint64_t edges_cap);
 
+/* ---- the two steps DF takes right after StageBuildGraph (10X/DF.cc:550,560), on the paths dfk_paths_build made ----
+ * dfk_paths_index_write  writePathsIndex (10X/PathsIndex.cc:23-146): dir/a.paths.inv -- per HBV edge the reads whose path holds
+ *                        it, ascending (a stable radix sort of the (edge, read) pairs on the device; a feudal file of unsigned
+ *                        long lists) -- and dir/a.countsb (reads per edge, an edge and its involution summed).  Defined for any
+ *                        graph; the reference itself overruns below ~870 edges (caveat 1).
+ * dfk_dups_write         MarkDups (10X/SecretOps.cc:410-566): a.dup, one byte per PAIR -- reads with the same first edge, offset
+ *                        and first five bases of their mate are duplicates; the one whose pair has the highest quality sum (the
+ *                        lowest read id among equals) stays.  Grouped in a hash table on the device instead of sorted. */
+int dfk_paths_index_write(dfk_ctx* ctx, const char* dir);
+int dfk_dups_write(dfk_ctx* ctx, const char* path, uint64_t* n_marked_pairs);
+
 /* ---- multi-GPU pieces (one process per GPU; the caller owns the RCCL exchange) ----
  * The reference's only exchange is MapReduceEngine's thread all-to-all ("swizzle",
  * MapReduceEngine.h:345-388): every key goes to the thread that owns hash % T.  Here every

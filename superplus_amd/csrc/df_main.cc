@@ -349,6 +349,7 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
                         throw std::runtime_error(dfk_last_error());
                     if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());
                     dfk_paths_stats(ctx, nullptr, &p_placed, nullptr);
+                    if (dfk_paths_index_write(ctx, dir.c_str()) || dfk_dups_write(ctx, (dir + "/a.dup").c_str(), nullptr)) throw std::runtime_error(dfk_last_error());
                     t_paths = now_s() - t0;
                 }
             }
@@ -709,8 +710,8 @@ int main(int argc, char** argv)
         T.fetch_write = now_s() - t0;
         // ---- buildEdges + buildHBVFromEdges + the graph files of WriteAssemblyFiles (BuildReadQGraph48.cc:1636,1664;
         //      10X/WriteFiles.cc:69-101): a.<K>/{a.k,a.hbv,a.hbx,a.to_left,a.to_right,a.inv,a.fastb,a.kmers}
-        double t_graph = 0, t_g_dev = 0, t_g_host = 0, t_g_write = 0, t_paths = 0, t_p_dev = 0, t_p_write = 0;
-        uint64_t g_ce = 0, g_v = 0, g_e = 0, p_placed = 0, p_edges = 0;
+        double t_graph = 0, t_g_dev = 0, t_g_host = 0, t_g_write = 0, t_paths = 0, t_p_dev = 0, t_p_write = 0, t_index = 0, t_dups = 0;
+        uint64_t g_ce = 0, g_v = 0, g_e = 0, p_placed = 0, p_edges = 0, n_dup = 0;
         if (truthy(a["GRAPH"])) {
             t0 = now_s();
             printf("%s: finding edge sequences.\n", date().c_str());
@@ -736,6 +737,14 @@ int main(int argc, char** argv)
                 t_p_write = now_s() - tw2;
                 dfk_paths_stats(ctx, nullptr, &p_placed, &p_edges);
                 t_paths = now_s() - t0;
+                // writePathsIndex and MarkDups, the two steps DF takes right after StageBuildGraph (10X/DF.cc:550,560)
+                t0 = now_s();
+                printf("%s: inverting paths index\n", date().c_str());
+                if (dfk_paths_index_write(ctx, dir.c_str())) throw std::runtime_error(dfk_last_error());
+                t_index = now_s() - t0; t0 = now_s();
+                if (dfk_dups_write(ctx, (dir + "/a.dup").c_str(), &n_dup)) throw std::runtime_error(dfk_last_error());
+                t_dups = now_s() - t0;
+                printf("%.2f%% of pairs appear to be duplicates\n", n_reads ? 100.0 * (double)n_dup / (double)(n_reads / 2) : 0.0);
             }
         }
         dfk_destroy(ctx);
@@ -747,10 +756,10 @@ int main(int argc, char** argv)
         // one machine-readable line (bench.py reads it): where the stage's wall time went
         printf("DF_TIMING {\"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"threads\": %u, \"open_validate_s\": %.3f, "
                "\"ingest_outputs_s\": %.3f, \"upload_s\": %.3f, \"count_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, \"graph_s\": %.3f, \"graph_device_s\": %.3f, \"graph_host_s\": %.3f, \"graph_write_s\": %.3f, "
-               "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"paths_s\": %.3f, \"paths_device_s\": %.3f, \"paths_write_s\": %.3f, \"reads_placed\": %llu, \"path_edges\": %llu, \"total_s\": %.3f, \"fast_path\": %s}\n",
+               "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"paths_s\": %.3f, \"paths_device_s\": %.3f, \"paths_write_s\": %.3f, \"reads_placed\": %llu, \"path_edges\": %llu, \"paths_index_s\": %.3f, \"mark_dups_s\": %.3f, \"dup_pairs\": %llu, \"total_s\": %.3f, \"fast_path\": %s}\n",
                (unsigned long long)n_reads, (unsigned long long)st.n_inst, (unsigned long long)nk, g_threads, T.read, T.ingest_out,
                T.upload, T.count, T.fetch_write, t_graph, t_g_dev, t_g_host, t_g_write, (unsigned long long)g_e, (unsigned long long)g_v,
-               t_paths, t_p_dev, t_p_write, (unsigned long long)p_placed, (unsigned long long)p_edges, T.total, fast ? "true" : "false");
+               t_paths, t_p_dev, t_p_write, (unsigned long long)p_placed, (unsigned long long)p_edges, t_index, t_dups, (unsigned long long)n_dup, T.total, fast ? "true" : "false");
         { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); printf("DF_EXIT_EPOCH %.3f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());

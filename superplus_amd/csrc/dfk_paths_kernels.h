@@ -395,4 +395,182 @@ k_path_emit(const uint64_t* __restrict__ size_off, const uint64_t* __restrict__ 
     }
 }
 
+// ============================================================================ row f-4: paths index, duplicate marks
+// What MarkDups needs of a read besides its path, gathered while the reads are at hand (dfk_paths_build): the first five
+// bases as a base-4 number (10X/SecretOps.cc:430-433) in bits 0-9, the sum of its qualities (:474-481) above them.
+__global__ void __launch_bounds__(256)
+k_read_digest(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ base_off, const uint32_t* __restrict__ read_len,
+              const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, uint64_t pq_nbytes, uint64_t n, uint32_t* __restrict__ digest)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (uint64_t)gridDim.x * 256) {
+        const uint8_t* read = packed + base_off[r];
+        const uint32_t L = read_len[r];
+        uint32_t head = 0;
+        for (uint32_t j = 0; j < 5; ++j) head = 4u * head + (j < L ? seq_base(read, j) : 0u);
+        uint32_t sum = 0;
+        uint64_t p = pq_off[r];
+        const uint64_t end = pq_off[r + 1];
+        while (p < end) {                                                 // PQVec blocks (feudal/PQVec.cc:87-127)
+            const uint32_t nQs = pq[p];
+            if (!nQs || p + 3 > end) break;
+            const uint32_t hdr = pq[p + 1] | ((uint32_t)pq[p + 2] << 8);
+            const uint32_t nBits = hdr & 7u, minQ = (hdr >> 3) & 63u;
+            const uint64_t blk = ((uint64_t)nQs * nBits + 24) >> 3;
+            if (p + blk > end) break;
+            sum += nQs * minQ;
+            if (nBits) {
+                uint64_t bit = 8 * (p + 1) + 9;
+                const uint32_t fmask = (1u << nBits) - 1u;
+                for (uint32_t i = 0; i < nQs; ++i, bit += nBits) {
+                    const uint64_t by = bit >> 3;                              // (a field of <= 7 bits spans at most two bytes)
+                    const uint32_t w = pq[by] | (by + 1 < pq_nbytes ? (uint32_t)pq[by + 1] << 8 : 0u);
+                    sum += (w >> (bit & 7)) & fmask;
+                }
+            }
+            p += blk;
+        }
+        digest[r] = head | (min(sum, 0x3FFFFFu) << 10);
+    }
+}
+
+// ---- writePathsIndex (10X/PathsIndex.cc:23-146): the (edge, read) pairs of every path entry, in read order
+__global__ void __launch_bounds__(256)
+k_pidx_pairs(const uint32_t* __restrict__ var, const uint64_t* __restrict__ elem_off, uint64_t nb, uint64_t r0, uint64_t file_base, uint64_t var_bytes,
+             uint64_t pair_base, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t w0 = (elem_off[i] - file_base) >> 2, w1 = (i + 1 < nb ? elem_off[i + 1] - file_base : var_bytes) >> 2;
+        // the element's first path entry is entry number (w0 - 2 i) of the batch: every element before it spent two words on offset and lastSkip
+        uint64_t at = pair_base + (w0 - 2 * i);
+        for (uint64_t w = w0 + 2; w < w1; ++w, ++at) { const uint32_t e = var[w]; keys[at] = e; vals[at] = (uint32_t)(r0 + i); atomicAdd(&counts[e], 1u); }
+    }
+}
+
+// Stable LSD radix sort of (edge, read) pairs by edge, eight bits a pass.  A tile is RS_ROUNDS x 64 consecutive pairs and
+// belongs to ONE wave, which takes it round by round: the lanes with the same digit find each other by eight ballots, rank
+// themselves by lane, and a counter per digit in the wave's own LDS carries the rank from round to round -- index order is
+// (round, lane), so equal keys keep their order.  Pass 1 counts per tile and digit, a device scan over the digit-major
+// counts gives every (digit, tile) its place, pass 2 ranks again and writes.
+constexpr int RS_ROUNDS = 32, RS_TILE = 64 * RS_ROUNDS, RS_WAVES = 4;
+__device__ __forceinline__ unsigned long long digit_peers(uint32_t d, bool act)
+{
+    unsigned long long m = __ballot(act);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { const unsigned long long v = __ballot(act && ((d >> b) & 1u)); m &= ((d >> b) & 1u) ? v : ~v; }
+    return m;
+}
+__global__ void __launch_bounds__(64 * RS_WAVES)
+k_rs_hist(const uint32_t* __restrict__ keys, uint64_t n, uint32_t shift, uint64_t n_tiles, uint64_t* __restrict__ hist /* [256][n_tiles] */)
+{
+    __shared__ uint32_t cnt[RS_WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t tile = (uint64_t)blockIdx.x * RS_WAVES + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * RS_WAVES) {
+        for (int i = lane; i < 256; i += 64) cnt[wave][i] = 0;
+        wave_sync();
+        const uint64_t base = tile * RS_TILE;
+        for (int r = 0; r < RS_ROUNDS; ++r) {
+            const uint64_t i = base + (uint64_t)r * 64 + lane;
+            if (i < n) atomicAdd(&cnt[wave][(keys[i] >> shift) & 255u], 1u);
+        }
+        wave_sync();
+        for (int i = lane; i < 256; i += 64) hist[(uint64_t)i * n_tiles + tile] = cnt[wave][i];
+        wave_sync();
+    }
+}
+__global__ void __launch_bounds__(64 * RS_WAVES)
+k_rs_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n, uint32_t shift, uint64_t n_tiles,
+             const uint64_t* __restrict__ place /* [256][n_tiles], exclusive scan of hist */, uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
+{
+    __shared__ uint32_t cnt[RS_WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t tile = (uint64_t)blockIdx.x * RS_WAVES + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * RS_WAVES) {
+        for (int i = lane; i < 256; i += 64) cnt[wave][i] = 0;
+        wave_sync();
+        const uint64_t base = tile * RS_TILE;
+        for (int r = 0; r < RS_ROUNDS; ++r) {
+            const uint64_t i = base + (uint64_t)r * 64 + lane;
+            const bool act = i < n;
+            const uint32_t k = act ? keys[i] : 0u, v = act ? vals[i] : 0u, d = (k >> shift) & 255u;
+            const unsigned long long peers = digit_peers(d, act);
+            const uint32_t before = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+            uint32_t prior = 0;
+            if (act) prior = tld(&cnt[wave][d]);
+            wave_sync();                                                   // every lane has read the counters of this round
+            if (act && before == 0) tst(&cnt[wave][d], prior + (uint32_t)__popcll(peers));
+            wave_sync();
+            if (act) { const uint64_t dst = place[(uint64_t)d * n_tiles + tile] + prior + before; keys_out[dst] = k; vals_out[dst] = v; }
+        }
+        wave_sync();
+    }
+}
+
+// the file's variable data (unsigned long read ids), element offsets and the per-edge counts of a.countsb
+__global__ void __launch_bounds__(256)
+k_pidx_widen(const uint32_t* __restrict__ vals, uint64_t n, uint64_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = vals[i];
+}
+__global__ void __launch_bounds__(256)
+k_pidx_tables(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ first /* exclusive scan of counts, [n_he + 1] */, const int32_t* __restrict__ inv,
+              uint64_t n_he, uint64_t* __restrict__ elem_off /* [n_he + 1] */, int32_t* __restrict__ countsb)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e <= n_he; e += (uint64_t)gridDim.x * 256) {
+        elem_off[e] = 24 + 8 * first[e];
+        if (e < n_he) { const int32_t o = inv[e]; countsb[e] = (int32_t)(counts[e] + ((uint64_t)o != e ? counts[o] : 0u)); }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_widen_u32(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = in[i];
+}
+
+// ---- MarkDups (10X/SecretOps.cc:410-566) without the sort: a read's group is its key -- first edge (29 bits), offset on it
+// (25 bits, biased), first five bases of its mate (10 bits) -- in an open-address table {key, best}; best = max over the
+// group of (quality sum of the pair << 32 | ~read id): the highest sum, the lowest read id among equals -- the member the
+// reference keeps after its sort (:529-541).  Every other member marks its pair.  The table covers one `pass` of `n_pass`
+// (keys dealt by hash), so that it fits whatever HBM is free.
+constexpr unsigned long long DUP_EMPTY = ~0ull;
+constexpr int32_t DUP_OFF_BIAS = 1 << 16;
+__device__ __forceinline__ uint64_t dup_hash(uint64_t k) { k ^= k >> 31; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 29; k *= 0xBF58476D1CE4E5B9ull; return k ^ (k >> 32); }
+// key of read r of the batch, or DUP_EMPTY if it has no path; *score = what atomicMax compares
+__device__ __forceinline__ uint64_t dup_key(const uint32_t* __restrict__ var, const uint64_t* __restrict__ elem_off, uint64_t i, uint64_t nb, uint64_t r0,
+                                            uint64_t file_base, uint64_t var_bytes, const uint32_t* __restrict__ digest, uint64_t* score, unsigned int* bad)
+{
+    const uint64_t w0 = (elem_off[i] - file_base) >> 2, w1 = (i + 1 < nb ? elem_off[i + 1] - file_base : var_bytes) >> 2;
+    if (w1 - w0 <= 2) return DUP_EMPTY;
+    const int32_t off = (int32_t)var[w0];
+    const uint32_t e = var[w0 + 2];
+    const uint64_t id = r0 + i, mate = id ^ 1ull;
+    if (e >= (1u << 29) || off < -DUP_OFF_BIAS || off >= (1 << 25) - DUP_OFF_BIAS) { atomicOr(bad, 1u); return DUP_EMPTY; }
+    const uint32_t dm = digest[mate], ds = digest[id];
+    *score = ((uint64_t)((ds >> 10) + (dm >> 10)) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)id);
+    return ((uint64_t)e << 35) | ((uint64_t)(uint32_t)(off + DUP_OFF_BIAS) << 10) | (uint64_t)(dm & 1023u);
+}
+template <bool MARK>
+__global__ void __launch_bounds__(256)
+k_dup_pass(const uint32_t* __restrict__ var, const uint64_t* __restrict__ elem_off, uint64_t nb, uint64_t r0, uint64_t file_base, uint64_t var_bytes,
+           const uint32_t* __restrict__ digest, unsigned long long* __restrict__ tkey, unsigned long long* __restrict__ tbest, uint64_t mask,
+           uint32_t n_pass, uint32_t pass, uint8_t* __restrict__ dup, unsigned int* __restrict__ bad)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
+        uint64_t score = 0;
+        const uint64_t k = dup_key(var, elem_off, i, nb, r0, file_base, var_bytes, digest, &score, bad);
+        if (k == DUP_EMPTY) continue;
+        const uint64_t h = dup_hash(k);
+        if ((uint32_t)(h >> 40) % n_pass != pass) continue;
+        uint64_t s = h & mask;
+        for (uint64_t guard = 0; guard <= mask; ++guard, s = (s + 1) & mask) {
+            if (!MARK) {
+                const unsigned long long old = atomicCAS(&tkey[s], DUP_EMPTY, (unsigned long long)k);
+                if (old == DUP_EMPTY || old == k) { atomicMax(&tbest[s], (unsigned long long)score); break; }
+            } else {
+                const unsigned long long cur = tkey[s];
+                if (cur == k) { if (tbest[s] != score) dup[(r0 + i) >> 1] = 1; break; }
+                if (cur == DUP_EMPTY) { atomicOr(bad, 2u); break; }                       // (every key was inserted by the pass before)
+            }
+        }
+    }
+}
+
 } // namespace dfk

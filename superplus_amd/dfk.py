@@ -26,7 +26,7 @@ EXPORTS = [
     "dfk_write_kvec", "dfk_write_kvec_part", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_begin_host", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_partition_begin", "dfk_shard_partition_end", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
     "dfk_shard_dict_share", "dfk_shard_dict_adopt", "dfk_shard_dict_whole",
-    "dfk_paths_build", "dfk_paths_build_device", "dfk_paths_stats", "dfk_paths_write", "dfk_paths_fetch",
+    "dfk_paths_build", "dfk_paths_build_device", "dfk_paths_stats", "dfk_paths_write", "dfk_paths_fetch", "dfk_paths_index_write", "dfk_dups_write",
 ]
 
 
@@ -216,6 +216,16 @@ class Dfk:
     def paths_write(self, path):
         """a.paths (feudal file of ReadPath) as WriteAssemblyFiles writes it."""
         _check(lib().dfk_paths_write(self._ctx, path.encode()))
+
+    def paths_index_write(self, directory):
+        """a.paths.inv and a.countsb (writePathsIndex) into `directory`."""
+        _check(lib().dfk_paths_index_write(self._ctx, directory.encode()))
+
+    def dups_write(self, path):
+        """a.dup (MarkDups); returns the number of pairs marked."""
+        n = C.c_uint64()
+        _check(lib().dfk_dups_write(self._ctx, path.encode(), C.byref(n)))
+        return n.value
 
     def paths(self):
         """-> (offsets i32[n], first_edge u64[n+1], edges i32[...])"""

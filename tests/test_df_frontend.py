@@ -140,6 +140,17 @@ def test_df_end_to_end_on_gpu(tmp_path, golden_dir, oracle):
 
 
 @pytest.mark.gpu
+def test_df_writes_paths_index_and_dups(tmp_path, golden_dir):
+    """DF on the fragmented fixture: a.48/ holds the graph, the read paths, the inverted paths index, the counts and the
+    duplicate marks -- what 10X/DF.cc:541-561 leaves behind -- byte for byte as the reference's classes wrote them."""
+    r = run_df(f"LR={golden_dir}/frag.fastb", f"OUT_DIR={tmp_path}/w", "K=48", "HBM_GB=8")
+    assert r.returncode == 0, r.stdout + r.stderr
+    for f in ("a.fastb", "a.hbv", "a.inv", "a.paths", "a.paths.inv", "a.countsb", "a.dup"):
+        assert open(f"{tmp_path}/w/a.48/{f}", "rb").read() == open(f"{golden_dir}/graph_frag_k48/{f}", "rb").read(), f
+    assert "% of pairs appear to be duplicates" in r.stdout
+
+
+@pytest.mark.gpu
 def test_runall_command_line_on_gpu(tmp_path, golden_dir, oracle):
     """The full command line of runall.sh:127, unchanged: MAX_MEM_GB=640 must not become a 640 GiB HBM plan.  The
     transfers are forced through the many-chunk staged path (a few KB per chunk, three host threads)."""

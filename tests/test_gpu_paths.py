@@ -12,7 +12,8 @@ from tests.test_paths_oracle import CASES, decode_paths, load_reads
 pytestmark = pytest.mark.gpu
 
 KW = {"graph_k48": dict(min_bc=2), "graph_k40_nobc": dict(min_bc=0, nobc=True), "graph_k60_nobc": dict(min_bc=0, nobc=True),
-      "graph_hot_k48_minfreq2": dict(min_freq=2), "graph_special_k48": dict(min_bc=0, nobc=True), "graph_pathy_k48": dict(min_bc=2)}
+      "graph_hot_k48_minfreq2": dict(min_freq=2), "graph_special_k48": dict(min_bc=0, nobc=True), "graph_pathy_k48": dict(min_bc=2),
+      "graph_frag_k48": dict(min_bc=2)}
 
 
 def explain(got, exp):
@@ -79,4 +80,42 @@ def test_paths_need_a_graph(oracle):
     with pytest.raises(DfkError):
         d.paths_write("/tmp/never")                                                                 # nothing built
     d.paths_build(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"])
+    d.close()
+
+
+def test_paths_index_and_dups_match_reference_fixture(golden_dir, tmp_path):
+    """Row f-4 through the ABI on the fragmented fixture (1816 edges, PCR-duplicate pairs): a.paths.inv and a.countsb
+    (writePathsIndex, written on the reference side by IncrementalWriter<ULongVec> / BinaryWriter) and a.dup (MarkDups)."""
+    from superplus_amd.dfk import Dfk
+    rs = load_reads(golden_dir, "frag")
+    for extra in (dict(), dict(passes=3, inst_per_item=1500)):
+        d = Dfk(K=48, keep_inputs=True, **extra)
+        d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+        d.graph_build(); d.paths_build()
+        d.paths_index_write(str(tmp_path))
+        marked = d.dups_write(os.path.join(tmp_path, "a.dup"))
+        for f in ("a.paths.inv", "a.countsb", "a.dup"):
+            assert open(os.path.join(tmp_path, f), "rb").read() == open(os.path.join(golden_dir, "graph_frag_k48", f), "rb").read(), f"{f} {extra}"
+        assert marked == int(np.frombuffer(open(os.path.join(golden_dir, "graph_frag_k48", "a.dup"), "rb").read(), np.uint8, offset=16).sum())
+        d.close()
+
+
+@pytest.mark.parametrize("seed,G,pairs", [(421, 20000, 8000), (422, 60000, 12000)])
+def test_paths_index_and_dups_match_oracle(oracle, tmp_path, seed, G, pairs):
+    """Seeded reads with duplicated pairs: the product's three files against the Python oracle's (which is pinned by the fixture)."""
+    from oracle import graph_oracle, paths_oracle
+    from superplus_amd.dfk import Dfk
+    rs = util.make_set(seed, G, pairs)
+    ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
+    g = graph_oracle.run(ref["solid"], 48)
+    reads, quals = paths_oracle.unpack_reads(rs)
+    r = paths_oracle.run(reads, quals, g, 48)
+    exp = paths_oracle.paths_index(r["paths"], g["hbv"].involution())
+    exp["a.dup"] = paths_oracle.mark_dups(r["paths"], reads, quals)
+    d = Dfk(K=48, keep_inputs=True)
+    d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    d.graph_build(); d.paths_build()
+    d.paths_index_write(str(tmp_path)); d.dups_write(os.path.join(tmp_path, "a.dup"))
+    for f, b in exp.items():
+        assert open(os.path.join(tmp_path, f), "rb").read() == b, f
     d.close()
