@@ -122,6 +122,9 @@ struct dfk_ctx {
     void (*graph_state_free)(void*) = nullptr;
     // DFK_F_KEEP_INPUTS: the device copies dfk_count made of the caller's reads (hipMalloc, outside the arena), kept for
     // dfk_paths_build until the next count: packed, base_off, read_len, pq, pq_off, bc
+    unsigned int* d_resident = nullptr;       // [0] workgroups of k_count that have started, ever (k_gate); [1] gates that timed out
+    unsigned int resident_target = 0;         // its value once every workgroup of the launches so far has started
+    unsigned int last_wg_idle = 0;            // workgroups of the last k_count launch that never counted an item (trace)
     void* kept[6] = {};
     uint64_t kept_packed_bytes = 0, kept_pq_bytes = 0, kept_n_reads = 0, kept_budget = 0;
 
@@ -417,7 +420,15 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     rc = c->alloc(ovf_tmp, ovf_cap * 4, "overflow read list (scratch)"); if (rc) return rc;
     rc = c->alloc(d_n, 16, "overflow read count"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
-    if (grid)
+    // the minimizer length everybody uses gets the scan whose window lives in registers; other lengths the general one
+    static const bool old_scan = getenv("DFK_OLD_SCAN") != nullptr;
+    if (grid && pp.M == 16 && !old_scan) {
+        const size_t lds_r = sizeof(uint32_t) * (PART_RING + SUMMARY_RUNS) * PART_THREADS + (by_class ? n_bins * 4 : 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_count<K, 16>), dim3(grid), dim3(PART_THREADS), lds_r, c->stream,
+                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.n_reads, pp,
+                           (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p, (unsigned long long*)d_n.p, ovf_cap,
+                           (uint32_t*)ovf_tmp.p, (uint4*)T->summ.p, (uint32_t*)T->classes.p);
+    } else if (grid)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p,
@@ -713,6 +724,7 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
     DevBuf d_ovf;
     int rc = c->alloc(d_ovf, n_items * sizeof(ItemRange), "overflow list"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(&R.g->next_item, 0, 8, c->stream));      // next_item, n_overflow
+    HIP_TRY(hipMemsetAsync(&R.g->n_wg_idle, 0, 4, c->stream));
     CountParams cp = R.cp; cp.n_items = (uint32_t)n_items; cp.single = single_kmer_records ? 1u : 0u;
     const size_t lds = count_lds_bytes<K, LOG2S, NW, NBC>();
     auto kern = d_sub ? k_count<K, LOG2S, NW, NBC, true> : k_count<K, LOG2S, NW, NBC, false>;
@@ -722,14 +734,22 @@ int launch_count(dfk_ctx* c, const Partition& P, const ItemRange* d_items, uint6
     tk.start();
     hipLaunchKernelGGL(kern, dim3(R.grid), dim3(NW * 64), lds, c->stream,
                        (const uint4*)P.records.p, d_items, (const uint64_t*)P.base.p, cp, R.g, R.seg, (WgOut*)R.d_wg.p, R.hist,
-                       (ItemRange*)d_ovf.p, d_sub);
+                       (ItemRange*)d_ovf.p, d_sub, c->d_resident);
     HIP_TRY(hipGetLastError());
+    c->resident_target += R.grid;
+    if (c->after_count_launch || c->pending_blist >= 0) {
+        // what the second stream is about to run beside this launch waits until its persistent workgroups are all in place
+        // (at most 2 ms: then it goes ahead and the gate says so)
+        static const bool no_gate = getenv("DFK_NO_GATE") != nullptr;
+        if (!no_gate) hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->stream2, (const unsigned int*)c->d_resident, c->resident_target, 200000ull, c->d_resident + 1);
+    }
     if (c->after_count_launch) { std::function<int()> f; f.swap(c->after_count_launch); rc = f(); if (rc) return rc; }
     rc = launch_boundary_list(c); if (rc) return rc;
     *kernel_ms += tk.stop();
     CountGlobals g{};
     HIP_TRY(hipMemcpyAsync(&g, R.g, sizeof g, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->last_wg_idle = g.n_wg_idle;
     if (g.n_overflow) {
         const size_t at = overflowed->size();
         overflowed->resize(at + g.n_overflow);
@@ -1025,8 +1045,13 @@ int count_run(dfk_ctx* c, const Partition& P, CountRun& R)
     c->st.n_items += P.n_items;
     const float ms_before = c->st.ms_count;
     rc = launch_count<K, NBC>(c, P, (const ItemRange*)P.items.p, P.n_items, R, &overflowed, &c->st.ms_count); if (rc) return rc;
-    TRACE("k_count: %llu instances in %.1f ms (%.1f G instances/s), reservation %.2f GB", (unsigned long long)P.n_inst, c->st.ms_count - ms_before,
-          1e-6 * (double)P.n_inst / (double)(c->st.ms_count - ms_before), R.d_part.bytes / 1e9);
+    if (g_trace) {
+        unsigned int gate[2] = {0, 0};
+        (void)hipMemcpy(gate, c->d_resident, 8, hipMemcpyDeviceToHost);
+        TRACE("k_count: %llu instances in %.1f ms (%.1f G instances/s), reservation %.2f GB, %u of %u workgroups idle, %u gate timeouts so far",
+              (unsigned long long)P.n_inst, c->st.ms_count - ms_before, 1e-6 * (double)P.n_inst / (double)(c->st.ms_count - ms_before), R.d_part.bytes / 1e9,
+              c->last_wg_idle, R.grid, gate[1]);
+    }
     t.start();
     // items that overflowed their LDS table are halved by bucket index and retried; a single fine bucket
     // that still overflows is counted in an HBM table
@@ -1832,6 +1857,8 @@ int dfk_create(const dfk_config* cfg, dfk_ctx** out)
         HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi_pri));
         HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamDefault, getenv("DFK_S2_SAME_PRIO") ? hi_pri : lo_pri));
     }
+    HIP_TRY(hipMalloc((void**)&c->d_resident, 64));
+    HIP_TRY(hipMemset(c->d_resident, 0, 64));
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
     // The budget is what the arena may reserve: never more than 90 % of what is free now, whatever was asked for (the
@@ -1854,6 +1881,7 @@ void dfk_destroy(dfk_ctx* c)
     c->release_all();
     c->drop_kept();
     c->drop_pool();
+    if (c->d_resident) (void)hipFree(c->d_resident);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -1870,6 +1898,7 @@ int dfk_count_device(dfk_ctx* c, const void* d_packed, uint64_t packed_bytes, co
     HIP_TRY(hipSetDevice(c->device));
     c->release_all();
     c->st = dfk_stats{}; c->peak = 0;
+    if (c->d_resident) HIP_TRY(hipMemset(c->d_resident + 1, 0, 4));
     c->first_chunk_hint = 8 * (packed_bytes + pq_nbytes + 28 * n_reads) + (1ull << 30);
     Inputs in{(const uint8_t*)d_packed, packed_bytes, (const uint64_t*)d_base_off, (const uint32_t*)d_read_len,
               (const uint8_t*)d_pq, pq_nbytes, (const uint64_t*)d_pq_off, (const int32_t*)d_bc, n_reads};
@@ -2083,6 +2112,10 @@ int dfk_write_kvec_part(dfk_ctx* c, const char* path, int flags, uint64_t first_
 int dfk_get_stats(dfk_ctx* c, dfk_stats* out)
 {
     if (!c || !out) return fail(DFK_E_ARG, "null argument");
+    if (c->d_resident && hipSetDevice(c->device) == hipSuccess) {           // reserved[4]: sweeps that went ahead of a k_count launch still being placed (k_gate timed out)
+        unsigned int t = 0;
+        if (hipMemcpy(&t, c->d_resident + 1, 4, hipMemcpyDeviceToHost) == hipSuccess) c->st.reserved[4] = t;
+    }
     *out = c->st;
     return 0;
 }

@@ -422,6 +422,150 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
     }
 }
 
+// ---- the counting scan, window arrays in registers (M = 16: the default minimizer length)
+// Same result as k_partition<K, false> -- bucket counters (or class counts), run summaries, class masks, the list of
+// reads with too many runs -- with the block prefix / suffix minima of the sliding window kept in W + W registers per lane
+// instead of W x 5 bytes of LDS: the loop over a block of W m-mer positions is unrolled so that every index is a
+// compile-time constant.  What that buys: no LDS operation per base (there were six, with their address arithmetic), and
+// a run is closed by two register moves and an LDS store -- its bucket counter is bumped after the read's last base, in
+// a loop all lanes walk together -- where the per-base version paid the whole close (atomic, class mask, summary field)
+// as a divergent block in almost every step: among 64 reads some run ends nearly everywhere.
+template <int K, int M>
+__global__ void __launch_bounds__(PART_THREADS)
+k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
+             const uint32_t* __restrict__ good_len, uint64_t n_reads, PartParams pp,
+             unsigned long long* __restrict__ bucket_acc, unsigned long long* __restrict__ class_hist,
+             unsigned long long* __restrict__ ovf_count, uint64_t ovf_cap, uint32_t* __restrict__ ovf_list,
+             uint4* __restrict__ summaries, uint32_t* __restrict__ read_classes)
+{
+    constexpr int W = K - M + 1;
+    constexpr uint32_t mmask = M == 16 ? 0xFFFFFFFFu : ((1u << (2 * M)) - 1u);
+    constexpr uint32_t rsh = 2 * (M - 1);
+    constexpr int RUNS = SUMMARY_RUNS;                                   // buckets a lane remembers per read: as many as a summary holds
+    extern __shared__ uint32_t smem[];
+    uint32_t* ring = smem;                                               // [PART_RING][PART_THREADS] words of the read
+    uint32_t* runb = smem + PART_RING * PART_THREADS;                    // [RUNS][PART_THREADS] bucket of each closed run
+    uint32_t* lh = nullptr;
+    const uint32_t n_bins = 2u * (PART_CLASSES << pp.log2_world);
+    if (class_hist) {
+        lh = runb + RUNS * PART_THREADS;
+        for (uint32_t i = threadIdx.x; i < n_bins; i += PART_THREADS) lh[i] = 0;
+        __syncthreads();
+    }
+    const int tid = threadIdx.x;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
+    const uint64_t n_words = (packed_bytes + 3) >> 2;
+    const uint32_t log2_local = pp.log2_nb - pp.log2_world;
+    for (uint64_t r0 = (uint64_t)blockIdx.x * PART_THREADS; r0 < n_reads; r0 += (uint64_t)gridDim.x * PART_THREADS) {
+        const uint64_t r = r0 + tid;
+        const uint32_t gl = r < n_reads ? good_len[r] : 0;
+        const bool live = gl >= (uint32_t)K + 1;                         // Kmerizer::map: len < K+1 emits nothing (:153)
+        uint32_t qn = 0, cmask = 0;
+        uint64_t sum_lo = 0, sum_hi = 0;
+        if (live) {
+            const uint64_t bit0 = base_off[r] * 8;
+            uint64_t wi = bit0 >> 5, filled_to = wi;
+            auto fill = [&]() {
+                uint32_t w[PART_RING];
+#pragma unroll
+                for (int k = 0; k < PART_RING; ++k) w[k] = filled_to + k < n_words ? words[filled_to + k] : 0u;
+#pragma unroll
+                for (int k = 0; k < PART_RING; ++k) ring[((filled_to + k) & (PART_RING - 1)) * PART_THREADS + tid] = w[k];
+                filled_to += PART_RING;
+            };
+            fill();
+            uint32_t wbits = ring[(wi & (PART_RING - 1)) * PART_THREADS + tid], wpos = (uint32_t)bit0 & 31u;
+            auto next_base = [&]() -> uint32_t {
+                const uint32_t b = (wbits >> wpos) & 3u;
+                wpos += 2;
+                if (wpos == 32) { wpos = 0; ++wi; if (wi == filled_to) fill(); wbits = ring[(wi & (PART_RING - 1)) * PART_THREADS + tid]; }
+                return b;
+            };
+            uint32_t f = 0, rc = 0;
+            for (int j = 0; j < M - 1; ++j) { const uint32_t b = next_base(); f = ((f << 2) | b) & mmask; rc = (rc >> 2) | ((3u - b) << rsh); }
+            const uint32_t n_mmers = gl - M + 1;                         // m-mer positions t = 0 .. n_mmers-1; k-mer s = t-W+1 is complete at t >= W-1
+            uint32_t arr[W], sidx[W];                                    // suffix minima of the previous block (and where they sit), overwritten by the hashes of this one
+            uint32_t P = 0, Pi = 0;
+            uint32_t cur_b = 0, cur_nk = 0, cur_rel = 0;
+            auto close_run = [&]() {                                     // (cheap on purpose: see the head of this kernel)
+                if (qn < (uint32_t)RUNS) {
+                    runb[qn * PART_THREADS + tid] = cur_b;
+                    const uint64_t fld = cur_nk | (cur_rel << 6);
+                    const uint32_t b = 8u + 12u * qn;
+                    if (b < 64u) { sum_lo |= fld << b; if (b > 52u) sum_hi |= fld >> (64u - b); } else sum_hi |= fld << (b - 64u);
+                } else {
+                    // the eleventh run and beyond (two reads in 10^5 have them; the read then goes through the scanning scatter):
+                    // counted on the spot
+                    if (lh) { const uint32_t bin = class_bin(cur_b, pp); atomicAdd(&lh[bin], 1u); atomicAdd(&lh[(PART_CLASSES << pp.log2_world) + bin], cur_nk); }
+                    else atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
+                    cmask |= 1u << sweep_class_of(cur_b & ((1u << log2_local) - 1u), log2_local);
+                }
+                ++qn;
+            };
+            for (uint32_t t0 = 0; t0 < n_mmers; t0 += W) {              // one block of W m-mer positions; t = t0 + bi
+#pragma unroll
+                for (int bi = 0; bi < W; ++bi) {
+                    if (t0 + (uint32_t)bi < n_mmers) {                       // (no break: the loop must unroll for arr[] / sidx[] to be registers)
+                        const uint32_t b = next_base();
+                        f = ((f << 2) | b) & mmask;
+                        rc = (rc >> 2) | ((3u - b) << rsh);
+                        const uint32_t h = mmer_hash(f < rc ? f : rc);
+                        const bool newmin = bi == 0 || h < P;
+                        P = newmin ? h : P;
+                        Pi = newmin ? (uint32_t)bi : Pi;
+                        const bool first = t0 == 0;                      // (with bi == W-1: the read's first k-mer)
+                        if (!first || bi == W - 1) {                      // a k-mer ends here
+                            uint32_t mv = P;
+                            bool older = false;
+                            if (bi != W - 1) { older = arr[bi + 1] < mv; mv = older ? arr[bi + 1] : mv; }
+                            const uint32_t bucket = bucket_of(mv, pp);
+                            const bool open = first || bucket != cur_b || cur_nk == (uint32_t)KTraits<K>::NK_MAX;
+                            if (open) {
+                                if (!first) close_run();
+                                cur_b = bucket; cur_nk = 1;
+                                cur_rel = (bi != W - 1 && older) ? sidx[bi + 1] - (uint32_t)bi - 1u : (uint32_t)(W - 1 - bi) + Pi;
+                            } else ++cur_nk;
+                        }
+                        arr[bi] = h;
+                        if (bi == W - 1) {                                // block complete: its hashes become suffix minima
+                            uint32_t run = h, ri = W - 1;
+                            sidx[W - 1] = W - 1;
+#pragma unroll
+                            for (int i = W - 2; i >= 0; --i) { const bool lt = arr[i] < run; run = lt ? arr[i] : run; arr[i] = run; ri = lt ? (uint32_t)i : ri; sidx[i] = ri; }
+                        }
+                    }
+                }
+            }
+            close_run();
+        }
+        // ---- the runs' buckets: counters and class mask, all lanes together (a read has ~4 runs)
+        const uint32_t mine = min(qn, (uint32_t)RUNS);
+        for (uint32_t i = 0; __ballot(i < mine) != 0ull; ++i) {
+            if (i < mine) {
+                const uint32_t cb = runb[i * PART_THREADS + tid];
+                const uint32_t bfld = 8u + 12u * i;
+                const uint32_t nk = (uint32_t)(bfld + 12 <= 64 ? sum_lo >> bfld : bfld >= 64 ? sum_hi >> (bfld - 64) : (sum_lo >> bfld) | (sum_hi << (64 - bfld))) & 63u;
+                if (lh) { const uint32_t bin = class_bin(cb, pp); atomicAdd(&lh[bin], 1u); atomicAdd(&lh[(PART_CLASSES << pp.log2_world) + bin], nk); }
+                else atomicAdd(&bucket_acc[cb], (1ull << 32) | nk);
+                cmask |= 1u << sweep_class_of(cb & ((1u << log2_local) - 1u), log2_local);
+            }
+        }
+        if (r < n_reads) {
+            const uint64_t lo = sum_lo | (qn <= (uint32_t)SUMMARY_RUNS ? qn : SUMMARY_OVERFLOW);
+            summaries[r] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)sum_hi, (uint32_t)(sum_hi >> 32)};
+            if (read_classes) read_classes[r] = cmask;
+        }
+        if (qn > (uint32_t)SUMMARY_RUNS) {
+            const unsigned long long at = atomicAdd(ovf_count, 1ull);
+            if (at < ovf_cap) ovf_list[at] = (uint32_t)r;
+        }
+    }
+    if (lh) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_bins; i += PART_THREADS) if (lh[i]) atomicAdd(&class_hist[i], (unsigned long long)lh[i]);
+    }
+}
+
 // Sharded scatter: the records of one pass go into one slice per owner rank, in no particular order inside
 // the slice (the owner regroups them by the bucket id in the header).  A block handles SLICE_READS reads per
 // thread: first it counts its records per owner (LDS), reserves room in every slice with one global atomic
@@ -606,6 +750,8 @@ struct CountGlobals {                // device-resident counters
     unsigned int n_split;            // items that overflowed their table and were cut in two by their workgroup
     unsigned long long n_boundary;   // solid entries left with unresolved (cross-item) context bits
     unsigned long long part_cursor;  // entries of the part's reservation handed out to workgroups so far (whole chunks)
+    unsigned int n_wg_idle;          // workgroups of the last launch that ended without having counted an item (placed late, or never needed)
+    unsigned int pad_idle;
 };
 
 // Where a persistent workgroup is in the chunk of the output buffer it is filling (kept across the launches of
@@ -888,21 +1034,26 @@ __device__ __forceinline__ uint32_t wave_stage_piece(const uint4* __restrict__ r
 // Count records [rb, min(rb+COUNT_CHUNK, re)) with the calling wave (wave-synchronous; no
 // block barriers).
 template <int K, int NBC, bool LDS_TABLE, bool SUB = false>
-__device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
-                                                 WaveStage<K>* __restrict__ st, int lane,
-                                                 uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
-                                                 uint32_t S, uint32_t* n_fill, uint32_t* overflow, uint32_t sub = 0)
+__device__ __forceinline__ uint32_t wave_count_chunk(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
+                                                     WaveStage<K>* __restrict__ st, int lane,
+                                                     uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
+                                                     uint32_t S, uint32_t* n_fill, uint32_t* overflow, uint32_t sub = 0,
+                                                     uint32_t skip = 0, uint32_t quota = 0xFFFFFFFFu)
 {
     // sub != 0: one of 2^(sub >> 8) sub-passes over a fine bucket too rich for one table -- only the k-mers whose
     // selector (a mix of the key words, 8 bits) equals sub & 0xFF are counted in this one
+    // skip / quota: the wave's share of an item is a range of INSTANCES (k_count deals them out evenly); of the staged
+    // piece it counts instances [skip, skip + quota) and returns how many that were
     const uint32_t sel_mask = (1u << (sub >> 8)) - 1u, sel = sub & 0xFFu;
     const uint32_t total = wave_stage_piece<K>(records, rb, re, st, lane);
     bool ok = true;
     uint32_t n_claimed = 0;
     const uint32_t total_u = __builtin_amdgcn_readfirstlane(total);     // scalar loop control
-    for (uint32_t t0 = 0; t0 < total_u; t0 += 64) {
+    const uint32_t first_u = __builtin_amdgcn_readfirstlane(min(skip, total_u));
+    const uint32_t end_u = first_u + min(quota, total_u - first_u);
+    for (uint32_t t0 = first_u; t0 < end_u; t0 += 64) {
         const uint32_t t = t0 + lane;
-        Probe A = make_probe<K>(fetch_instance<K>(st, min(t, total_u - 1u)), S, t < total_u);
+        Probe A = make_probe<K>(fetch_instance<K>(st, min(t, end_u - 1u)), S, t < end_u);
         // (every key word goes into the selector: the k-mers of a hot bucket share their minimizer, often at the
         // same offset, i.e. whole words of the key)
         if (SUB) A.active = A.active && ((((A.k0 * 0x9E3779B1u) ^ (A.k1 * 0x85EBCA77u) ^ (A.k2 * 0xC2B2AE3Du) ^ (A.k3 * 0x27D4EB2Fu)) >> 24) & sel_mask) == sel;
@@ -916,6 +1067,7 @@ __device__ __forceinline__ void wave_count_chunk(const uint4* __restrict__ recor
     if (lane == 0 && n_claimed) atomicAdd(n_fill, n_claimed);
     if (!ok) atomicOr(overflow, 1u);
     wave_sync();
+    return end_u - first_u;
 }
 
 constexpr int BIG_TICKET_CHUNKS = 4;                 // chunks a wave takes per ticket
@@ -1312,7 +1464,8 @@ __global__ void __launch_bounds__(NWAVES * 64)
 k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, const uint64_t* __restrict__ rec_base,
         CountParams cp, CountGlobals* __restrict__ g, uint4* __restrict__ out, WgOut* __restrict__ wg_out,
         unsigned long long* __restrict__ hist_global, ItemRange* __restrict__ overflow_items,
-        const uint32_t* __restrict__ item_sub)        // optional: per item, its sub-pass word (single buckets counted in several sub-passes)
+        const uint32_t* __restrict__ item_sub,        // optional: per item, its sub-pass word (single buckets counted in several sub-passes)
+        unsigned int* __restrict__ resident)          // bumped once by every workgroup as it starts (k_gate waits on it)
 {
     constexpr uint32_t S = 1u << LOG2S;
     constexpr int KW = KTraits<K>::KW;
@@ -1332,6 +1485,11 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
     WaveStage<K>* st = stages + wave;
     uint4* seg_out = out;                                              // the part's reservation, shared by all workgroups
 
+    // This workgroup has its LDS: say so.  The next range's sweep (thousands of short-lived 4-KB blocks on the second stream)
+    // is held back by k_gate until every persistent workgroup of this launch has said it -- a sweep block placed in the
+    // middle of a CU's LDS before the CU's second workgroup arrives leaves no 71-KB hole, and that workgroup then never
+    // starts: the launch runs at half rate to its end ("the cliff").
+    if (tid == 0 && resident) __hip_atomic_fetch_add(resident, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = tid; i < COUNT_HIST_BINS; i += NT) hist[i] = 0;
     for (uint32_t i = tid; i < (3 + XW) * S; i += NT) cnt[i] = 0;      // count, context and barcode words; key words are written on claim
     // The item loop is software-pipelined: while the workgroup counts item i, thread 0 already holds the
@@ -1355,12 +1513,14 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
 #ifdef DFK_PHASE_TIMES
     PhaseClock phase; phase.start();
 #endif
+    uint32_t items_done = 0;
     for (;;) {
         PH(0);
         __syncthreads();                                               // table empty, counters reset, item published
         PH(1);
         const uint32_t item = __builtin_amdgcn_readfirstlane(ctl[CTL_ITEM]);
         if (item >= cp.n_items) break;
+        ++items_done;
         const uint64_t rb = uniform64(ctl[CTL_RB_LO], ctl[CTL_RB_HI]);
         const uint64_t re = uniform64(ctl[CTL_RE_LO], ctl[CTL_RE_HI]);
         const uint32_t sub = __builtin_amdgcn_readfirstlane(ctl[CTL_SUB]);
@@ -1463,6 +1623,21 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         wg_out[blockIdx.x] = WgOut{(unsigned long long)ctl[CTL_OUT_LO] | ((unsigned long long)ctl[CTL_OUT_HI] << 32), ctl[CTL_USED], 0u};
         if (ctl[CTL_DISTINCT]) atomicAdd(&g->n_distinct, (unsigned long long)ctl[CTL_DISTINCT]);
         if (ctl[CTL_BOUNDARY]) atomicAdd(&g->n_boundary, (unsigned long long)ctl[CTL_BOUNDARY]);
+        if (!items_done) atomicAdd(&g->n_wg_idle, 1u);
+    }
+}
+
+// One wave, no LDS, on the sweep's stream in front of the sweep: returns when the counter has reached `target` (every
+// persistent workgroup of the k_count launched just before has its LDS) or after `max_ticks` of the 100 MHz wall clock,
+// whichever comes first -- a bounded wait, then the sweep goes ahead regardless.
+__global__ void __launch_bounds__(64)
+k_gate(const unsigned int* __restrict__ ctr, unsigned int target, unsigned long long max_ticks, unsigned int* __restrict__ timed_out)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (wall_clock64() - t0 > max_ticks) { __hip_atomic_fetch_add(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(64);
     }
 }
 
