@@ -203,15 +203,51 @@ def write_read_files(rs, head, workers=8):
     feudal.write_bci(head + ".bci", rs.bci)
 
 
+def host_memory_limits():
+    """What the box lets this command hold in RAM (files on /dev/shm count): the cgroup's limit and use, and the room on
+    /dev/shm.  gpurun ends a command at about 90 % of the cgroup limit (its 270 GiB of a 300 GiB cgroup), so that is the cap."""
+    out = {}
+    for name, path in (("cgroup_memory_max", "/sys/fs/cgroup/memory.max"), ("cgroup_memory_current", "/sys/fs/cgroup/memory.current")):
+        try:
+            v = open(path).read().strip()
+            out[name] = None if v == "max" else int(v)
+        except OSError:
+            out[name] = None
+    try:
+        st = os.statvfs("/dev/shm"); out["dev_shm_free"] = st.f_bavail * st.f_frsize
+    except OSError:
+        out["dev_shm_free"] = None
+    try:
+        out["mem_available"] = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+    except (OSError, IndexError):
+        out["mem_available"] = None
+    cap = min(x for x in (0.9 * out["cgroup_memory_max"] if out["cgroup_memory_max"] else None, out["mem_available"], 1e18) if x is not None)
+    out["usable"] = int(cap - (out["cgroup_memory_current"] or 0))
+    return out
+
+
 def df_stage_wall(args, dev, local):
     """BASELINE.json's other half: the DF stage's wall-clock, measured as SURVEY 8(d) defines it -- process start of
-    `DF ROOT=... LR=...` (the unchanged runall.sh:127 command line) to its exit, with every output written:
-    frag_reads_orig.*, the side files, the spectrum JSON and kmers.kvec.  Files live on /dev/shm (RAM-backed), the only
-    place the box has room; the set is the bench's workload scaled so that inputs + outputs fit the host memory cap."""
+    `DF ROOT=... LR=...` (the unchanged runall.sh:127 command line) to its exit, with every output written.  With the
+    graph (the default): everything 10X/DF.cc:300-561 leaves behind for the next stage -- frag_reads_orig.*, the side files,
+    the spectrum JSON and a.<K>/ with the graph, the read paths, the inverted paths index and the duplicate marks (no
+    kmers.kvec: the reference removes its own, BuildReadQGraph48.cc:303).  Files live on /dev/shm (RAM-backed); the leg runs
+    BASELINE configs[1] at full size when the command's memory allowance holds inputs + outputs, scaled down otherwise."""
     import shutil
     G = int(args.genome_mb * 1e6)
     total_pairs = int(args.coverage * G / 200.0) if args.coverage > 0 else args.pairs
-    pairs = min(total_pairs, args.df_pairs)
+    mem = host_memory_limits()
+    # bytes in RAM per read: input files 50.4, their frag_reads_orig copies 50.4 (none when hard-linked), lens 2, and with the
+    # graph a.paths 20, a.paths.inv 8, a.dup 0.5; kmers.kvec (GRAPH=False) 32 per solid k-mer = 55; DF's own vectors 6
+    per_read_link = 50.4 + 2 + 6 + (28.5 if args.df_graph else 55.0)
+    per_read_copy = per_read_link + 50.4
+    want = min(total_pairs, args.df_pairs) if args.df_pairs else total_pairs
+    link = False
+    if 2 * want * per_read_copy * 1.25 > mem["usable"]:
+        link = True                                                      # frag_reads_orig.{fastb,qualp} as hard links to the inputs (LINK_READS=True)
+    pairs = want
+    if 2 * pairs * per_read_link * 1.25 > mem["usable"]:
+        pairs = max(1000, int(mem["usable"] / 1.25 / per_read_link / 2))
     Gd = max(1000, int(G * pairs / total_pairs))
     root = tempfile.mkdtemp(prefix="dfk_df_", dir=args.df_dir if os.path.isdir(args.df_dir) else None)
     try:
@@ -226,7 +262,8 @@ def df_stage_wall(args, dev, local):
         torch.cuda.synchronize(); torch.cuda.empty_cache()
         cmd = [os.path.join(ROOT, "superplus_amd", "DF"), f"ROOT={root}", f"LR={root}/reads.fastb", "PIPELINE=cs", "ALIGN=False",
                f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}",
-               "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (ingest + count; --df-graph adds rows f-1 and f-2: edges + HBV + read paths -> a.<K>/)
+               "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (GRAPH=True: rows f-1, f-2, f-4 -- edges + HBV + read paths + paths index + duplicate marks -> a.<K>/)
+        if link: cmd.append("LINK_READS=True")
         env = dict(os.environ, DFK_HOST_THREADS=str(min(args.df_threads, 16)))
         if args.df_gpus > 1 or args.df_transport:
             # the C++ multi-GPU host (df_shard.h): DF forks one rank per GPU and moves the records over RCCL itself;
@@ -257,7 +294,11 @@ def df_stage_wall(args, dev, local):
                             f": {pairs} pairs 2x100 bp over a {Gd / 1e6:g} Mb random genome ({200.0 * pairs / Gd:.1f}x), K={args.K}",
                 "definition": "wall time of the child process `DF ROOT= LR= PIPELINE=cs ALIGN=False NUM_THREADS= MAX_MEM_GB=640` "
                               "(runall.sh:127) from start to exit: map inputs, re-emit frag_reads_orig.*, lens/qhist/dti, upload, "
-                              "createDict on the GPU, spectrum JSON, kmers.kvec -- ingest + count, not the other seven DF stages",
+                              "createDict on the GPU, spectrum JSON" + (", then what buildReadQGraph48's second half, writePathsIndex and MarkDups leave in a.<K>/ "
+                              "(10X/DF.cc:541-561: graph, read paths, paths index, duplicate marks)" if args.df_graph else ", kmers.kvec") +
+                              " -- ingest + StageBuildGraph, not the other seven DF stages",
+                "frag_reads_orig": "hard links to the inputs (LINK_READS=True: byte-identical files, no second copy in RAM)" if link else "copies of the inputs",
+                "host_memory": dict(mem, estimated_need=int(2 * pairs * (per_read_link if link else per_read_copy))),
                 "kmers_per_s_whole_stage": (timing.get("kmer_instances", 0) / wall) if wall > 0 else None,
                 "breakdown_s": {k: timing.get(k) for k in ("spawn_to_main_s", "open_validate_s", "ingest_outputs_s", "upload_s", "count_s",
                                                            "spectrum_kvec_write_s", "total_s", "exit_to_reaped_s")},
@@ -298,15 +339,17 @@ def main():
                     help="plant this many diverged copies of one 300-bp element in the genome (hot minimizer buckets)")
     ap.add_argument("--low-complexity", type=float, default=0.0, help="share of the genome overwritten with microsatellite stretches")
     ap.add_argument("--ragged-quals", type=float, default=0.0, help="share of the reads with per-base (nBits=2) quality blocks")
-    ap.add_argument("--df-pairs", type=int, default=450_000_000,
-                    help="pairs of the DF-stage wall-clock leg: its files live in RAM (/dev/shm) beside DF's outputs, and "
-                         "inputs + outputs of the full 900 M-pair set (~300 GB) exceed the box's 270 GiB host memory cap")
+    ap.add_argument("--df-pairs", type=int, default=0,
+                    help="pairs of the DF-stage wall-clock leg (0 = the whole set); scaled down by itself when inputs + outputs, "
+                         "which live in RAM (/dev/shm), would not fit the command's memory allowance (cgroup memory.max)")
     ap.add_argument("--df-dir", default="/dev/shm", help="where the DF leg's files go")
     ap.add_argument("--df-threads", type=int, default=16, help="NUM_THREADS of the DF leg (the box's CPU share for one GPU)")
     ap.add_argument("--sharded-one", action="store_true",
                     help="run the whole set through the SHARDED pipeline with one rank (class-count scan without scattered atomics, "
                          "slices, two-level LDS regroup): the alternative single-GPU design, for comparison (DESIGN.md section 9)")
-    ap.add_argument("--df-graph", action="store_true", help="DF leg: also build the unipath graph and write a.<K>/ (row f-1)")
+    ap.add_argument("--df-graph", action=argparse.BooleanOptionalAction, default=True,
+                    help="DF leg: GRAPH=True -- the graph, the read paths, the paths index and the duplicate marks in a.<K>/ (rows f-1, f-2, f-4); "
+                         "--no-df-graph: ingest + count + kmers.kvec only")
     ap.add_argument("--df-gpus", type=int, default=1, help="DF leg: NUM_GPUS of the C++ multi-GPU host (DF forks one rank per GPU, RCCL directly)")
     ap.add_argument("--df-transport", default="", choices=["", "rccl", "loopback"],
                     help="DF leg: run the C++ sharded host even with one rank (rccl), or all ranks as threads on one GPU (loopback)")

@@ -199,7 +199,11 @@ int dfk_graph_write(dfk_ctx* ctx, const char* dir);
  *   dfk_paths_write         a.<K>/a.paths as WriteAssemblyFiles writes it (10X/WriteFiles.cc:78-82: ReadPathVec::WriteAll, a feudal
  *                           file of {i32 offset, u32 lastSkip = 0, i32 edges...}, paths/long/ReadPath.h:56-63) -- byte for byte
  *   dfk_paths_fetch         offsets[n], first_edge[n+1] (read r's edges are edges[first_edge[r] .. first_edge[r+1])), edges
- * Needs dfk_graph_build on the same count.  dfk_stats.reserved[3]: microseconds spent pathing. */
+ * Needs dfk_graph_build on the same count.  dfk_stats.reserved[3]: microseconds spent pathing.
+ * dfk_graph_write and dfk_paths_write only READ the context (host tables, finished device buffers) and allocate nothing on the
+ * device: each may run on a thread of its own beside the NEXT call in the chain -- dfk_graph_write beside dfk_paths_build,
+ * dfk_paths_write beside dfk_paths_index_write / dfk_dups_write -- which is how DF hides the files under the device work.
+ * Every other call on a context is serialised by the caller. */
 int dfk_paths_build(dfk_ctx* ctx, const uint8_t* packed_bases, const uint64_t* base_off, const uint32_t* read_len,
               const uint8_t* pq_bytes, const uint64_t* pq_off, uint64_t n_reads);
 int dfk_paths_build_device(dfk_ctx* ctx, const void* d_packed_bases, uint64_t packed_bytes, const void* d_base_off,

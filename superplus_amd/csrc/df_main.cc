@@ -19,7 +19,7 @@
 //
 // Arguments beyond the reference's: HBM_GB= (device memory the library may use; 0 = 90 % of what is free --
 // MAX_MEM_GB keeps its reference meaning, a HOST memory cap (system/System.cc:1073-1078), and is not a device
-// budget), DEVICE=, KVEC= / KVEC_SORTED= (write kmers.kvec; in ascending k-mer order), GRAPH= (build the graph and
+// budget), DEVICE=, KVEC= / KVEC_SORTED= (write kmers.kvec -- by default only when GRAPH=False; in ascending k-mer order), GRAPH= (build the graph and
 // write a.<K>/: on by default, as in the reference), MINIMIZER=.
 #include "../../include/dfk.h"
 #include "df_shard.h"
@@ -187,6 +187,18 @@ void write_range(int fd, const uint8_t* src, uint64_t bytes, uint64_t file_off)
 
 // A feudal file re-emitted from its mapped image: our control block (the reference's writer constants), then the
 // var data, offset table and fixed data as they are.
+// LINK_READS=True: when the input already is, byte for byte, the file that would be written (it carries the control block
+// the reference's writer gives such a file, and LoadData keeps every read in place), frag_reads_orig.* can be another name
+// for the same data instead of a second copy of tens of GB -- a hard link; anything in the way (another file system, a
+// different control block) falls back to the copy.
+bool link_feudal(const FeudalMap& in, const std::string& path, uint8_t szFixed, uint8_t szX, uint8_t szA)
+{
+    feudal::Header h{(uint32_t)in.n, 1, szFixed, szX, szA, in.varTab, in.fixedOff};
+    if (memcmp(&h, in.m.p, 24) != 0) return false;
+    unlink(path.c_str());
+    return link(in.path.c_str(), path.c_str()) == 0;
+}
+
 void copy_feudal(const FeudalMap& in, const std::string& path, uint8_t szFixed, uint8_t szX, uint8_t szA)
 {
     const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
@@ -321,7 +333,8 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
         T->all_gather(mine, 2, all.data());
         uint64_t first = 0, total = 0, inst = 0;
         for (int r = 0; r < world; ++r) { if (r < rank) first += all[2 * r]; total += all[2 * r]; inst += all[2 * r + 1]; }
-        if (truthy(a["KVEC"]) && dfk_write_kvec_part(ctx, (work_dir + "/kmers.kvec").c_str(), 0, first, total)) throw std::runtime_error(dfk_last_error());
+        const bool want_kvec = a["KVEC"] == "Auto" ? !truthy(a["GRAPH"]) : truthy(a["KVEC"]);
+        if (want_kvec && dfk_write_kvec_part(ctx, (work_dir + "/kmers.kvec").c_str(), 0, first, total)) throw std::runtime_error(dfk_last_error());
         const double t_write = now_s() - t0;
         uint64_t done = 1; T->all_reduce(&done, 1, false);                                   // every share is in the file
         dfk_stats st{}; dfk_get_stats(ctx, &st);
@@ -426,7 +439,7 @@ int main(int argc, char** argv)
     std::map<std::string, std::string> a = {
         {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
         {"OUT_DIR", ""}, {"LR", ""}, {"LR_SELECT_FRAC", "1.0"}, {"EXIT_LOAD", "False"}, {"DEVICE", "0"}, {"MAX_MEM_GB", "0"},
-        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "True"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}, {"PATHS", "True"}, {"NUM_GPUS", "1"}};
+        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "Auto"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}, {"PATHS", "True"}, {"LINK_READS", "False"}, {"NUM_GPUS", "1"}};
     std::string command = "DF";
     for (int i = 1; i < argc; ++i) {
         std::string s = argv[i]; command += " " + s;
@@ -549,8 +562,9 @@ int main(int argc, char** argv)
             d.dt = 3; d.start = x.bci[1]; datasets.push_back(d);
             h_packed = x.fb.m.p; h_boff = x.fb.off_table(); h_len = x.fb.fixed();
             h_pq = x.qp.m.p; h_qoff = x.qp.off_table();
-            in_background([&] { copy_feudal(x.fb, rh + ".fastb", 4, 16, 1); });      // (two files, two writers)
-            in_background([&] { copy_feudal(x.qp, rh + ".qualp", 0, 8, 1); });
+            const bool may_link = truthy(a["LINK_READS"]);
+            if (!(may_link && link_feudal(x.fb, rh + ".fastb", 4, 16, 1))) in_background([&] { copy_feudal(x.fb, rh + ".fastb", 4, 16, 1); });      // (two files, two writers)
+            if (!(may_link && link_feudal(x.qp, rh + ".qualp", 0, 8, 1))) in_background([&] { copy_feudal(x.qp, rh + ".qualp", 0, 8, 1); });
             { feudal::BinWriter w(rh + ".bci"); w.vec(bci); }
         } else {
             R.base_off.push_back(0); R.pq_off.push_back(0);
@@ -687,6 +701,10 @@ int main(int argc, char** argv)
         cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
         cfg.hbm_budget_bytes = (uint64_t)(atof(a["HBM_GB"].c_str()) * 1073741824.0);   // 0 = 90 % of the free HBM; MAX_MEM_GB is host memory
         const bool want_paths = truthy(a["GRAPH"]) && truthy(a["PATHS"]);
+        // kmers.kvec is a transient file of the reference (written at BuildReadQGraph48.cc:287, read back at :294-301, removed
+        // at :303): with the graph built here nothing downstream reads it, so it is written only on request -- or when
+        // GRAPH=False, where it is the one way the dictionary leaves this process
+        const bool want_kvec = a["KVEC"] == "Auto" ? (!truthy(a["GRAPH"]) || truthy(a["KVEC_SORTED"])) : truthy(a["KVEC"]);
         if (want_paths) cfg.flags |= DFK_F_KEEP_INPUTS;                          // the reads stay on the device for pathReads
         dfk_ctx* ctx = nullptr;
         if (dfk_create(&cfg, &ctx)) { fprintf(stderr, "DF: %s\n", dfk_last_error()); join_background(); return 1; }
@@ -703,7 +721,7 @@ int main(int argc, char** argv)
         std::string js(need, '\0'); dfk_spectrum_json(ctx, &js[0], need, &need);
         { FILE* f = fopen((work_dir + "/stats/histogram_kmer_count.json").c_str(), "wb"); if (!f) throw std::runtime_error("cannot write spectrum"); fwrite(js.data(), 1, js.size(), f); fclose(f); }
         uint64_t nk = 0; dfk_solid_count(ctx, &nk);
-        if (truthy(a["KVEC"])) {
+        if (want_kvec) {
             printf("%s: writing kmers.kvec\n", date().c_str());
             if (dfk_write_kvec(ctx, (work_dir + "/kmers.kvec").c_str(), truthy(a["KVEC_SORTED"]) ? DFK_KVEC_SORTED : 0)) throw std::runtime_error(dfk_last_error());
         }
@@ -720,10 +738,13 @@ int main(int argc, char** argv)
             const std::string dir = work_dir + "/a." + std::to_string(K);
             mkpath(dir);
             printf("%s: writing files\n", date().c_str());
-            const double tw = now_s();
-            if (dfk_graph_write(ctx, dir.c_str())) throw std::runtime_error(dfk_last_error());
-            t_g_write = now_s() - tw;
+            // the graph's files are written (host work: numbering is done, the edges are packed) while the device paths the reads;
+            // a.paths is written while the device inverts the paths and marks duplicates.  Both writers only read the context.
+            std::string bg_fail; double tw_graph = 0, tw_paths = 0;
+            std::thread graph_writer([&] { const double t1 = now_s(); if (dfk_graph_write(ctx, dir.c_str())) bg_fail = dfk_last_error(); tw_graph = now_s() - t1; });
+            struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_graph{graph_writer};
             dfk_graph_stats(ctx, &g_ce, &g_v, &g_e);
+            if (!want_paths) { graph_writer.join(); if (!bg_fail.empty()) throw std::runtime_error(bg_fail); }
             t_graph = now_s() - t0;
             if (want_paths) {
                 // pathReads (BuildReadQGraph48.cc:1664-1665) and a.<K>/a.paths (10X/WriteFiles.cc:78-82)
@@ -731,21 +752,28 @@ int main(int argc, char** argv)
                 printf("%s: pathing reads\n", date().c_str());
                 if (dfk_paths_build(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) throw std::runtime_error(dfk_last_error());
                 { dfk_stats ps{}; dfk_get_stats(ctx, &ps); t_p_dev = 1e-6 * (double)ps.reserved[3]; }
-                const double tw2 = now_s();
+                graph_writer.join();
+                if (!bg_fail.empty()) throw std::runtime_error(bg_fail);
+                t_graph += std::max(0.0, tw_graph - (now_s() - t0));          // (what of the graph's files was not hidden under the pathing)
                 printf("%s: writing paths\n", date().c_str());
-                if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());
-                t_p_write = now_s() - tw2;
+                std::thread paths_writer([&] { const double t1 = now_s(); if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) bg_fail = dfk_last_error(); tw_paths = now_s() - t1; });
+                Join join_paths{paths_writer};
                 dfk_paths_stats(ctx, nullptr, &p_placed, &p_edges);
-                t_paths = now_s() - t0;
                 // writePathsIndex and MarkDups, the two steps DF takes right after StageBuildGraph (10X/DF.cc:550,560)
-                t0 = now_s();
+                const double ti = now_s();
                 printf("%s: inverting paths index\n", date().c_str());
                 if (dfk_paths_index_write(ctx, dir.c_str())) throw std::runtime_error(dfk_last_error());
-                t_index = now_s() - t0; t0 = now_s();
+                t_index = now_s() - ti;
+                const double td = now_s();
                 if (dfk_dups_write(ctx, (dir + "/a.dup").c_str(), &n_dup)) throw std::runtime_error(dfk_last_error());
-                t_dups = now_s() - t0;
+                t_dups = now_s() - td;
+                paths_writer.join();
+                if (!bg_fail.empty()) throw std::runtime_error(bg_fail);
+                t_p_write = tw_paths;
+                t_paths = now_s() - t0;
                 printf("%.2f%% of pairs appear to be duplicates\n", n_reads ? 100.0 * (double)n_dup / (double)(n_reads / 2) : 0.0);
             }
+            t_g_write = tw_graph;
         }
         dfk_destroy(ctx);
         join_background();

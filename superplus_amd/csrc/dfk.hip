@@ -1946,9 +1946,11 @@ int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const
         c->st.ms_upload = ms_up;
         if (!rc && (c->cfg.flags & DFK_F_KEEP_INPUTS)) {
             // the reads stay on the device for dfk_paths_build, and the arena's budget stays reduced by them
-            void* k[6] = {d_packed, d_boff, d_len, d_pq, d_poff, d_bc};
+            // (the barcodes are createDict's alone: their room goes back at once)
+            void* k[6] = {d_packed, d_boff, d_len, d_pq, d_poff, nullptr};
             memcpy(c->kept, k, sizeof k);
             c->kept_packed_bytes = pb; c->kept_pq_bytes = qb; c->kept_n_reads = n_reads; c->kept_budget = saved - c->budget;
+            if (d_bc) { (void)hipFree(d_bc); const uint64_t b = n_reads * 4 + 64; c->budget += b; c->kept_budget -= b; }
             return 0;
         }
         c->budget = saved;

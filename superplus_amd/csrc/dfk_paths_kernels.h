@@ -46,9 +46,21 @@ struct PathGraph {
     const int32_t* to_vtx;
     const int32_t* to_edge;
     uint32_t n_ce, n_he, n_v;
+    uint64_t store_words;         // 32-bit words of `store` (it is read as aligned words by the base comparisons)
 };
 
 __device__ __forceinline__ uint32_t seq_base(const uint8_t* __restrict__ p, uint64_t i) { return (p[i >> 2] >> (2 * (i & 3))) & 3u; }
+
+// sixteen bases from base index `first` of a 2-bit stream that starts at byte `byte0` of the word array `words` (base `first`
+// in bits 0-1): two aligned loads and a funnel shift.  `n_words` bounds the second load (the stream's last word has no successor).
+__device__ __forceinline__ uint32_t bases16(const uint32_t* __restrict__ words, uint64_t n_words, uint64_t byte0, uint64_t first)
+{
+    const uint64_t bit = 8 * byte0 + 2 * first, wi = bit >> 5;
+    const uint32_t lo = words[wi], hi = wi + 1 < n_words ? words[wi + 1] : 0u;
+    return alignbit(hi, lo, (uint32_t)bit & 31u);
+}
+// the order of the sixteen 2-bit fields of x reversed
+__device__ __forceinline__ uint32_t rev2_32(uint32_t x) { x = __brev(x); return ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1); }
 
 // a canonical edge read along (rc = false) or against (rc = true) its stored orientation
 struct EdgeView {
@@ -72,14 +84,24 @@ __device__ __forceinline__ uint32_t dict_find(const PartTable& pt, const uint32_
 
 template <int K>
 __device__ uint32_t path_parts(const PartTable& pt, const uint32_t* __restrict__ index, uint64_t mask, const PathGraph& G,
+                               const uint32_t* __restrict__ rwords, uint64_t r_nwords, uint64_t r_byte0,
                                const uint8_t* __restrict__ read, uint32_t n, PartD* __restrict__ parts, unsigned int* __restrict__ bad)
 {
     if (n < (uint32_t)K) { parts[0] = part_gap_of(n); return 1; }
+    const uint32_t* ewords = reinterpret_cast<const uint32_t*>(G.store);
     uint32_t np = 0, at = 0;
     const uint32_t stop = n - K + 1;
     while (at != stop) {
-        u128 km{0, 0};
-        for (int i = 0; i < K; ++i) km = kmer_succ<K>(km, seq_base(read, at + i));
+        // the k-mer at `at`: its 2K bits straight from the stream (sixteen bases a word), then turned big-endian as KMer keeps them
+        u128 ks;
+        {
+            const uint32_t w0 = bases16(rwords, r_nwords, r_byte0, at), w1 = bases16(rwords, r_nwords, r_byte0, at + 16u),
+                           w2 = bases16(rwords, r_nwords, r_byte0, at + 32u), w3 = K > 48 ? bases16(rwords, r_nwords, r_byte0, at + 48u) : 0u;
+            ks = u128{(uint64_t)w0 | ((uint64_t)w1 << 32), (uint64_t)w2 | ((uint64_t)w3 << 32)};
+            const u128 m = KTraits<K>::mask();
+            ks.lo &= m.lo; ks.hi &= m.hi;
+        }
+        u128 km = shr128(u128{rev2_64(ks.hi), rev2_64(ks.lo)}, 128 - KTraits<K>::BITS);
         uint32_t hit = dict_find<K>(pt, index, mask, km);
         if (hit == GRAPH_EMPTY) {
             uint32_t missed = 1, nxt = at + K;
@@ -96,7 +118,8 @@ __device__ uint32_t path_parts(const PartTable& pt, const uint32_t* __restrict__
             const uint32_t c = b.x;
             if (c >= G.n_ce) { atomicOr(bad, 4u); parts[np++] = part_gap_of(stop - at); break; }   // (an entry without an edge: the graph is not the dictionary's)
             int32_t off = (int32_t)(b.y & 0xFFFFFFu);
-            const EdgeView fw = edge_view<K>(G, c, false);
+            const EdgeRec er = G.ce[c];
+            const EdgeView fw{G.store + er.byte_off, er.n + (uint32_t)K - 1u, false};
             // CF<K>::isRC: at the first position where the read's k-mer differs from its own reverse complement, does it
             // differ from the edge's k-mer too?  (a palindrome never does)
             const u128 R = kmer_rc<K>(km);
@@ -107,13 +130,29 @@ __device__ uint32_t path_parts(const PartTable& pt, const uint32_t* __restrict__
                 const int i = (lead - (128 - KTraits<K>::BITS)) >> 1;
                 rc = kmer_base<K>(km, i) != fw.at((uint32_t)off + (uint32_t)i);
             }
+            // matchLen (:532-541), sixteen bases a step while both sequences have them, then base by base
             uint32_t len = 1;
             if (!rc) {
-                for (uint32_t i = at + K, j = (uint32_t)off + K; i < n && j < fw.L && seq_base(read, i) == fw.at(j); ++i, ++j) ++len;
+                uint32_t i = at + K, j = (uint32_t)off + K;
+                for (;;) {
+                    if (i + 16u > n || j + 16u > fw.L) break;
+                    const uint32_t x = bases16(rwords, r_nwords, r_byte0, i) ^ bases16(ewords, G.store_words, er.byte_off, j);
+                    if (x) { const uint32_t m = (uint32_t)__builtin_ctz(x) >> 1; len += m; i = n; break; }   // (i = n: the loop below has nothing left to do)
+                    len += 16u; i += 16u; j += 16u;
+                }
+                for (; i < n && j < fw.L && seq_base(read, i) == fw.at(j); ++i, ++j) ++len;
             } else {
                 const EdgeView bw{fw.p, fw.L, true};
                 off = (int32_t)fw.L - off;
-                for (uint32_t i = at + K, j = (uint32_t)off; i < n && j < bw.L && seq_base(read, i) == bw.at(j); ++i, ++j) ++len;
+                uint32_t i = at + K, j = (uint32_t)off;                 // j: index on the reverse complement = stored position L-1-j, walked downwards
+                for (;;) {
+                    if (i + 16u > n || j + 16u > bw.L) break;
+                    const uint32_t e = bases16(ewords, G.store_words, er.byte_off, bw.L - 16u - j);   // stored positions L-16-j .. L-1-j
+                    const uint32_t x = bases16(rwords, r_nwords, r_byte0, i) ^ rev2_32(~e);
+                    if (x) { const uint32_t m = (uint32_t)__builtin_ctz(x) >> 1; len += m; i = n; break; }
+                    len += 16u; i += 16u; j += 16u;
+                }
+                for (; i < n && j < bw.L && seq_base(read, i) == bw.at(j); ++i, ++j) ++len;
                 off -= K;
             }
             parts[np++] = PartD{c, rc ? ~off : off, len, fw.L - (uint32_t)K + 1u};
@@ -312,7 +351,7 @@ k_path_slots(const uint32_t* __restrict__ read_len, uint64_t r0, uint64_t nb, ui
 template <int K>
 __global__ void __launch_bounds__(256)
 k_path_reads(PartTable pt, const uint32_t* __restrict__ index, uint64_t mask, PathGraph G,
-             const uint8_t* __restrict__ packed, const uint64_t* __restrict__ base_off, const uint32_t* __restrict__ read_len,
+             const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off, const uint32_t* __restrict__ read_len,
              const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, uint64_t r0, uint64_t nb,
              const uint64_t* __restrict__ slot_off, PartD* __restrict__ parts_all, int32_t* __restrict__ path_all, uint8_t* __restrict__ qual_all,
              int32_t* __restrict__ out_offset, uint32_t* __restrict__ out_len, uint32_t* __restrict__ out_first,
@@ -326,7 +365,7 @@ k_path_reads(PartTable pt, const uint32_t* __restrict__ index, uint64_t mask, Pa
         PartD* parts = parts_all + so;
         int32_t* path = path_all + 2 * so + 2 * i;
         uint8_t* q = qual_all + so + i * K;
-        uint32_t np = path_parts<K>(pt, index, mask, G, read, n, parts, bad);
+        uint32_t np = path_parts<K>(pt, index, mask, G, reinterpret_cast<const uint32_t*>(packed), (packed_bytes + 3) >> 2, base_off[r], read, n, parts, bad);
         if (np > s) atomicOr(bad, 8u);                                            // (cannot happen: every part covers a k-mer position of its own)
         np = edit_parts<K>(G, parts, np);
         // pathPartsToReadPath
@@ -383,11 +422,11 @@ k_path_sizes(const uint32_t* __restrict__ out_len, uint64_t nb, uint64_t* __rest
 __global__ void __launch_bounds__(256)
 k_path_emit(const uint64_t* __restrict__ size_off, const uint64_t* __restrict__ slot_off, const int32_t* __restrict__ path_all,
             const int32_t* __restrict__ out_offset, const uint32_t* __restrict__ out_len, const uint32_t* __restrict__ out_first,
-            uint64_t nb, uint64_t file_base, uint32_t* __restrict__ var, uint64_t* __restrict__ elem_off)
+            uint64_t nb, uint32_t* __restrict__ var, uint32_t* __restrict__ elem_off /* byte offset of every element inside the batch's data */)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
         const uint64_t at = size_off[i];
-        elem_off[i] = file_base + at;
+        elem_off[i] = (uint32_t)at;
         uint32_t* o = var + (at >> 2);
         o[0] = (uint32_t)out_offset[i]; o[1] = 0u;                               // mLastSkip: never set (ReadPath.h:27-29)
         const int32_t* p = path_all + 2 * slot_off[i] + 2 * i + out_first[i];
@@ -435,11 +474,11 @@ k_read_digest(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ b
 
 // ---- writePathsIndex (10X/PathsIndex.cc:23-146): the (edge, read) pairs of every path entry, in read order
 __global__ void __launch_bounds__(256)
-k_pidx_pairs(const uint32_t* __restrict__ var, const uint64_t* __restrict__ elem_off, uint64_t nb, uint64_t r0, uint64_t file_base, uint64_t var_bytes,
+k_pidx_pairs(const uint32_t* __restrict__ var, const uint32_t* __restrict__ elem_off, uint64_t nb, uint64_t r0, uint64_t var_bytes,
              uint64_t pair_base, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
-        const uint64_t w0 = (elem_off[i] - file_base) >> 2, w1 = (i + 1 < nb ? elem_off[i + 1] - file_base : var_bytes) >> 2;
+        const uint64_t w0 = elem_off[i] >> 2, w1 = (i + 1 < nb ? (uint64_t)elem_off[i + 1] : var_bytes) >> 2;
         // the element's first path entry is entry number (w0 - 2 i) of the batch: every element before it spent two words on offset and lastSkip
         uint64_t at = pair_base + (w0 - 2 * i);
         for (uint64_t w = w0 + 2; w < w1; ++w, ++at) { const uint32_t e = var[w]; keys[at] = e; vals[at] = (uint32_t)(r0 + i); atomicAdd(&counts[e], 1u); }
@@ -520,9 +559,9 @@ k_pidx_tables(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ 
     }
 }
 __global__ void __launch_bounds__(256)
-k_widen_u32(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out)
+k_widen_u32(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out, uint64_t add = 0)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = in[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = in[i] + add;
 }
 
 // ---- MarkDups (10X/SecretOps.cc:410-566) without the sort: a read's group is its key -- first edge (29 bits), offset on it
@@ -534,10 +573,10 @@ constexpr unsigned long long DUP_EMPTY = ~0ull;
 constexpr int32_t DUP_OFF_BIAS = 1 << 16;
 __device__ __forceinline__ uint64_t dup_hash(uint64_t k) { k ^= k >> 31; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 29; k *= 0xBF58476D1CE4E5B9ull; return k ^ (k >> 32); }
 // key of read r of the batch, or DUP_EMPTY if it has no path; *score = what atomicMax compares
-__device__ __forceinline__ uint64_t dup_key(const uint32_t* __restrict__ var, const uint64_t* __restrict__ elem_off, uint64_t i, uint64_t nb, uint64_t r0,
-                                            uint64_t file_base, uint64_t var_bytes, const uint32_t* __restrict__ digest, uint64_t* score, unsigned int* bad)
+__device__ __forceinline__ uint64_t dup_key(const uint32_t* __restrict__ var, const uint32_t* __restrict__ elem_off, uint64_t i, uint64_t nb, uint64_t r0,
+                                            uint64_t var_bytes, const uint32_t* __restrict__ digest, uint64_t* score, unsigned int* bad)
 {
-    const uint64_t w0 = (elem_off[i] - file_base) >> 2, w1 = (i + 1 < nb ? elem_off[i + 1] - file_base : var_bytes) >> 2;
+    const uint64_t w0 = elem_off[i] >> 2, w1 = (i + 1 < nb ? (uint64_t)elem_off[i + 1] : var_bytes) >> 2;
     if (w1 - w0 <= 2) return DUP_EMPTY;
     const int32_t off = (int32_t)var[w0];
     const uint32_t e = var[w0 + 2];
@@ -549,13 +588,13 @@ __device__ __forceinline__ uint64_t dup_key(const uint32_t* __restrict__ var, co
 }
 template <bool MARK>
 __global__ void __launch_bounds__(256)
-k_dup_pass(const uint32_t* __restrict__ var, const uint64_t* __restrict__ elem_off, uint64_t nb, uint64_t r0, uint64_t file_base, uint64_t var_bytes,
+k_dup_pass(const uint32_t* __restrict__ var, const uint32_t* __restrict__ elem_off, uint64_t nb, uint64_t r0, uint64_t var_bytes,
            const uint32_t* __restrict__ digest, unsigned long long* __restrict__ tkey, unsigned long long* __restrict__ tbest, uint64_t mask,
            uint32_t n_pass, uint32_t pass, uint8_t* __restrict__ dup, unsigned int* __restrict__ bad)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
         uint64_t score = 0;
-        const uint64_t k = dup_key(var, elem_off, i, nb, r0, file_base, var_bytes, digest, &score, bad);
+        const uint64_t k = dup_key(var, elem_off, i, nb, r0, var_bytes, digest, &score, bad);
         if (k == DUP_EMPTY) continue;
         const uint64_t h = dup_hash(k);
         if ((uint32_t)(h >> 40) % n_pass != pass) continue;

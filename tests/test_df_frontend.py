@@ -117,7 +117,7 @@ def _kvec(path):
 @pytest.mark.gpu
 def test_df_end_to_end_on_gpu(tmp_path, golden_dir, oracle):
     from tests import util
-    r = run_df(f"LR={golden_dir}/reads.fastb", f"OUT_DIR={tmp_path}/w", "K=48")
+    r = run_df(f"LR={golden_dir}/reads.fastb", f"OUT_DIR={tmp_path}/w", "K=48", "KVEC=True")
     assert r.returncode == 0, r.stdout + r.stderr
     exp = np.load(f"{golden_dir}/expect_k48.npz")
     assert open(f"{tmp_path}/w/stats/histogram_kmer_count.json").read() == oracle.spectrum_json(exp["spectrum"])
@@ -145,6 +145,7 @@ def test_df_writes_paths_index_and_dups(tmp_path, golden_dir):
     duplicate marks -- what 10X/DF.cc:541-561 leaves behind -- byte for byte as the reference's classes wrote them."""
     r = run_df(f"LR={golden_dir}/frag.fastb", f"OUT_DIR={tmp_path}/w", "K=48", "HBM_GB=8")
     assert r.returncode == 0, r.stdout + r.stderr
+    assert not os.path.exists(f"{tmp_path}/w/kmers.kvec")              # transient in the reference (BuildReadQGraph48.cc:303): not left behind unless asked for
     for f in ("a.fastb", "a.hbv", "a.inv", "a.paths", "a.paths.inv", "a.countsb", "a.dup"):
         assert open(f"{tmp_path}/w/a.48/{f}", "rb").read() == open(f"{golden_dir}/graph_frag_k48/{f}", "rb").read(), f
     assert "% of pairs appear to be duplicates" in r.stdout
@@ -157,7 +158,7 @@ def test_runall_command_line_on_gpu(tmp_path, golden_dir, oracle):
     from tests import util
     env = dict(os.environ, DFK_XFER_CHUNK="4096", DFK_HOST_THREADS="3")
     r = subprocess.run([DF, f"ROOT={tmp_path}", f"LR={golden_dir}/reads.fastb", "PIPELINE=cs", "ALIGN=False", "NUM_THREADS=8",
-                        "MAX_MEM_GB=640"], capture_output=True, text=True, env=env)
+                        "MAX_MEM_GB=640", "KVEC=True"], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     exp = np.load(f"{golden_dir}/expect_k48.npz")
     w = f"{tmp_path}/GapToy/1"
@@ -171,7 +172,7 @@ def test_df_general_path_on_gpu(tmp_path, golden_dir, oracle):
     """Two inputs (LoadData reorders): the gathered arrays go through the same count."""
     from tests import util
     from oracle import pyoracle
-    r = run_df("LR={" + f"{golden_dir}/reads.fastb,{golden_dir}/reads.fastb" + "}", f"OUT_DIR={tmp_path}/w", "K=48", "HBM_GB=8")
+    r = run_df("LR={" + f"{golden_dir}/reads.fastb,{golden_dir}/reads.fastb" + "}", f"OUT_DIR={tmp_path}/w", "K=48", "HBM_GB=8", "KVEC=True")
     assert r.returncode == 0, r.stdout + r.stderr
     assert '"fast_path": false' in r.stdout
     w = f"{tmp_path}/w/data/frag_reads_orig"
@@ -206,7 +207,7 @@ def test_df_num_gpus_cpp_host(tmp_path, golden_dir, oracle, mode):
         args, env["DF_TRANSPORT"] = [f"NUM_GPUS={mode[-1]}"], "loopback"
         env["DFK_A2A_PIECE_BYTES"] = "4096"                               # several rounds per pair of ranks
     r = subprocess.run([DF, f"ROOT={tmp_path}", f"LR={golden_dir}/reads.fastb", "PIPELINE=cs", "ALIGN=False", "NUM_THREADS=8", "MAX_MEM_GB=640",
-                        "HBM_GB=8", *args], capture_output=True, text=True, env=env, timeout=600)
+                        "HBM_GB=8", "KVEC=True", *args], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     exp = np.load(f"{golden_dir}/expect_k48.npz")
     w = f"{tmp_path}/GapToy/1"
@@ -258,9 +259,9 @@ def test_df_num_gpus_larger_set_equals_single_gpu(tmp_path, oracle):
     feudal.write_fastb(f"{tmp_path}/r.fastb", rs["packed"], rs["base_off"], rs["read_len"])
     feudal.write_qualp(f"{tmp_path}/r.qualp", rs["pq_bytes"], rs["pq_off"])
     feudal.write_bci(f"{tmp_path}/r.bci", rs["bci"])
-    a = subprocess.run([DF, f"OUT_DIR={tmp_path}/one", f"LR={tmp_path}/r.fastb", "HBM_GB=16"], capture_output=True, text=True, timeout=600)
+    a = subprocess.run([DF, f"OUT_DIR={tmp_path}/one", f"LR={tmp_path}/r.fastb", "HBM_GB=16", "KVEC=True"], capture_output=True, text=True, timeout=600)
     assert a.returncode == 0, a.stdout + a.stderr
-    b = subprocess.run([DF, f"OUT_DIR={tmp_path}/four", f"LR={tmp_path}/r.fastb", "NUM_GPUS=4", "HBM_GB=4"], capture_output=True, text=True, timeout=600,
+    b = subprocess.run([DF, f"OUT_DIR={tmp_path}/four", f"LR={tmp_path}/r.fastb", "NUM_GPUS=4", "HBM_GB=4", "KVEC=True"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, DF_TRANSPORT="loopback"))
     assert b.returncode == 0, b.stdout + b.stderr
     assert open(f"{tmp_path}/one/stats/histogram_kmer_count.json").read() == open(f"{tmp_path}/four/stats/histogram_kmer_count.json").read()
