@@ -58,6 +58,8 @@ bool g_trace = getenv("DFK_TRACE") != nullptr;
 template <int K> struct CountCfg;
 #ifndef DFK_LOG2S
 #define DFK_LOG2S 11
+#endif
+#ifndef DFK_NWAVES
 #define DFK_NWAVES 8
 #endif
 template <> struct CountCfg<40> { static constexpr int LOG2S = DFK_LOG2S, NWAVES = DFK_NWAVES; };
@@ -404,7 +406,7 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     if (by_class) { rc = c->alloc(T->class_hist, n_bins * 8, "class counters", true); if (rc) return rc; HIP_TRY(hipMemsetAsync(T->class_hist.p, 0, n_bins * 8, c->stream)); }
     else { rc = c->alloc(T->acc, nb * 8, "bucket counters", true); if (rc) return rc; }
     rc = c->alloc(T->summ, std::max<uint64_t>(1, in.n_reads) * 16, "run summaries", true); if (rc) return rc;
-    rc = c->alloc(T->classes, std::max<uint64_t>(1, in.n_reads) * 4, "read bucket classes", true); if (rc) return rc;
+    rc = c->alloc(T->classes, read_classes_bytes(std::max<uint64_t>(1, in.n_reads)), "read bucket classes", true); if (rc) return rc;
     if (!by_class) HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
     unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
     static const unsigned scan_blocks = getenv("DFK_SCAN_BLOCKS") ? (unsigned)atoi(getenv("DFK_SCAN_BLOCKS")) : 0;

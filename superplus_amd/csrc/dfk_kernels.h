@@ -124,6 +124,20 @@ struct PartParams {
 // not look at the other reads at all: a read has ~4 runs, so a pass over 1/8 of the buckets needs ~45 % of the
 // reads, one over 1/32 of them 11 %.
 constexpr uint32_t SWEEP_CLASSES = 32;
+// -DDFK_RUN_CLASSES (measured, not the default): behind the masks, in the same buffer, per read one 64-bit word with the
+// class of EACH of its (up to ten) runs, five bits a run.  A sweep then rebuilds the bucket -- a random read of the
+// minimizer's bases and a hash -- only for the runs whose class the pass touches instead of for every run of every listed
+// read (that look-up is four times as frequent as the records a sweep writes).  At configs[1]: a sweep takes 81.7 ms
+// instead of 95.9 -- but the 8 bytes per read (14.4 GB) make it 11 passes instead of 9, and the step comes out the same
+// (1504 against 1508 ms); the sweeps hide under the counts either way.
+#ifndef DFK_RUN_CLASSES
+__host__ __device__ inline uint64_t read_classes_bytes(uint64_t n_reads) { return n_reads * 4; }
+__device__ __forceinline__ const uint64_t* run_classes_of(const uint32_t*, uint64_t) { return nullptr; }
+#else
+__host__ __device__ inline uint64_t read_classes_bytes(uint64_t n_reads) { return ((n_reads + 1) & ~1ull) * 4 + n_reads * 8; }
+__device__ __forceinline__ const uint64_t* run_classes_of(const uint32_t* read_classes, uint64_t n_reads)
+{ return read_classes ? reinterpret_cast<const uint64_t*>(read_classes + ((n_reads + 1) & ~1ull)) : nullptr; }
+#endif
 __host__ __device__ inline uint32_t sweep_class_of(uint32_t local_bucket, uint32_t log2_local)
 { return log2_local > 5 ? local_bucket >> (log2_local - 5) : local_bucket; }
 __host__ __device__ inline uint32_t sweep_class_mask(uint32_t sub_lo, uint32_t sub_n, uint32_t log2_local)
@@ -232,11 +246,12 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
     const uint32_t M = pp.M, W = pp.W;
     const uint32_t gl = r < n_reads ? good_len[r] : 0;
     if (gl < (uint32_t)K + 1) {                                  // Kmerizer::map: len < K+1 emits nothing (:153)
-        if (!WRITE && r < n_reads) { summaries[r] = uint4{0, 0, 0, 0}; if (read_classes) read_classes[r] = 0u; }
+        if (!WRITE && r < n_reads) { summaries[r] = uint4{0, 0, 0, 0}; if (read_classes) { read_classes[r] = 0u; if (uint64_t* rc_ = const_cast<uint64_t*>(run_classes_of(read_classes, n_reads))) rc_[r] = 0ull; } }
         return;
     }
     uint32_t Pi = 0, cur_rel = 0;                                // !WRITE: where the prefix minimum sits; minimizer offset of the open run
     uint32_t cmask = 0;                                          // !WRITE: classes of the runs' buckets (the sweeps' prefilter)
+    uint64_t rcls = 0;                                           // !WRITE: ... and run by run, five bits each
     const uint32_t log2_local = pp.log2_nb - pp.log2_world;
 
     const uint64_t byte0 = base_off[r];
@@ -281,7 +296,9 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
         if (!WRITE) {
             if (lh) { const uint32_t bin = class_bin(cur_b, pp); atomicAdd(&lh[bin], 1u); atomicAdd(&lh[(PART_CLASSES << pp.log2_world) + bin], cur_nk); }
             else atomicAdd(&bucket_acc[cur_b], (1ull << 32) | cur_nk);
-            cmask |= 1u << sweep_class_of(cur_b & ((1u << log2_local) - 1u), log2_local);
+            const uint32_t cls = sweep_class_of(cur_b & ((1u << log2_local) - 1u), log2_local);
+            cmask |= 1u << cls;
+            if (qn < (uint32_t)SUMMARY_RUNS) rcls |= (uint64_t)cls << (5u * qn);
             if (qn < (uint32_t)SUMMARY_RUNS) {                          // 12 bits per run from bit 8 (kept in registers: LDS is what limits this kernel's occupancy)
                 const uint64_t fld = cur_nk | (cur_rel << 6);
                 const uint32_t b = 8u + 12u * qn;
@@ -368,7 +385,7 @@ partition_read(uint64_t r, uint32_t* smem, uint32_t* __restrict__ lh,
         // scatter), then 12 bits per run from bit 8
         const uint64_t lo = sum_lo | (qn <= (uint32_t)SUMMARY_RUNS ? qn : SUMMARY_OVERFLOW), hi = sum_hi;
         summaries[r] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-        if (read_classes) read_classes[r] = cmask;
+        if (read_classes) { read_classes[r] = cmask; if (uint64_t* rc_ = const_cast<uint64_t*>(run_classes_of(read_classes, n_reads))) rc_[r] = rcls; }
         // a read with more runs than a summary holds goes on the list of reads the scanning scatter handles (two in
         // 10^5; in the counting scan `bucket_cur` is that list's counter, `records` the list, `n_out` its capacity)
         if (qn > (uint32_t)SUMMARY_RUNS && bucket_cur) {
@@ -461,7 +478,7 @@ k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const ui
         const uint32_t gl = r < n_reads ? good_len[r] : 0;
         const bool live = gl >= (uint32_t)K + 1;                         // Kmerizer::map: len < K+1 emits nothing (:153)
         uint32_t qn = 0, cmask = 0;
-        uint64_t sum_lo = 0, sum_hi = 0;
+        uint64_t sum_lo = 0, sum_hi = 0, rcls = 0;
         if (live) {
             const uint64_t bit0 = base_off[r] * 8;
             uint64_t wi = bit0 >> 5, filled_to = wi;
@@ -547,13 +564,15 @@ k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const ui
                 const uint32_t nk = (uint32_t)(bfld + 12 <= 64 ? sum_lo >> bfld : bfld >= 64 ? sum_hi >> (bfld - 64) : (sum_lo >> bfld) | (sum_hi << (64 - bfld))) & 63u;
                 if (lh) { const uint32_t bin = class_bin(cb, pp); atomicAdd(&lh[bin], 1u); atomicAdd(&lh[(PART_CLASSES << pp.log2_world) + bin], nk); }
                 else atomicAdd(&bucket_acc[cb], (1ull << 32) | nk);
-                cmask |= 1u << sweep_class_of(cb & ((1u << log2_local) - 1u), log2_local);
+                const uint32_t cls = sweep_class_of(cb & ((1u << log2_local) - 1u), log2_local);
+                cmask |= 1u << cls;
+                rcls |= (uint64_t)cls << (5u * i);
             }
         }
         if (r < n_reads) {
             const uint64_t lo = sum_lo | (qn <= (uint32_t)SUMMARY_RUNS ? qn : SUMMARY_OVERFLOW);
             summaries[r] = uint4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)sum_hi, (uint32_t)(sum_hi >> 32)};
-            if (read_classes) read_classes[r] = cmask;
+            if (read_classes) { read_classes[r] = cmask; if (uint64_t* rc_ = const_cast<uint64_t*>(run_classes_of(read_classes, n_reads))) rc_[r] = rcls; }
         }
         if (qn > (uint32_t)SUMMARY_RUNS) {
             const unsigned long long at = atomicAdd(ovf_count, 1ull);
@@ -574,11 +593,12 @@ constexpr int SLICE_READS = 16;
 template <int K, bool EMIT, typename F>
 __device__ __forceinline__ void for_each_run_in_pass(uint64_t r, const uint8_t* __restrict__ packed, uint64_t packed_bytes,
                                                      const uint64_t* __restrict__ base_off, const PartParams& pp,
-                                                     const uint4* __restrict__ summaries, F&& f)
+                                                     const uint4* __restrict__ summaries, const uint64_t* __restrict__ run_classes, F&& f)
 {
     const uint4 sm = summaries[r];
     const uint32_t n = sm.x & 15u;
     if (n == 0 || n == SUMMARY_OVERFLOW) return;
+    const uint64_t rcls = run_classes ? run_classes[r] : 0ull;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
     const uint64_t n_words = (packed_bytes + 3) >> 2;
     const uint64_t bit0 = base_off[r] * 8;
@@ -593,6 +613,7 @@ __device__ __forceinline__ void for_each_run_in_pass(uint64_t r, const uint8_t* 
             const int b = B0 + 12 * i;
             const uint32_t fld = (uint32_t)(b + 12 <= 64 ? lo >> b : b >= 64 ? hi >> (b - 64) : (lo >> b) | (hi << (64 - b))) & 0xFFFu;
             const uint32_t nk = fld & 63u, rel = fld >> 6;
+            if (run_classes && !((pp.class_mask >> ((uint32_t)(rcls >> (5 * i)) & 31u)) & 1u)) { s0 += nk; continue; }   // a run of a class this pass does not touch
             const uint64_t bo = bit0 + 2ull * (s0 + rel);
             const uint64_t wi = bo >> 5;
             const uint32_t w0 = words[wi], w1 = wi + 1 < n_words ? words[wi + 1] : 0u;
@@ -641,7 +662,7 @@ k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, cons
     __syncthreads();
     const uint32_t n = n_list;
     for (uint32_t i = threadIdx.x; i < n; i += 256)
-        for_each_run_in_pass<K, false>(r_block + list[i], packed, packed_bytes, base_off, pp, summaries,
+        for_each_run_in_pass<K, false>(r_block + list[i], packed, packed_bytes, base_off, pp, summaries, run_classes_of(read_classes, n_reads),
                                        [&](uint32_t, uint32_t, uint32_t, uint32_t owner, uint64_t, bool) { atomicAdd(&cnt[owner], 1u); });
     __syncthreads();
     if (threadIdx.x < world) {
@@ -657,7 +678,7 @@ k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, cons
         const uint64_t r = r_block + list[i];
         int32_t tag = -1;
         if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
-        for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
+        for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries, run_classes_of(read_classes, n_reads),
             [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t owner, uint64_t bit0, bool last) {
                 const uint64_t dst = at[owner] + atomicAdd(&cnt[owner], 1u);
                 // only the read's last run has no successor base (its last k-mer ends the trimmed read)
@@ -673,7 +694,10 @@ k_scatter_slices(const uint8_t* __restrict__ packed, uint64_t packed_bytes, cons
 // reads per thread of a k_scatter_runs block.  The block's list lives in LDS, and the sweep runs beside k_count,
 // whose two workgroups per CU leave 16 KB of LDS at K=40/48 and 8 KB at K=60: with 4 KB lists a K=60 sweep got one
 // block per CU and ran 3.6 times longer than alone.
-template <int K> constexpr int sweep_reads() { return KTraits<K>::KW == 4 ? 2 : 8; }
+#ifndef DFK_SWEEP_READS
+#define DFK_SWEEP_READS 8
+#endif
+template <int K> constexpr int sweep_reads() { return KTraits<K>::KW == 4 ? 2 : DFK_SWEEP_READS; }
 template <int K>
 __global__ void __launch_bounds__(256)
 k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
@@ -712,7 +736,7 @@ k_scatter_runs(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const 
         const uint64_t r = r_block + list[i];
         int32_t tag = -1;
         if (bc && (int64_t)r + pp.read_id0 >= ign_bc_below) tag = bc[r];
-        for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries,
+        for_each_run_in_pass<K, true>(r, packed, packed_bytes, base_off, pp, summaries, run_classes_of(read_classes, n_reads),
             [&](uint32_t s0, uint32_t nk, uint32_t lb, uint32_t, uint64_t bit0, bool last) {
                 const uint64_t dst = atomicAdd(&bucket_cur[lb], 1ull);             // one random access for base and rank
                 // only the read's last run has no successor base (its last k-mer ends the trimmed read)
