@@ -422,11 +422,14 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     rc = c->alloc(ovf_tmp, ovf_cap * 4, "overflow read list (scratch)"); if (rc) return rc;
     rc = c->alloc(d_n, 16, "overflow read count"); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
-    // the minimizer length everybody uses gets the scan whose window lives in registers; other lengths the general one
+    // the minimizer length everybody uses gets the scan whose window lives in registers; other lengths the general one --
+    // and K = 60, whose window of 45 hashes and 45 positions the compiler keeps in scratch, not in registers: 593 ms
+    // against the LDS version's ~400 (k_sweep of the bench; K = 40: 510 ms at 165 VGPRs, as fast as the LDS version)
     static const bool old_scan = getenv("DFK_OLD_SCAN") != nullptr;
-    if (grid && pp.M == 16 && !old_scan) {
+    constexpr bool window_fits_registers = K - 16 + 1 <= 33;
+    if (grid && pp.M == 16 && window_fits_registers && !old_scan) {
         const size_t lds_r = sizeof(uint32_t) * (PART_RING + SUMMARY_RUNS) * PART_THREADS + (by_class ? n_bins * 4 : 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_count<K, 16>), dim3(grid), dim3(PART_THREADS), lds_r, c->stream,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_count<(window_fits_registers ? K : 48), 16>), dim3(grid), dim3(PART_THREADS), lds_r, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.n_reads, pp,
                            (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p, (unsigned long long*)d_n.p, ovf_cap,
                            (uint32_t*)ovf_tmp.p, (uint4*)T->summ.p, (uint32_t*)T->classes.p);

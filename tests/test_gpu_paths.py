@@ -119,3 +119,55 @@ def test_paths_index_and_dups_match_oracle(oracle, tmp_path, seed, G, pairs):
     for f, b in exp.items():
         assert open(os.path.join(tmp_path, f), "rb").read() == b, f
     d.close()
+
+
+def test_paths_edge_cases(oracle, tmp_path):
+    """Reads shorter than K, reads with no solid k-mer at all (random bases seen once), device-resident inputs, an odd number
+    of reads, and the calls out of order."""
+    import torch
+    from oracle import graph_oracle, paths_oracle
+    from superplus_amd.dfk import Dfk, DfkError
+    rs = util.make_set(431, 40000, 3000)
+    # cut some reads below K and overwrite others with poly-C (no solid k-mer): rebuild the packed arrays
+    reads, quals = paths_oracle.unpack_reads(rs)
+    reads = [bytes(r) for r in reads]
+    for i in range(0, len(reads), 97):
+        reads[i] = reads[i][:30]; quals[i] = quals[i][:30]
+    rng = np.random.default_rng(9)
+    for i in range(5, len(reads), 131):
+        reads[i] = rng.integers(0, 4, len(reads[i]), dtype=np.uint8).tobytes()
+    from superplus_amd import feudal
+    packed = np.concatenate([feudal.pack_bases(np.frombuffer(r, np.uint8)[None, :])[0] for r in reads])
+    read_len = np.array([len(r) for r in reads], np.uint32)
+    base_off = np.concatenate([[0], np.cumsum((read_len.astype(np.uint64) + 3) // 4)]).astype(np.uint64)
+    pqs = [np.frombuffer(feudal.pq_encode(np.asarray(q, np.uint8)), np.uint8) for q in quals]
+    pq_bytes = np.concatenate(pqs); pq_off = np.concatenate([[0], np.cumsum([len(x) for x in pqs])]).astype(np.uint64)
+    ref = oracle.run(packed, base_off, read_len, pq_bytes, pq_off, rs["bc"], K=48)
+    g = graph_oracle.run(ref["solid"], 48)
+    exp = paths_oracle.run(reads, quals, g, 48)
+    d = Dfk(K=48)
+    d.count(packed, base_off, read_len, pq_bytes, pq_off, rs["bc"])
+    with pytest.raises(DfkError):
+        d.paths_index_write(str(tmp_path))                                 # no paths yet
+    d.graph_build()
+    dev = torch.device("cuda:0")
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt) if dt is not None else np.ascontiguousarray(a)).to(dev)
+    packed_d = torch.cat([t(packed, None), torch.zeros(8, dtype=torch.uint8, device=dev)])      # (the stream is read as aligned words)
+    st = d.paths_build_device(packed_d, t(base_off, np.int64), t(read_len, np.int32), torch.cat([t(pq_bytes, None), torch.zeros(8, dtype=torch.uint8, device=dev)]), t(pq_off, np.int64))
+    assert st["n_reads"] == len(reads)
+    out = os.path.join(tmp_path, "a.paths"); d.paths_write(out)
+    got = open(out, "rb").read()
+    assert got == exp["file"], explain(got, exp["file"])
+    want = decode_paths(got)
+    assert all(not want[i][1] for i in range(0, len(reads), 97)) and all(not want[i][1] for i in range(5, len(reads), 131))
+    d.paths_index_write(str(tmp_path)); d.dups_write(os.path.join(tmp_path, "a.dup"))
+    files = paths_oracle.paths_index(exp["paths"], g["hbv"].involution()); files["a.dup"] = paths_oracle.mark_dups(exp["paths"], reads, quals)
+    for f, b in files.items():
+        assert open(os.path.join(tmp_path, f), "rb").read() == b, f
+    with pytest.raises(DfkError):
+        d.paths_build(packed, base_off, read_len, pq_bytes, pq_off)        # the k-mer index went back to the arena with the paths index
+    d.graph_build()
+    d.paths_build(packed[: int(base_off[-2])], base_off[:-1], read_len[:-1], pq_bytes[: int(pq_off[-2])], pq_off[:-1])   # an odd number of reads paths fine ...
+    with pytest.raises(DfkError):
+        d.dups_write(os.path.join(tmp_path, "b.dup"))                      # ... but MarkDups works on pairs
+    d.close()
