@@ -79,11 +79,11 @@ __device__ __forceinline__ int32_t part_hbv_edge(const PathGraph& G, const PartD
 // ---- Pather::path
 // KmerDict::findEntry (kmers/ReadPather.h:222-225) through the edge builder's index: entry index or GRAPH_EMPTY
 template <int K>
-__device__ __forceinline__ uint32_t dict_find(const PartTable& pt, const uint32_t* __restrict__ index, uint64_t mask, u128 v)
+__device__ __forceinline__ uint32_t dict_find(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, u128 v)
 { uint32_t ctx; bool pal; return graph_lookup<K>(pt, index, mask, v, &ctx, &pal); }
 
 template <int K>
-__device__ uint32_t path_parts(const PartTable& pt, const uint32_t* __restrict__ index, uint64_t mask, const PathGraph& G,
+__device__ uint32_t path_parts(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, const PathGraph& G,
                                const uint32_t* __restrict__ rwords, uint64_t r_nwords, uint64_t r_byte0,
                                const uint8_t* __restrict__ read, uint32_t n, PartD* __restrict__ parts, unsigned int* __restrict__ bad)
 {
@@ -350,13 +350,15 @@ k_path_slots(const uint32_t* __restrict__ read_len, uint64_t r0, uint64_t nb, ui
 
 template <int K>
 __global__ void __launch_bounds__(256)
-k_path_reads(PartTable pt, const uint32_t* __restrict__ index, uint64_t mask, PathGraph G,
+k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t mask, PathGraph G,
              const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off, const uint32_t* __restrict__ read_len,
              const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, uint64_t r0, uint64_t nb,
              const uint64_t* __restrict__ slot_off, PartD* __restrict__ parts_all, int32_t* __restrict__ path_all, uint8_t* __restrict__ qual_all,
              int32_t* __restrict__ out_offset, uint32_t* __restrict__ out_len, uint32_t* __restrict__ out_first,
              unsigned long long* __restrict__ stats /* [0] reads placed, [1] path edges */, unsigned int* __restrict__ bad)
 {
+    __shared__ PartLds pt;
+    part_lds_init(pt_arg, pt);
     unsigned long long placed = 0, n_edges = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
         const uint64_t r = r0 + i, so = slot_off[i];
