@@ -77,13 +77,72 @@ __device__ __forceinline__ uint32_t from_size(const PathGraph& G, int32_t v) { r
 __device__ __forceinline__ int32_t part_hbv_edge(const PathGraph& G, const PartD& p) { const int2 x = G.xlat[p.edge]; return part_rc(p) ? x.y : x.x; }
 
 // ---- Pather::path
-// KmerDict::findEntry (kmers/ReadPather.h:222-225) through the edge builder's index: entry index or GRAPH_EMPTY
+// KmerDict::findEntry (kmers/ReadPather.h:222-225) through the edge builder's index: entry index or GRAPH_EMPTY, and the
+// entry's second half ((edge, offset) since the graph was built) read beside its key rather than after it.
+struct DictKey { uint64_t w0, w1, slot; };
+template <int K> __device__ __forceinline__ DictKey dict_key(uint64_t mask, u128 v)
+{
+    const u128 R = kmer_rc<K>(v);
+    const u128 c = lt128(R, v) ? R : v;
+    const u128 kw = shl128(c, 128 - KTraits<K>::BITS);
+    return DictKey{kw.hi, kw.lo, set_hash(kw.hi, kw.lo) & mask};
+}
+__device__ __forceinline__ bool key_is(const uint4 a, const DictKey& k)
+{ return ((uint64_t)a.x | ((uint64_t)a.y << 32)) == k.w0 && ((uint64_t)a.z | ((uint64_t)a.w << 32)) == k.w1; }
+// the probe sequence from slot s on
+__device__ __forceinline__ uint32_t dict_probe(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, const DictKey& k, uint64_t s, uint4* second)
+{
+    for (uint32_t guard = 0; guard < 1u << 20; ++guard) {
+        const uint32_t g = index[s];
+        if (g == GRAPH_EMPTY) return GRAPH_EMPTY;
+        const uint4* e = entry_ptr(pt, g);
+        const uint4 a = e[0], b = e[1];
+        if (key_is(a, k)) { *second = b; return g; }
+        s = (s + 1) & mask;
+    }
+    return GRAPH_EMPTY;
+}
+// In front of the index, a filter of two bytes per k-mer: one 32-bit word per key, four of its bits.  A wrong base in a read
+// makes K look-ups in a row miss, and a miss in the index is 2.7 scattered reads on average (slots at load 1/2, and the key
+// of every occupied slot on the way lies in its entry); the filter answers 99.5 % of them with one.  What it lets through
+// the index decides as before.
+struct KmerFilter { const uint32_t* words; uint64_t n_words; };
+__device__ __forceinline__ void filter_place(const DictKey& k, uint64_t n_words, uint64_t* word, uint32_t* bits)
+{
+    const uint64_t h = (k.w0 ^ (k.w1 * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+    const uint64_t h2 = (h ^ (h >> 32)) * 0xD6E8FEB86659FD93ull;
+    *word = __umul64hi(h2, n_words);
+    const uint32_t x = (uint32_t)(h >> 7);
+    *bits = (1u << (x & 31)) | (1u << ((x >> 5) & 31)) | (1u << ((x >> 10) & 31)) | (1u << ((x >> 15) & 31));
+}
 template <int K>
-__device__ __forceinline__ uint32_t dict_find(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, u128 v)
-{ uint32_t ctx; bool pal; return graph_lookup<K>(pt, index, mask, v, &ctx, &pal); }
+__global__ void __launch_bounds__(256)
+k_filter_build(PartTable pt_arg, uint64_t n, uint32_t* __restrict__ words, uint64_t n_words)
+{
+    __shared__ PartLds pt;
+    part_lds_init(pt_arg, pt);
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (uint64_t)gridDim.x * 256) {
+        const uint4 a = entry_ptr(pt, g)[0];
+        const DictKey k{(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), 0};
+        uint64_t w; uint32_t bits;
+        filter_place(k, n_words, &w, &bits);
+        atomicOr(&words[w], bits);
+    }
+}
+template <int K>
+__device__ __forceinline__ uint32_t dict_find(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, const KmerFilter& F, u128 v, uint4* second)
+{
+    const DictKey k = dict_key<K>(mask, v);
+    if (F.words) {
+        uint64_t w; uint32_t bits;
+        filter_place(k, F.n_words, &w, &bits);
+        if ((F.words[w] & bits) != bits) return GRAPH_EMPTY;
+    }
+    return dict_probe(pt, index, mask, k, k.slot, second);
+}
 
 template <int K>
-__device__ uint32_t path_parts(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, const PathGraph& G,
+__device__ uint32_t path_parts(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, const KmerFilter& F, const PathGraph& G,
                                const uint32_t* __restrict__ rwords, uint64_t r_nwords, uint64_t r_byte0,
                                const uint8_t* __restrict__ read, uint32_t n, PartD* __restrict__ parts, unsigned int* __restrict__ bad)
 {
@@ -102,19 +161,20 @@ __device__ uint32_t path_parts(const PartLds& pt, const uint32_t* __restrict__ i
             ks.lo &= m.lo; ks.hi &= m.hi;
         }
         u128 km = shr128(u128{rev2_64(ks.hi), rev2_64(ks.lo)}, 128 - KTraits<K>::BITS);
-        uint32_t hit = dict_find<K>(pt, index, mask, km);
+        uint4 b;
+        // (a read's first k-mer is in the dictionary more often than not: no filter in front of that look-up)
+        uint32_t hit = dict_find<K>(pt, index, mask, np ? F : KmerFilter{nullptr, 0}, km, &b);
         if (hit == GRAPH_EMPTY) {
             uint32_t missed = 1, nxt = at + K;
             ++at;
             while (nxt != n) {
                 km = kmer_succ<K>(km, seq_base(read, nxt)); ++nxt;
-                if ((hit = dict_find<K>(pt, index, mask, km)) != GRAPH_EMPTY) break;
+                if ((hit = dict_find<K>(pt, index, mask, F, km, &b)) != GRAPH_EMPTY) break;
                 ++missed; ++at;
             }
             parts[np++] = part_gap_of(missed);
         }
         if (hit != GRAPH_EMPTY) {
-            const uint4 b = entry_ptr(pt, hit)[1];
             const uint32_t c = b.x;
             if (c >= G.n_ce) { atomicOr(bad, 4u); parts[np++] = part_gap_of(stop - at); break; }   // (an entry without an edge: the graph is not the dictionary's)
             int32_t off = (int32_t)(b.y & 0xFFFFFFu);
@@ -350,7 +410,7 @@ k_path_slots(const uint32_t* __restrict__ read_len, uint64_t r0, uint64_t nb, ui
 
 template <int K>
 __global__ void __launch_bounds__(256)
-k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t mask, PathGraph G,
+k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t mask, KmerFilter F, PathGraph G,
              const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off, const uint32_t* __restrict__ read_len,
              const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, uint64_t r0, uint64_t nb,
              const uint64_t* __restrict__ slot_off, PartD* __restrict__ parts_all, int32_t* __restrict__ path_all, uint8_t* __restrict__ qual_all,
@@ -367,7 +427,7 @@ k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t mask
         PartD* parts = parts_all + so;
         int32_t* path = path_all + 2 * so + 2 * i;
         uint8_t* q = qual_all + so + i * K;
-        uint32_t np = path_parts<K>(pt, index, mask, G, reinterpret_cast<const uint32_t*>(packed), (packed_bytes + 3) >> 2, base_off[r], read, n, parts, bad);
+        uint32_t np = path_parts<K>(pt, index, mask, F, G, reinterpret_cast<const uint32_t*>(packed), (packed_bytes + 3) >> 2, base_off[r], read, n, parts, bad);
         if (np > s) atomicOr(bad, 8u);                                            // (cannot happen: every part covers a k-mer position of its own)
         np = edit_parts<K>(G, parts, np);
         // pathPartsToReadPath
