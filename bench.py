@@ -274,6 +274,8 @@ def df_stage_wall(args, dev, local):
         t0 = time.perf_counter(); e0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
         wall = time.perf_counter() - t0; e1 = time.time()
+        if os.environ.get("DFK_TRACE") and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # the child's trace, for whoever asked for it
+            with open(os.path.join(ROOT, "gpurun_out", "df_child_trace.txt"), "w") as f: f.write(r.stderr)
         if r.returncode != 0:
             return {"error": f"DF exited {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
         timing = {}

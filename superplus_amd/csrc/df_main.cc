@@ -129,7 +129,13 @@ struct Mapped {
             (void)madvise(m, n, MADV_WILLNEED);
         }
     }
-    ~Mapped() { if (p) munmap((void*)p, n); if (fd >= 0) close(fd); }
+    ~Mapped()
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (p) munmap((void*)p, n);
+        if (fd >= 0) close(fd);
+        if (p && getenv("DFK_TRACE")) fprintf(stderr, "[DF] unmapped %.2f GB in %.3f s\n", n / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
 };
 
 // a mapped feudal file: control block, var data, absolute offset table, fixed data (feudal_io.h has the layout)

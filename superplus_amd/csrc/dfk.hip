@@ -1970,6 +1970,7 @@ int dfk_good_lens(dfk_ctx* c, uint32_t* out, uint64_t cap)
     return guarded([&]() -> int {
     if (!c || !c->have) return fail(DFK_E_STATE, "no completed count");
     if (cap < c->n_reads) return fail(DFK_E_ARG, "buffer too small");
+    if (c->n_reads && !c->good_len.p) return fail(DFK_E_STATE, "the trimmed lengths were given back when the reads were pathed (dfk_paths_build): fetch them before");
     HIP_TRY(hipSetDevice(c->device));
     if (c->n_reads) HIP_TRY(hipMemcpy(out, c->good_len.p, c->n_reads * 4, hipMemcpyDeviceToHost));
     return 0;

@@ -88,17 +88,21 @@ __device__ __forceinline__ uint32_t one_pred(uint32_t c) { return (uint32_t)__ff
 // a slot names an entry and the key is read from the entry itself (the dictionary is the key store).
 constexpr uint32_t GRAPH_EMPTY = 0xFFFFFFFFu;
 
+// where a key's probe sequence starts and how it goes on.  The table has as many slots as its load asks for, not the next
+// power of two (which at 3.1e9 k-mers would be 34 GB where 25 do).
+__device__ __forceinline__ uint64_t index_home(uint64_t hash, uint64_t n_slots) { return __umul64hi(hash, n_slots); }
+__device__ __forceinline__ uint64_t index_next(uint64_t s, uint64_t n_slots) { return s + 1 == n_slots ? 0 : s + 1; }
 template <int K>
 __global__ void __launch_bounds__(256)
-k_graph_index(PartTable pt_arg, uint64_t n, uint32_t* __restrict__ index, uint64_t mask)
+k_graph_index(PartTable pt_arg, uint64_t n, uint32_t* __restrict__ index, uint64_t n_slots)
 {
     __shared__ PartLds pt;
     part_lds_init(pt_arg, pt);
     for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n; g += (uint64_t)gridDim.x * 256) {
         const uint4 a = *entry_ptr(pt, g);
         const uint64_t w0 = (uint64_t)a.x | ((uint64_t)a.y << 32), w1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
-        uint64_t s = set_hash(w0, w1) & mask;
-        while (atomicCAS(&index[s], GRAPH_EMPTY, (uint32_t)g) != GRAPH_EMPTY) s = (s + 1) & mask;
+        uint64_t s = index_home(set_hash(w0, w1), n_slots);
+        while (atomicCAS(&index[s], GRAPH_EMPTY, (uint32_t)g) != GRAPH_EMPTY) s = index_next(s, n_slots);
     }
 }
 
@@ -106,7 +110,7 @@ k_graph_index(PartTable pt_arg, uint64_t n, uint32_t* __restrict__ index, uint64
 // (BuildReadQGraph48.cc:467-478).  Returns GRAPH_EMPTY if the k-mer is not in the dictionary (cannot happen for a
 // neighbour named by a context bit after recomputeAdjacencies; callers treat it as "stop").
 template <int K>
-__device__ __forceinline__ uint32_t graph_lookup(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, u128 v,
+__device__ __forceinline__ uint32_t graph_lookup(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t n_slots, u128 v,
                                                  uint32_t* ctx, bool* is_pal, bool* is_rev = nullptr)
 {
     const u128 R = kmer_rc<K>(v);
@@ -116,7 +120,7 @@ __device__ __forceinline__ uint32_t graph_lookup(const PartLds& pt, const uint32
     const u128 c = rev ? R : v;
     const u128 kw = shl128(c, 128 - KTraits<K>::BITS);
     const uint64_t w0 = kw.hi, w1 = kw.lo;
-    uint64_t s = set_hash(w0, w1) & mask;
+    uint64_t s = index_home(set_hash(w0, w1), n_slots);
     for (uint32_t guard = 0; guard < 1u << 20; ++guard) {
         const uint32_t g = index[s];
         if (g == GRAPH_EMPTY) return GRAPH_EMPTY;
@@ -127,7 +131,7 @@ __device__ __forceinline__ uint32_t graph_lookup(const PartLds& pt, const uint32
             *ctx = rev ? ctx_rc(cx) : cx;
             return g;
         }
-        s = (s + 1) & mask;
+        s = index_next(s, n_slots);
     }
     return GRAPH_EMPTY;
 }
@@ -152,7 +156,7 @@ enum : uint32_t { GK_INTERIOR = 0, GK_END_DOWN = 1,      // first k-mer of an ed
 
 template <int K>
 __global__ void __launch_bounds__(256)
-k_graph_classify(PartTable pt_arg, uint64_t n, const uint32_t* __restrict__ index, uint64_t mask, unsigned long long* __restrict__ n_ends)
+k_graph_classify(PartTable pt_arg, uint64_t n, const uint32_t* __restrict__ index, uint64_t n_slots, unsigned long long* __restrict__ n_ends)
 {
     __shared__ PartLds pt;
     part_lds_init(pt_arg, pt);
@@ -169,13 +173,13 @@ k_graph_classify(PartTable pt_arg, uint64_t n, const uint32_t* __restrict__ inde
             uint32_t c2;
             if (n_pred(ctx) == 1) {
                 const u128 p = kmer_pred<K>(F, one_pred(ctx));
-                const uint32_t g2 = graph_lookup<K>(pt, index, mask, p, &c2, &pal, &rev);
+                const uint32_t g2 = graph_lookup<K>(pt, index, n_slots, p, &c2, &pal, &rev);
                 up = !pal && g2 != GRAPH_EMPTY && n_succ(c2) == 1;
                 if (g2 != GRAPH_EMPTY) { up_to = g2; links |= GL_UP | (rev ? GL_UP_REV : 0u); }
             }
             if (n_succ(ctx) == 1) {
                 const u128 s = kmer_succ<K>(F, one_succ(ctx));
-                const uint32_t g2 = graph_lookup<K>(pt, index, mask, s, &c2, &pal, &rev);
+                const uint32_t g2 = graph_lookup<K>(pt, index, n_slots, s, &c2, &pal, &rev);
                 down = !pal && g2 != GRAPH_EMPTY && n_pred(c2) == 1;
                 if (g2 != GRAPH_EMPTY) { down_to = g2; links |= GL_DOWN | (rev ? GL_DOWN_REV : 0u); }
             }
@@ -475,7 +479,7 @@ k_graph_bases(PartTable pt_arg, uint64_t n_entries, const EdgeRec* __restrict__ 
 // (canonicalizeCircle, :367-392).
 template <int K>
 __global__ void __launch_bounds__(256)
-k_graph_cycles(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t mask, const uint32_t* __restrict__ members, uint64_t n_members,
+k_graph_cycles(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t n_slots, const uint32_t* __restrict__ members, uint64_t n_members,
                EdgeRec* __restrict__ recs, uint64_t rec_cap, unsigned long long* __restrict__ ctr, uint32_t max_steps,
                unsigned int* __restrict__ bad)
 {
@@ -497,7 +501,7 @@ k_graph_cycles(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t ma
                 if (n_succ(ctx) != 1) { atomicOr(bad, 1u); owner = false; break; }       // (a member of a branch-free cycle has one successor)
                 const u128 nxt = kmer_succ<K>(cur, one_succ(ctx));
                 uint32_t c2; bool pal;
-                const uint32_t g2 = graph_lookup<K>(pt, index, mask, nxt, &c2, &pal);
+                const uint32_t g2 = graph_lookup<K>(pt, index, n_slots, nxt, &c2, &pal);
                 if (g2 == GRAPH_EMPTY) { owner = false; break; }
                 if (g2 == g) break;                                          // back at the start: the whole cycle seen
                 if (lt128(kmer_of_entry<K>(entry_ptr(pt, g2)[0]), F)) { owner = false; break; }

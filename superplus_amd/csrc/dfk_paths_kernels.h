@@ -80,17 +80,17 @@ __device__ __forceinline__ int32_t part_hbv_edge(const PathGraph& G, const PartD
 // KmerDict::findEntry (kmers/ReadPather.h:222-225) through the edge builder's index: entry index or GRAPH_EMPTY, and the
 // entry's second half ((edge, offset) since the graph was built) read beside its key rather than after it.
 struct DictKey { uint64_t w0, w1, slot; };
-template <int K> __device__ __forceinline__ DictKey dict_key(uint64_t mask, u128 v)
+template <int K> __device__ __forceinline__ DictKey dict_key(uint64_t n_slots, u128 v)
 {
     const u128 R = kmer_rc<K>(v);
     const u128 c = lt128(R, v) ? R : v;
     const u128 kw = shl128(c, 128 - KTraits<K>::BITS);
-    return DictKey{kw.hi, kw.lo, set_hash(kw.hi, kw.lo) & mask};
+    return DictKey{kw.hi, kw.lo, index_home(set_hash(kw.hi, kw.lo), n_slots)};
 }
 __device__ __forceinline__ bool key_is(const uint4 a, const DictKey& k)
 { return ((uint64_t)a.x | ((uint64_t)a.y << 32)) == k.w0 && ((uint64_t)a.z | ((uint64_t)a.w << 32)) == k.w1; }
 // the probe sequence from slot s on
-__device__ __forceinline__ uint32_t dict_probe(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, const DictKey& k, uint64_t s, uint4* second)
+__device__ __forceinline__ uint32_t dict_probe(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t n_slots, const DictKey& k, uint64_t s, uint4* second)
 {
     for (uint32_t guard = 0; guard < 1u << 20; ++guard) {
         const uint32_t g = index[s];
@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t dict_probe(const PartLds& pt, const uint32_t
         const uint4* e = entry_ptr(pt, g);
         const uint4 a = e[0], b = e[1];
         if (key_is(a, k)) { *second = b; return g; }
-        s = (s + 1) & mask;
+        s = index_next(s, n_slots);
     }
     return GRAPH_EMPTY;
 }
@@ -130,22 +130,24 @@ k_filter_build(PartTable pt_arg, uint64_t n, uint32_t* __restrict__ words, uint6
     }
 }
 template <int K>
-__device__ __forceinline__ uint32_t dict_find(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, const KmerFilter& F, u128 v, uint4* second)
+__device__ __forceinline__ uint32_t dict_find(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t n_slots, const KmerFilter& F, u128 v, uint4* second)
 {
-    const DictKey k = dict_key<K>(mask, v);
+    const DictKey k = dict_key<K>(n_slots, v);
     if (F.words) {
         uint64_t w; uint32_t bits;
         filter_place(k, F.n_words, &w, &bits);
         if ((F.words[w] & bits) != bits) return GRAPH_EMPTY;
     }
-    return dict_probe(pt, index, mask, k, k.slot, second);
+    return dict_probe(pt, index, n_slots, k, k.slot, second);
 }
 
+constexpr uint32_t PARTS_OVERFLOW = 0xFFFFFFFFu;
 template <int K>
-__device__ uint32_t path_parts(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t mask, const KmerFilter& F, const PathGraph& G,
+__device__ uint32_t path_parts(const PartLds& pt, const uint32_t* __restrict__ index, uint64_t n_slots, const KmerFilter& F, const PathGraph& G,
                                const uint32_t* __restrict__ rwords, uint64_t r_nwords, uint64_t r_byte0,
-                               const uint8_t* __restrict__ read, uint32_t n, PartD* __restrict__ parts, unsigned int* __restrict__ bad)
+                               const uint8_t* __restrict__ read, uint32_t n, PartD* __restrict__ parts, uint32_t room, unsigned int* __restrict__ bad)
 {
+    // (`room` parts fit; PARTS_OVERFLOW if the read wants more -- with room for one part per k-mer position it cannot)
     if (n < (uint32_t)K) { parts[0] = part_gap_of(n); return 1; }
     const uint32_t* ewords = reinterpret_cast<const uint32_t*>(G.store);
     uint32_t np = 0, at = 0;
@@ -163,18 +165,20 @@ __device__ uint32_t path_parts(const PartLds& pt, const uint32_t* __restrict__ i
         u128 km = shr128(u128{rev2_64(ks.hi), rev2_64(ks.lo)}, 128 - KTraits<K>::BITS);
         uint4 b;
         // (a read's first k-mer is in the dictionary more often than not: no filter in front of that look-up)
-        uint32_t hit = dict_find<K>(pt, index, mask, np ? F : KmerFilter{nullptr, 0}, km, &b);
+        uint32_t hit = dict_find<K>(pt, index, n_slots, np ? F : KmerFilter{nullptr, 0}, km, &b);
         if (hit == GRAPH_EMPTY) {
             uint32_t missed = 1, nxt = at + K;
             ++at;
             while (nxt != n) {
                 km = kmer_succ<K>(km, seq_base(read, nxt)); ++nxt;
-                if ((hit = dict_find<K>(pt, index, mask, F, km, &b)) != GRAPH_EMPTY) break;
+                if ((hit = dict_find<K>(pt, index, n_slots, F, km, &b)) != GRAPH_EMPTY) break;
                 ++missed; ++at;
             }
+            if (np == room) return PARTS_OVERFLOW;
             parts[np++] = part_gap_of(missed);
         }
         if (hit != GRAPH_EMPTY) {
+            if (np == room) return PARTS_OVERFLOW;
             const uint32_t c = b.x;
             if (c >= G.n_ce) { atomicOr(bad, 4u); parts[np++] = part_gap_of(stop - at); break; }   // (an entry without an edge: the graph is not the dictionary's)
             int32_t off = (int32_t)(b.y & 0xFFFFFFu);
@@ -400,17 +404,20 @@ __device__ bool extend_path(const PathGraph& G, int32_t* __restrict__ path, int3
 // parts starts in the middle, leftward extensions grow down, rightward ones up; a path never holds more than s edges) and
 // its decoded qualities (s+K >= L bytes) live in per-batch scratch arrays addressed by the exclusive scan of the slots.
 __global__ void __launch_bounds__(256)
-k_path_slots(const uint32_t* __restrict__ read_len, uint64_t r0, uint64_t nb, uint32_t K, uint64_t* __restrict__ slots)
+k_path_slots(const uint32_t* __restrict__ read_len, uint64_t r0, uint64_t nb, uint32_t K, uint32_t cap, uint64_t* __restrict__ slots)
 {
+    // low half: the parts (and path edges) a read gets room for -- one per k-mer position covers every case, `cap` nearly every
+    // read at a fraction of the room; high half: its bases (the decoded qualities).  One scan gives both offsets: a batch holds
+    // at most 2^24 reads of at most 255 bases.
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
-        const uint32_t L = read_len[r0 + i];
-        slots[i] = L >= K ? L - K + 1 : 1;
+        const uint32_t L = read_len[r0 + i], s = L >= K ? L - K + 1 : 1;
+        slots[i] = (uint64_t)(s < cap ? s : cap) | ((uint64_t)((L + 3u) & ~3u) << 32);
     }
 }
 
 template <int K>
 __global__ void __launch_bounds__(256)
-k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t mask, KmerFilter F, PathGraph G,
+k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t n_slots, KmerFilter F, PathGraph G,
              const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off, const uint32_t* __restrict__ read_len,
              const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, uint64_t r0, uint64_t nb,
              const uint64_t* __restrict__ slot_off, PartD* __restrict__ parts_all, int32_t* __restrict__ path_all, uint8_t* __restrict__ qual_all,
@@ -421,14 +428,17 @@ k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t mask
     part_lds_init(pt_arg, pt);
     unsigned long long placed = 0, n_edges = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
-        const uint64_t r = r0 + i, so = slot_off[i];
-        const uint32_t n = read_len[r], s = (uint32_t)(slot_off[i + 1] - so);
+        const uint64_t r = r0 + i, so2 = slot_off[i];
+        const uint32_t so = (uint32_t)so2, n = read_len[r], s = (uint32_t)slot_off[i + 1] - so, s_full = n >= (uint32_t)K ? n - K + 1 : 1;
         const uint8_t* read = packed + base_off[r];
         PartD* parts = parts_all + so;
-        int32_t* path = path_all + 2 * so + 2 * i;
-        uint8_t* q = qual_all + so + i * K;
-        uint32_t np = path_parts<K>(pt, index, mask, F, G, reinterpret_cast<const uint32_t*>(packed), (packed_bytes + 3) >> 2, base_off[r], read, n, parts, bad);
-        if (np > s) atomicOr(bad, 8u);                                            // (cannot happen: every part covers a k-mer position of its own)
+        int32_t* path = path_all + 2 * (uint64_t)so + 2 * i;
+        uint8_t* q = qual_all + (so2 >> 32);
+        // out of room: with one slot per k-mer position that cannot happen (every part covers a position of its own); with
+        // fewer, the host does the batch again with all of them
+        const unsigned int no_room = s < s_full ? 32u : 8u;
+        uint32_t np = path_parts<K>(pt, index, n_slots, F, G, reinterpret_cast<const uint32_t*>(packed), (packed_bytes + 3) >> 2, base_off[r], read, n, parts, s, bad);
+        if (np == PARTS_OVERFLOW) { atomicOr(bad, no_room); out_offset[i] = 0; out_len[i] = 0; out_first[i] = 0; continue; }
         np = edit_parts<K>(G, parts, np);
         // pathPartsToReadPath
         int32_t first = (int32_t)s + 1, count = 0, offset = 0;
@@ -456,7 +466,7 @@ k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t mask
                     if (h < 10) break;
                     // (a path never holds more edges than the read has k-mers: every edge of it covers a k-mer position of
                     // its own.  That bounds the scratch; an overhang of ten k-mers beside a full path would disprove it.)
-                    if (count >= (int32_t)s) { atomicOr(bad, 8u); break; }
+                    if (count >= (int32_t)s) { atomicOr(bad, no_room); break; }
                     if (!have_q) {
                         have_q = true;
                         if (!decode_quals(pq, pq_off[r], pq_off[r + 1], q, n)) { atomicOr(bad, 16u); side = 2; break; }
@@ -491,7 +501,7 @@ k_path_emit(const uint64_t* __restrict__ size_off, const uint64_t* __restrict__ 
         elem_off[i] = (uint32_t)at;
         uint32_t* o = var + (at >> 2);
         o[0] = (uint32_t)out_offset[i]; o[1] = 0u;                               // mLastSkip: never set (ReadPath.h:27-29)
-        const int32_t* p = path_all + 2 * slot_off[i] + 2 * i + out_first[i];
+        const int32_t* p = path_all + 2 * (uint64_t)(uint32_t)slot_off[i] + 2 * i + out_first[i];
         for (uint32_t j = 0; j < out_len[i]; ++j) o[2 + j] = (uint32_t)p[j];
     }
 }

@@ -23,16 +23,21 @@ def explain(got, exp):
 
 
 @pytest.mark.parametrize("case,K,npz,which", CASES)
-def test_paths_file_matches_reference_fixture(golden_dir, tmp_path, case, K, npz, which):
+def test_paths_file_matches_reference_fixture(golden_dir, tmp_path, monkeypatch, case, K, npz, which):
     from superplus_amd.dfk import Dfk
     rs = load_reads(golden_dir, which)
     kw = dict(KW[case]); nobc = kw.pop("nobc", False)
     exp = open(os.path.join(golden_dir, case, "a.paths"), "rb").read()
-    for extra in (dict(), dict(passes=3, inst_per_item=1500, keep_inputs=True)):      # one part / several parts; reads re-uploaded / kept
+    # one part / several parts; reads re-uploaded / kept; room for two parts a read (batches done again with all of it) and no
+    # filter in front of the index
+    for extra in (dict(), dict(passes=3, inst_per_item=1500, keep_inputs=True), dict(slots=2)):
+        extra = dict(extra)
+        if extra.pop("slots", None):
+            monkeypatch.setenv("DFK_PATH_SLOTS", "2"); monkeypatch.setenv("DFK_NO_FILTER", "1")
         d = Dfk(K=K, **kw, **extra)
         d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], None if nobc else rs["bc"])
         d.graph_build()
-        st = d.paths_build() if extra else d.paths_build(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"])
+        st = d.paths_build() if extra.get("keep_inputs") else d.paths_build(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"])
         out = os.path.join(tmp_path, "a.paths")
         d.paths_write(out)
         got = open(out, "rb").read()
