@@ -98,6 +98,16 @@ void        dfk_destroy(dfk_ctx* ctx);
 const char* dfk_last_error(void);
 int         dfk_abi_version(void);
 
+/* A hint for the host-buffer calls (dfk_count, dfk_shard_begin_host, dfk_paths_build): the host range
+ * [base, base + bytes) is a mapping of file `fd` from `file_off` on, and the library may READ THE FILE instead of the
+ * memory.  It then does, for every byte of an input array that lies inside a hinted range: the caller may unmap the range
+ * while the call runs (the descriptor must stay open), and pages the library would have been the first to touch are never
+ * mapped -- unmapping a 90-GB input every page of which was touched is three seconds of page-table work, at exit if not
+ * before.  A failing read is DFK_E_INPUT, never a quiet fall back to the memory.  base = NULL forgets all hints; at most
+ * 8 are kept; dfk_destroy forgets them.  Replaces nothing in the reference (LoadData reads its files through read(2)
+ * into vectors, feudal/FeudalFileReader.cc). */
+int dfk_hint_file_range(dfk_ctx* ctx, const void* base, uint64_t bytes, int fd, uint64_t file_off);
+
 /* createDict(...) on host buffers laid out exactly as the .fastb/.qualp var data and DF's
  * expanded barcode vector (DF.cc:447-452):
  *   packed_bases + base_off[n+1]  BaseVec bytes, 2-bit LSB-first (feudal/FieldVec.h:766-770)

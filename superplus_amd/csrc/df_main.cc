@@ -129,12 +129,20 @@ struct Mapped {
             (void)madvise(m, n, MADV_WILLNEED);
         }
     }
-    ~Mapped()
+    ~Mapped() { unmap(); if (fd >= 0) close(fd); }
+    void unmap()                                                        // the descriptor stays open
     {
+        if (!p) return;
         const auto t0 = std::chrono::steady_clock::now();
-        if (p) munmap((void*)p, n);
-        if (fd >= 0) close(fd);
-        if (p && getenv("DFK_TRACE")) fprintf(stderr, "[DF] unmapped %.2f GB in %.3f s\n", n / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        // from the end, a piece at a time: an unmap of tens of GB holds the address-space lock for seconds, and other threads
+        // (the GPU runtime pinning a buffer for a copy, say) wait for it that long; a piece is some tens of milliseconds
+        if (p) {
+            const size_t piece = (size_t)256 << 20, page = 4096;
+            size_t end = (n + page - 1) / page * page;
+            while (end > 0) { const size_t lo = end > piece ? (end - piece) / page * page : 0; munmap((void*)(p + lo), end - lo); end = lo; }
+        }
+        if (getenv("DFK_TRACE")) fprintf(stderr, "[DF] unmapped %.2f GB in %.3f s\n", n / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        p = nullptr;
     }
 };
 
@@ -638,6 +646,46 @@ int main(int argc, char** argv)
         printf("%s: loaded %llu reads\n", date().c_str(), (unsigned long long)n_reads);
         for (const DataSet& d : datasets) printf("\t%s starts at %ld\n", d.dt == 2 ? "UNBAR_10X" : "BAR_10X", (long)d.start);
 
+        // ---- barcode expansion (DF.cc:447-452) and createDict on the GPU.  With the inputs mapped in place (fast path) the upload
+        //      and the count start NOW, in a thread of their own, while this one computes the side files below; otherwise
+        //      they run where the reference has them.
+        std::vector<int32_t> bc;
+        dfk_config cfg{};
+        cfg.abi_version = DFK_ABI_VERSION; cfg.K = K; cfg.min_qual = (uint32_t)atoi(a["MIN_QUAL"].c_str());
+        cfg.min_freq = (uint32_t)atoi(a["MIN_FREQ"].c_str()); cfg.min_bc = (uint32_t)atoi(a["MIN_BC"].c_str());
+        cfg.device = atoi(a["DEVICE"].c_str()); cfg.ign_bc_below = 0;           // bc_start = 0 for LR-only input (DF.cc:344-349)
+        cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
+        cfg.hbm_budget_bytes = (uint64_t)(atof(a["HBM_GB"].c_str()) * 1073741824.0);   // 0 = 90 % of the free HBM; MAX_MEM_GB is host memory
+        const bool want_paths = truthy(a["GRAPH"]) && truthy(a["PATHS"]);
+        // kmers.kvec is a transient file of the reference (written at BuildReadQGraph48.cc:287, read back at :294-301, removed
+        // at :303): with the graph built here nothing downstream reads it, so it is written only on request -- or when
+        // GRAPH=False, where it is the one way the dictionary leaves this process
+        const bool want_kvec = a["KVEC"] == "Auto" ? (!truthy(a["GRAPH"]) || truthy(a["KVEC_SORTED"])) : truthy(a["KVEC"]);
+        if (want_paths) cfg.flags |= DFK_F_KEEP_INPUTS;                          // the reads stay on the device for pathReads
+        dfk_ctx* ctx = nullptr;
+        int count_rc = 0; bool create_failed = false; std::string count_err; double t_count = 0;
+        std::atomic<bool> hinted{false};                                        // the library knows the files behind the maps (or never will)
+        auto count_job = [&] {
+            struct SetAtExit { std::atomic<bool>& f; ~SetAtExit() { f = true; } } hinted_whatever_happens{hinted};
+            bc.assign(n_reads, 0);
+            parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t lo, uint64_t hi) {
+                for (uint64_t b = lo; b < hi; ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
+            }, 1024);
+            if (dfk_create(&cfg, &ctx)) { create_failed = true; count_err = dfk_last_error(); return; }
+            if (fast)                                                           // the arrays are maps of these files: read the files (see below)
+                for (const Mapped* m : {&ins[0].fb.m, &ins[0].qp.m})
+                    if (m->p && dfk_hint_file_range(ctx, m->p, m->n, m->fd, 0)) { create_failed = true; count_err = dfk_last_error(); return; }
+            hinted = true;
+            printf("%s: building dictionary on the GPU\n", date().c_str());
+            const double tc = now_s();
+            count_rc = dfk_count(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bc.data(), n_reads);
+            if (count_rc) count_err = dfk_last_error();
+            t_count = now_s() - tc;
+        };
+        std::thread count_thread;
+        struct JoinAtExit { std::thread& t; ~JoinAtExit() { if (t.joinable()) t.join(); } } count_joiner{count_thread};   // (an exception below must not leave it running)
+        if (fast && !sharded && !truthy(a["EXIT_LOAD"])) count_thread = std::thread(count_job);
+
         // ---- lens, quality histogram, datasets (DF.cc:50-68, DfTools.cc:172-238)
         std::vector<int16_t> lens(n_reads);
         std::vector<int> tmax(g_threads + 1, 0);
@@ -676,6 +724,20 @@ int main(int argc, char** argv)
             background.clear();
             if (bg_failed) std::rethrow_exception(bg_err);
         };
+        if (count_thread.joinable()) {
+            // This process is done with the mapped inputs, and the library reads them through their descriptors (the hint above):
+            // the maps go now, behind the tasks that still read them and beside the upload.  Unmapping 45 GB every page of which
+            // was touched (the qualities, the tables; the bases never were) is a second and a half of page-table work -- at exit,
+            // if not here, where nothing waits for the address-space lock it holds.
+            auto earlier = std::make_shared<std::vector<std::thread>>(std::move(background));
+            background.clear();
+            background.emplace_back([&ins, &hinted, &create_failed, earlier] {
+                for (auto& x : *earlier) x.join();
+                while (!hinted.load()) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                if (create_failed) return;                                      // (no count will run; the maps go with the process)
+                for (In& x : ins) { x.fb.m.unmap(); x.qp.m.unmap(); }
+            });
+        }
         if (truthy(a["EXIT_LOAD"])) { join_background(); return 0; }             // DF.cc:483
         if (sharded) {
             // the ranks are counting (or, loopback, start now); this process has done the ingest
@@ -695,33 +757,16 @@ int main(int argc, char** argv)
             return rc;
         }
 
-        // ---- barcode expansion (DF.cc:447-452) and createDict on the GPU
-        std::vector<int32_t> bc(n_reads, 0);
-        parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t lo, uint64_t hi) {
-            for (uint64_t b = lo; b < hi; ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
-        }, 1024);
-        dfk_config cfg{};
-        cfg.abi_version = DFK_ABI_VERSION; cfg.K = K; cfg.min_qual = (uint32_t)atoi(a["MIN_QUAL"].c_str());
-        cfg.min_freq = (uint32_t)atoi(a["MIN_FREQ"].c_str()); cfg.min_bc = (uint32_t)atoi(a["MIN_BC"].c_str());
-        cfg.device = atoi(a["DEVICE"].c_str()); cfg.ign_bc_below = 0;           // bc_start = 0 for LR-only input (DF.cc:344-349)
-        cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
-        cfg.hbm_budget_bytes = (uint64_t)(atof(a["HBM_GB"].c_str()) * 1073741824.0);   // 0 = 90 % of the free HBM; MAX_MEM_GB is host memory
-        const bool want_paths = truthy(a["GRAPH"]) && truthy(a["PATHS"]);
-        // kmers.kvec is a transient file of the reference (written at BuildReadQGraph48.cc:287, read back at :294-301, removed
-        // at :303): with the graph built here nothing downstream reads it, so it is written only on request -- or when
-        // GRAPH=False, where it is the one way the dictionary leaves this process
-        const bool want_kvec = a["KVEC"] == "Auto" ? (!truthy(a["GRAPH"]) || truthy(a["KVEC_SORTED"])) : truthy(a["KVEC"]);
-        if (want_paths) cfg.flags |= DFK_F_KEEP_INPUTS;                          // the reads stay on the device for pathReads
-        dfk_ctx* ctx = nullptr;
-        if (dfk_create(&cfg, &ctx)) { fprintf(stderr, "DF: %s\n", dfk_last_error()); join_background(); return 1; }
-        printf("%s: building dictionary on the GPU\n", date().c_str());
-        t0 = now_s();
-        int rc = dfk_count(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bc.data(), n_reads);
-        const double t_count = now_s() - t0;
+        // ---- createDict on the GPU: started above (fast path) or here
+        if (!count_thread.joinable()) count_job();
+        else count_thread.join();
+        if (create_failed) { fprintf(stderr, "DF: %s\n", count_err.c_str()); join_background(); return 1; }
+        const int rc = count_rc;
         if (rc == DFK_E_NOGOOD) { printf("\nLooks like your input data have almost no good bases.\nGiving up.\n\n"); join_background(); return 1; }   // :227-230
-        if (rc) { fprintf(stderr, "DF: %s\n", dfk_last_error()); join_background(); return rc == DFK_E_NOMEM ? 185 : 1; }        // Martian::exit code
+        if (rc) { fprintf(stderr, "DF: %s\n", count_err.c_str()); join_background(); return rc == DFK_E_NOMEM ? 185 : 1; }        // Martian::exit code
         dfk_stats st{}; dfk_get_stats(ctx, &st);
         T.upload = 1e-3 * st.ms_upload; T.count = t_count - T.upload;
+        { std::vector<int32_t>().swap(bc); }
         t0 = now_s();
         uint64_t need = 0; dfk_spectrum_json(ctx, nullptr, 0, &need);
         std::string js(need, '\0'); dfk_spectrum_json(ctx, &js[0], need, &need);
@@ -758,11 +803,9 @@ int main(int argc, char** argv)
                 printf("%s: pathing reads\n", date().c_str());
                 if (dfk_paths_build(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) throw std::runtime_error(dfk_last_error());
                 { dfk_stats ps{}; dfk_get_stats(ctx, &ps); t_p_dev = 1e-6 * (double)ps.reserved[3]; }
-                graph_writer.join();
-                if (!bg_fail.empty()) throw std::runtime_error(bg_fail);
-                t_graph += std::max(0.0, tw_graph - (now_s() - t0));          // (what of the graph's files was not hidden under the pathing)
                 printf("%s: writing paths\n", date().c_str());
-                std::thread paths_writer([&] { const double t1 = now_s(); if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) bg_fail = dfk_last_error(); tw_paths = now_s() - t1; });
+                std::string bg_fail2;
+                std::thread paths_writer([&] { const double t1 = now_s(); if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) bg_fail2 = dfk_last_error(); tw_paths = now_s() - t1; });
                 Join join_paths{paths_writer};
                 dfk_paths_stats(ctx, nullptr, &p_placed, &p_edges);
                 // writePathsIndex and MarkDups, the two steps DF takes right after StageBuildGraph (10X/DF.cc:550,560)
@@ -774,7 +817,9 @@ int main(int argc, char** argv)
                 if (dfk_dups_write(ctx, (dir + "/a.dup").c_str(), &n_dup)) throw std::runtime_error(dfk_last_error());
                 t_dups = now_s() - td;
                 paths_writer.join();
+                graph_writer.join();
                 if (!bg_fail.empty()) throw std::runtime_error(bg_fail);
+                if (!bg_fail2.empty()) throw std::runtime_error(bg_fail2);
                 t_p_write = tw_paths;
                 t_paths = now_s() - t0;
                 printf("%.2f%% of pairs appear to be duplicates\n", n_reads ? 100.0 * (double)n_dup / (double)(n_reads / 2) : 0.0);

@@ -88,6 +88,8 @@ struct dfk_ctx {
     // results of the last run
     bool have = false;
     uint64_t n_reads = 0;
+    struct FileRange { const char* base; uint64_t bytes; int fd; uint64_t off; };
+    std::vector<FileRange> file_ranges;       // dfk_hint_file_range
     DevBuf good_len;                          // u32[n_reads]
     // dfk_entry32[n], one part per pass.  blist != 0: behind the entries, in the same buffer, 16 bytes of counters
     // and the indices of the n_blist entries that still have unresolved context bits (k_boundary_list)
@@ -1736,16 +1738,38 @@ int xfer_run(dfk_ctx* c, uint64_t n_chunks, const XferBody& body, const XferFin&
     return rc;
 }
 
+// `bytes` of the caller's host memory at h, or -- inside a range it has hinted (dfk_hint_file_range) -- of the file behind it
+int host_read(dfk_ctx* c, void* dst, const void* h, uint64_t bytes)
+{
+    for (const dfk_ctx::FileRange& r : c->file_ranges)
+        if ((const char*)h >= r.base && (const char*)h + bytes <= r.base + r.bytes) {
+            uint64_t at = r.off + (uint64_t)((const char*)h - r.base);
+            for (uint64_t done = 0; done < bytes;) {
+                const ssize_t got = pread(r.fd, (char*)dst + done, bytes - done, (off_t)(at + done));
+                if (got <= 0) return fail(DFK_E_INPUT, "cannot read %llu bytes at %llu of the file behind a hinted input range", (unsigned long long)(bytes - done), (unsigned long long)(at + done));
+                done += (uint64_t)got;
+            }
+            return 0;
+        }
+    memcpy(dst, h, bytes);
+    return 0;
+}
+
 // host -> device, `bytes` from pageable (or mapped-file) memory
 int upload(dfk_ctx* c, void* d, const void* h, uint64_t bytes)
 {
     if (!bytes) return 0;
-    if (bytes < 4 * XFER_CHUNK) { HIP_TRY(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return 0; }
+    if (bytes < 4 * XFER_CHUNK) {
+        std::vector<char> tmp(bytes);
+        int rc = host_read(c, tmp.data(), h, bytes); if (rc) return rc;
+        HIP_TRY(hipMemcpy(d, tmp.data(), bytes, hipMemcpyHostToDevice));
+        return 0;
+    }
     return xfer_run(c, (bytes + XFER_CHUNK - 1) / XFER_CHUNK, [&](unsigned, XferLane& l, uint64_t i) -> int {
         const int k = l.turn++ & 1;                                  // the lane's two buffers alternate; the one about to be
         HIP_TRY(hipEventSynchronize(l.ev[k]));                       // overwritten must have left the host
         const uint64_t off = i * XFER_CHUNK, n = std::min<uint64_t>(XFER_CHUNK, bytes - off);
-        memcpy(l.pin[k], (const char*)h + off, n);
+        { const int rr = host_read(c, l.pin[k], (const char*)h + off, n); if (rr) return rr; }
         HIP_TRY(hipMemcpyAsync((char*)d + off, l.pin[k], n, hipMemcpyHostToDevice, l.st));
         HIP_TRY(hipEventRecord(l.ev[k], l.st));
         return 0;
@@ -1913,6 +1937,16 @@ int dfk_count_device(dfk_ctx* c, const void* d_packed, uint64_t packed_bytes, co
     });
 }
 
+int dfk_hint_file_range(dfk_ctx* c, const void* base, uint64_t bytes, int fd, uint64_t file_off)
+{
+    if (!c) return fail(DFK_E_ARG, "null context");
+    if (!base) { c->file_ranges.clear(); return 0; }
+    if (fd < 0 || !bytes) return fail(DFK_E_ARG, "a hinted range needs an open descriptor and a length");
+    if (c->file_ranges.size() >= 8) return fail(DFK_E_ARG, "8 hinted ranges are kept at most");
+    c->file_ranges.push_back(dfk_ctx::FileRange{(const char*)base, bytes, fd, file_off});
+    return 0;
+}
+
 int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const uint32_t* read_len,
               const uint8_t* pq, const uint64_t* pq_off, const int32_t* bc, uint64_t n_reads)
 {
@@ -1924,7 +1958,7 @@ int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const
     c->drop_kept();
     // (the host tables may sit at any address -- e.g. inside a mapped feudal file -- so they are not dereferenced as u64)
     uint64_t pb = 0, qb = 0;
-    if (n_reads) { memcpy(&pb, (const char*)base_off + 8 * n_reads, 8); memcpy(&qb, (const char*)pq_off + 8 * n_reads, 8); }
+    if (n_reads) { int r1 = host_read(c, &pb, (const char*)base_off + 8 * n_reads, 8); if (!r1) r1 = host_read(c, &qb, (const char*)pq_off + 8 * n_reads, 8); if (r1) return r1; }
     // staging copies live outside the context's run allocations (release_all() at the start of a run)
     void *d_packed = nullptr, *d_boff = nullptr, *d_len = nullptr, *d_pq = nullptr, *d_poff = nullptr, *d_bc = nullptr;
     Timer t(c->stream);

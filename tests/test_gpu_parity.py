@@ -1,4 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the oracle.  Bit-exact: integer work."""
+import os
+
 import numpy as np
 import pytest
 
@@ -447,3 +449,31 @@ def test_counts_beyond_2_pow_24_in_an_hbm_table(oracle):
     assert np.array_equal(rest["w0"], ref["solid"]["w0"]) and np.array_equal(rest["w1"], ref["solid"]["w1"])
     assert np.array_equal(rest["count_ctx"] & 0xFFFFFF, ref["solid"]["count_ctx"] & 0xFFFFFF)
     d.close()
+
+
+def test_hinted_file_ranges_are_read_from_the_file(oracle, tmp_path):
+    """dfk_hint_file_range: the arrays are maps of a file whose CONTENT is right while the mapped bytes the library is handed
+    are not (a private, scribbled-over mapping) -- the count must come out of the file."""
+    import mmap
+    from superplus_amd.dfk import Dfk
+    rs = util.make_set(77, 30000, 1500)
+    ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
+    names = ("packed", "base_off", "read_len", "pq_bytes", "pq_off")
+    path = os.path.join(tmp_path, "arrays.bin")
+    at, where = 0, {}
+    with open(path, "wb") as f:
+        for k in names:
+            b = np.ascontiguousarray(rs[k]).tobytes()
+            f.write(b); where[k] = (at, len(b)); at += len(b)
+            pad = -at % 4096; f.write(b"\0" * pad); at += pad
+    fd = os.open(path, os.O_RDONLY)
+    m = mmap.mmap(fd, at, flags=mmap.MAP_PRIVATE, prot=mmap.PROT_READ | mmap.PROT_WRITE)
+    whole = np.frombuffer(m, np.uint8)
+    arr = {k: whole[o:o + n].view(np.asarray(rs[k]).dtype) for k, (o, n) in where.items()}
+    d = Dfk(K=48)
+    d.hint_file_range(whole, fd)
+    whole[:] = 0xA5                                                       # (private: the file keeps the truth)
+    d.count(arr["packed"], arr["base_off"], arr["read_len"], arr["pq_bytes"], arr["pq_off"], rs["bc"])
+    assert d.stats()["n_solid"] == len(ref["solid"]) and np.array_equal(d.good_lens(), ref["good_len"])
+    d.hint_file_range(None, -1)
+    d.close(); del arr, whole; m.close(); os.close(fd)
