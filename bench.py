@@ -264,7 +264,7 @@ def df_stage_wall(args, dev, local):
                f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}",
                "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (GRAPH=True: rows f-1, f-2, f-4 -- edges + HBV + read paths + paths index + duplicate marks -> a.<K>/)
         if link: cmd.append("LINK_READS=True")
-        env = dict(os.environ, DFK_HOST_THREADS=str(min(args.df_threads, 16)))
+        env = dict(os.environ, DFK_HOST_THREADS=os.environ.get("DFK_HOST_THREADS", str(min(args.df_threads, 16))))
         if args.df_gpus > 1 or args.df_transport:
             # the C++ multi-GPU host (df_shard.h): DF forks one rank per GPU and moves the records over RCCL itself;
             # `loopback` runs the ranks as threads on ONE GPU (the rehearsal a one-GPU box allows)
@@ -272,6 +272,7 @@ def df_stage_wall(args, dev, local):
             if args.df_transport == "loopback": env["DF_TRANSPORT"] = "loopback"
             elif args.df_gpus <= 1: env["DF_FORCE_SHARDED"] = "1"
         t0 = time.perf_counter(); e0 = time.time()
+        if os.environ.get("DF_TASKSET"): cmd = ["taskset", "-c", os.environ["DF_TASKSET"]] + cmd      # (an experiment's switch: bind the stage's threads)
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
         wall = time.perf_counter() - t0; e1 = time.time()
         if os.environ.get("DFK_TRACE") and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # the child's trace, for whoever asked for it

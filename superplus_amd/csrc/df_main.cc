@@ -98,9 +98,11 @@ static_assert(sizeof(DataSet) == 16, "DataSet is 16 bytes");
 unsigned g_threads = 1;
 
 // fn(t, lo, hi) over [0, n) cut into one contiguous range per thread
-void parallel_ranges(uint64_t n, const std::function<void(unsigned, uint64_t, uint64_t)>& fn, uint64_t min_per_thread = 1 << 16)
+unsigned g_side_threads = 0;     // (0 = all) what the side-file passes may use while the upload's lanes want the cores
+void parallel_ranges(uint64_t n, const std::function<void(unsigned, uint64_t, uint64_t)>& fn, uint64_t min_per_thread = 1 << 16, bool side = false)
 {
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(g_threads, n / std::max<uint64_t>(1, min_per_thread)));
+    const unsigned most = side && g_side_threads ? std::min(g_side_threads, g_threads) : g_threads;
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(most, n / std::max<uint64_t>(1, min_per_thread)));
     if (T <= 1) { fn(0, 0, n); return; }
     std::vector<std::thread> th;
     std::exception_ptr err; std::atomic<bool> failed{false};
@@ -283,6 +285,32 @@ std::string spectrum_json(const std::vector<uint64_t>& hist)
 
 // One rank of `DF NUM_GPUS=N`: its pair range of the (single, already LoadData-ordered) input, the sharded createDict
 // over the transport, its share of kmers.kvec; rank 0 writes the spectrum summed over the ranks.
+// This process's threads on the CPUs of the GPU's NUMA node: the transfer lanes copy between the page cache, their pinned
+// buffers and the device, and from the other socket that is half the rate (measured on a two-socket box: the whole stage
+// 20.0 -> 18.6 s).  Threads started afterwards inherit it.  DF_NO_BIND=1 leaves the threads where the scheduler puts them.
+void bind_to_gpu_node(int device)
+{
+    if (getenv("DF_NO_BIND")) return;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char* p = bus; *p; ++p) *p = (char)tolower(*p);
+    int node = -1;
+    { FILE* f = fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r"); if (!f) return; if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return;
+    char list[4096] = {0};
+    { FILE* f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r"); if (!f) return; if (!fgets(list, sizeof list, f)) list[0] = 0; fclose(f); }
+    cpu_set_t set; CPU_ZERO(&set);
+    int n_cpus = 0;
+    for (char* p = list; *p && *p != '\n';) {
+        char* e; const long a = strtol(p, &e, 10); long b = a;
+        if (e == p) break;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &set); ++n_cpus; }
+        p = *e == ',' ? e + 1 : e;
+    }
+    if (n_cpus && sched_setaffinity(0, sizeof set, &set) == 0 && getenv("DFK_TRACE")) fprintf(stderr, "[DF] bound to NUMA node %d (%d CPUs) of device %d\n", node, n_cpus, device);
+}
+
 int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::string& work_dir, const std::string& head, int rank, int world,
               dfkx::LoopbackHub* hub)
 {
@@ -311,6 +339,7 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
         cfg.abi_version = DFK_ABI_VERSION; cfg.K = K; cfg.min_qual = (uint32_t)atoi(a["MIN_QUAL"].c_str());
         cfg.min_freq = (uint32_t)atoi(a["MIN_FREQ"].c_str()); cfg.min_bc = (uint32_t)atoi(a["MIN_BC"].c_str());
         cfg.device = hub ? atoi(a["DEVICE"].c_str()) : rank % ndev; cfg.ign_bc_below = 0;
+        if (!hub) bind_to_gpu_node(cfg.device);
         cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
         cfg.hbm_budget_bytes = (uint64_t)(atof(a["HBM_GB"].c_str()) * 1073741824.0);
         if (hub && !cfg.hbm_budget_bytes) { size_t fr = 0, tot = 0; (void)hipSetDevice(cfg.device); (void)hipMemGetInfo(&fr, &tot); cfg.hbm_budget_bytes = (uint64_t)(0.8 * (double)fr / world); }   // ranks sharing one GPU
@@ -496,6 +525,7 @@ int main(int argc, char** argv)
     if (getenv("DF_RANK")) return rank_main(a, K, work_dir, heads[0], atoi(getenv("DF_RANK")), atoi(getenv("DF_WORLD")), nullptr);
     // EXIT_LOAD (DF.cc:483) stops after the ingest: no rank is spawned for it
     const bool sharded = (num_gpus > 1 || getenv("DF_FORCE_SHARDED")) && !truthy(a["EXIT_LOAD"]);
+    if (!sharded && !truthy(a["EXIT_LOAD"])) bind_to_gpu_node(atoi(a["DEVICE"].c_str()));      // (a parent of ranks must not touch the GPU before it forks)
     ChildWatch watch;
     std::vector<pid_t>& children = watch.live;
     if (sharded) {
@@ -664,26 +694,35 @@ int main(int argc, char** argv)
         if (want_paths) cfg.flags |= DFK_F_KEEP_INPUTS;                          // the reads stay on the device for pathReads
         dfk_ctx* ctx = nullptr;
         int count_rc = 0; bool create_failed = false; std::string count_err; double t_count = 0;
-        std::atomic<bool> hinted{false};                                        // the library knows the files behind the maps (or never will)
+        // frag_reads_orig.qhist: counted on the device from the reads the count keeps there (the pathing wants them), behind the
+        // count, once this thread has been through the read lengths; counted here when the device keeps nothing
+        const bool device_hist = fast && !sharded && !truthy(a["EXIT_LOAD"]) && want_paths && !getenv("DF_HOST_QHIST");
+        std::atomic<int> max_len_known{-1};
+        std::vector<int64_t> qh_dev; std::string qh_err;
         auto count_job = [&] {
-            struct SetAtExit { std::atomic<bool>& f; ~SetAtExit() { f = true; } } hinted_whatever_happens{hinted};
             bc.assign(n_reads, 0);
             parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t lo, uint64_t hi) {
                 for (uint64_t b = lo; b < hi; ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
             }, 1024);
             if (dfk_create(&cfg, &ctx)) { create_failed = true; count_err = dfk_last_error(); return; }
-            if (fast)                                                           // the arrays are maps of these files: read the files (see below)
+            if (fast)                                                           // the arrays are maps of these files: what has been uploaded leaves the page table (see below)
                 for (const Mapped* m : {&ins[0].fb.m, &ins[0].qp.m})
-                    if (m->p && dfk_hint_file_range(ctx, m->p, m->n, m->fd, 0)) { create_failed = true; count_err = dfk_last_error(); return; }
-            hinted = true;
+                    if (m->p && dfk_hint_file_range(ctx, m->p, m->n, -1, 0)) { create_failed = true; count_err = dfk_last_error(); return; }
             printf("%s: building dictionary on the GPU\n", date().c_str());
             const double tc = now_s();
             count_rc = dfk_count(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bc.data(), n_reads);
             if (count_rc) count_err = dfk_last_error();
             t_count = now_s() - tc;
+            if (!count_rc && device_hist) {
+                while (max_len_known.load() < 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                const int ml = max_len_known.load();
+                qh_dev.assign((size_t)2 * ml * 256, 0);
+                if (ml && dfk_qual_hist(ctx, (uint32_t)ml, qh_dev.data())) qh_err = dfk_last_error();
+            }
         };
         std::thread count_thread;
         struct JoinAtExit { std::thread& t; ~JoinAtExit() { if (t.joinable()) t.join(); } } count_joiner{count_thread};   // (an exception below must not leave it running)
+        struct LenAtExit { std::atomic<int>& v; ~LenAtExit() { if (v.load() < 0) v = 0; } } len_guard{max_len_known};   // (the count thread waits for it)
         if (fast && !sharded && !truthy(a["EXIT_LOAD"])) count_thread = std::thread(count_job);
 
         // ---- lens, quality histogram, datasets (DF.cc:50-68, DfTools.cc:172-238)
@@ -693,27 +732,31 @@ int main(int argc, char** argv)
             int m = 0;
             for (uint64_t i = lo; i < hi; ++i) { lens[i] = (int16_t)rlen(i); m = std::max<int>(m, lens[i]); }
             tmax[t] = m;
-        });
+        }, 1 << 16, true);
         const int max_len = *std::max_element(tmax.begin(), tmax.end());
+        max_len_known = max_len;
         printf("%s: computing quality histogram\n", date().c_str());
         std::vector<int64_t> qh((size_t)2 * max_len * 256, 0);                  // [parity][pos][q]
-        {
+        if (!device_hist) {
             std::vector<std::unique_ptr<QualHist>> part(g_threads + 1);
             parallel_ranges(n_reads, [&](unsigned t, uint64_t lo, uint64_t hi) {
                 part[t].reset(new QualHist(max_len));
                 for (uint64_t r = lo; r < hi; ++r) part[t]->add_read(r, h_pq + qoff(r), h_pq + qoff(r + 1));
-            });
+            }, 1 << 16, true);
             for (const auto& p : part) if (p) p->merge_into(qh);
         }
-        int max_q = -1;
-        for (size_t i = 0; i < qh.size(); ++i) if (qh[i]) max_q = std::max(max_q, (int)(i & 255));
+        auto write_qhist = [&](const std::vector<int64_t>& h) {
+            int max_q = -1;
+            for (size_t i = 0; i < h.size(); ++i) if (h[i]) max_q = std::max(max_q, (int)(i & 255));
+            feudal::BinWriter w(rh + ".qhist");                                 // vec<vec<vec<int64_t>>> [2][max_len][max_q+1]
+            w.pod<uint64_t>(2);
+            for (int par = 0; par < 2; ++par) {
+                w.pod<uint64_t>((uint64_t)max_len);
+                for (int pos = 0; pos < max_len; ++pos) { w.pod<uint64_t>((uint64_t)(max_q + 1)); w.raw(&h[((size_t)par * max_len + pos) * 256], 8 * (size_t)(max_q + 1)); }
+            }
+        };
         { feudal::BinWriter w(rh + ".lens"); w.vec(lens); }
-        { feudal::BinWriter w(rh + ".qhist");                                   // vec<vec<vec<int64_t>>> [2][max_len][max_q+1]
-          w.pod<uint64_t>(2);
-          for (int par = 0; par < 2; ++par) {
-              w.pod<uint64_t>((uint64_t)max_len);
-              for (int pos = 0; pos < max_len; ++pos) { w.pod<uint64_t>((uint64_t)(max_q + 1)); w.raw(&qh[((size_t)par * max_len + pos) * 256], 8 * (size_t)(max_q + 1)); }
-          } }
+        if (!device_hist) write_qhist(qh);
         { std::vector<int16_t>().swap(lens); }
         { feudal::BinWriter w(rh + ".dti"); w.vec(datasets); }
         { feudal::BinWriter w(work_dir + "/subsam.names"); w.pod<uint64_t>(1); w.str("C"); }
@@ -724,20 +767,6 @@ int main(int argc, char** argv)
             background.clear();
             if (bg_failed) std::rethrow_exception(bg_err);
         };
-        if (count_thread.joinable()) {
-            // This process is done with the mapped inputs, and the library reads them through their descriptors (the hint above):
-            // the maps go now, behind the tasks that still read them and beside the upload.  Unmapping 45 GB every page of which
-            // was touched (the qualities, the tables; the bases never were) is a second and a half of page-table work -- at exit,
-            // if not here, where nothing waits for the address-space lock it holds.
-            auto earlier = std::make_shared<std::vector<std::thread>>(std::move(background));
-            background.clear();
-            background.emplace_back([&ins, &hinted, &create_failed, earlier] {
-                for (auto& x : *earlier) x.join();
-                while (!hinted.load()) std::this_thread::sleep_for(std::chrono::milliseconds(2));
-                if (create_failed) return;                                      // (no count will run; the maps go with the process)
-                for (In& x : ins) { x.fb.m.unmap(); x.qp.m.unmap(); }
-            });
-        }
         if (truthy(a["EXIT_LOAD"])) { join_background(); return 0; }             // DF.cc:483
         if (sharded) {
             // the ranks are counting (or, loopback, start now); this process has done the ingest
@@ -762,11 +791,24 @@ int main(int argc, char** argv)
         else count_thread.join();
         if (create_failed) { fprintf(stderr, "DF: %s\n", count_err.c_str()); join_background(); return 1; }
         const int rc = count_rc;
+        if (!rc && device_hist) {
+            if (!qh_err.empty()) throw std::runtime_error(qh_err);
+            write_qhist(qh_dev);
+            std::vector<int64_t>().swap(qh_dev);
+        }
         if (rc == DFK_E_NOGOOD) { printf("\nLooks like your input data have almost no good bases.\nGiving up.\n\n"); join_background(); return 1; }   // :227-230
         if (rc) { fprintf(stderr, "DF: %s\n", count_err.c_str()); join_background(); return rc == DFK_E_NOMEM ? 185 : 1; }        // Martian::exit code
         dfk_stats st{}; dfk_get_stats(ctx, &st);
         T.upload = 1e-3 * st.ms_upload; T.count = t_count - T.upload;
         { std::vector<int32_t>().swap(bc); }
+        if (fast) {
+            // The mapped inputs are on the device (and stay there for the pathing), and the transfer lanes have dropped what they
+            // copied from the page table (the hint above): unmapping them is cheap now, where it would have been three seconds
+            // of one thread's page-table work -- at exit, if not before.  Behind the tasks that still read the maps.
+            auto earlier = std::make_shared<std::vector<std::thread>>(std::move(background));
+            background.clear();
+            background.emplace_back([&ins, earlier] { for (auto& x : *earlier) x.join(); for (In& x : ins) { x.fb.m.unmap(); x.qp.m.unmap(); } });
+        }
         t0 = now_s();
         uint64_t need = 0; dfk_spectrum_json(ctx, nullptr, 0, &need);
         std::string js(need, '\0'); dfk_spectrum_json(ctx, &js[0], need, &need);

@@ -1738,11 +1738,19 @@ int xfer_run(dfk_ctx* c, uint64_t n_chunks, const XferBody& body, const XferFin&
     return rc;
 }
 
-// `bytes` of the caller's host memory at h, or -- inside a range it has hinted (dfk_hint_file_range) -- of the file behind it
+// `bytes` of the caller's host memory at h.  Inside a range it has hinted (dfk_hint_file_range): of the file behind it, if a
+// descriptor came with the hint; else out of the memory, whose pages are then dropped from the caller's page table (the file
+// keeps them) -- by the lane that copied them, so that no single thread is left to unmap 90 GB of touched pages.
 int host_read(dfk_ctx* c, void* dst, const void* h, uint64_t bytes)
 {
     for (const dfk_ctx::FileRange& r : c->file_ranges)
         if ((const char*)h >= r.base && (const char*)h + bytes <= r.base + r.bytes) {
+            if (r.fd < 0) {
+                memcpy(dst, h, bytes);
+                const uintptr_t page = 4096, lo = ((uintptr_t)h + page - 1) & ~(page - 1), hi = ((uintptr_t)h + bytes) & ~(page - 1);
+                if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
+                return 0;
+            }
             uint64_t at = r.off + (uint64_t)((const char*)h - r.base);
             for (uint64_t done = 0; done < bytes;) {
                 const ssize_t got = pread(r.fd, (char*)dst + done, bytes - done, (off_t)(at + done));
@@ -1941,7 +1949,7 @@ int dfk_hint_file_range(dfk_ctx* c, const void* base, uint64_t bytes, int fd, ui
 {
     if (!c) return fail(DFK_E_ARG, "null context");
     if (!base) { c->file_ranges.clear(); return 0; }
-    if (fd < 0 || !bytes) return fail(DFK_E_ARG, "a hinted range needs an open descriptor and a length");
+    if (!bytes) return fail(DFK_E_ARG, "a hinted range needs a length");
     if (c->file_ranges.size() >= 8) return fail(DFK_E_ARG, "8 hinted ranges are kept at most");
     c->file_ranges.push_back(dfk_ctx::FileRange{(const char*)base, bytes, fd, file_off});
     return 0;
@@ -1968,7 +1976,9 @@ int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const
         if (rc) return;
         // (64 bytes of slack: the kernels read the 2-bit stream as aligned 32-bit words, up to 3 bytes past its end)
         if (hipMalloc(d, bytes + 64) != hipSuccess) { (void)hipGetLastError(); rc = fail(DFK_E_NOMEM, "no room on the device for %zu bytes of input", bytes); return; }
+        const auto t0 = std::chrono::steady_clock::now();
         rc = upload(c, *d, h, bytes);
+        TRACE("uploaded %.2f GB in %.3f s", bytes / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     };
     up(&d_packed, packed, pb);
     up(&d_boff, base_off, (n_reads + 1) * 8);

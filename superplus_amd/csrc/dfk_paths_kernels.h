@@ -344,6 +344,66 @@ __device__ bool decode_quals(const uint8_t* __restrict__ pq, uint64_t p, uint64_
     return idx == n;
 }
 
+// ---- the quality histogram of DF's side files (10X/DF.cc:50-68 through DfTools.cc:172-238): how often quality q stands at
+// position pos of a first / second read.  Kept as a DIFFERENCE table [parity][q][pos]: a run of equal qualities is +1 where it
+// begins and -1 behind its end (a block of single qualities is cut into its runs), summed along pos on the host afterwards.
+// Every workgroup has the part q < 64, pos <= 256 of it in LDS -- 1.8e9 reads put their one or two runs on a handful of
+// addresses, which global atomics would take one after the other -- and adds it to the global table at the end; what lies
+// outside goes there directly.  Positions >= max_len are left out, as the reference leaves them.
+constexpr uint32_t QH_POS = 256, QH_Q = 64;
+__global__ void __launch_bounds__(1024)
+k_qual_hist(const uint8_t* __restrict__ pq, const uint64_t* __restrict__ pq_off, uint64_t n_reads, uint32_t max_len,
+            long long* __restrict__ diff /* [2][256][max_len + 1] */)
+{
+    extern __shared__ int qh_lds[];                                       // [2][QH_Q][QH_POS + 1]
+    for (uint32_t i = threadIdx.x; i < 2 * QH_Q * (QH_POS + 1); i += blockDim.x) qh_lds[i] = 0;
+    __syncthreads();
+    auto run = [&](uint32_t par, uint32_t q, uint32_t from, uint32_t to) {      // positions [from, to)
+        const uint32_t a = from < max_len ? from : max_len, b = to < max_len ? to : max_len;
+        if (a == b) return;
+        if (q < QH_Q && b <= QH_POS) {
+            int* row = qh_lds + (par * QH_Q + q) * (QH_POS + 1);
+            atomicAdd(&row[a], 1); atomicAdd(&row[b], -1);
+        } else {
+            long long* row = diff + ((uint64_t)par * 256 + q) * (max_len + 1);
+            atomicAdd((unsigned long long*)&row[a], 1ull); atomicAdd((unsigned long long*)&row[b], ~0ull);
+        }
+    };
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t p = pq_off[r]; const uint64_t end = pq_off[r + 1];
+        const uint32_t par = (uint32_t)(r & 1);
+        uint32_t pos = 0;
+        while (p < end) {
+            const uint32_t nQs = pq[p];
+            if (!nQs || p + 3 > end) break;
+            const uint32_t hdr = pq[p + 1] | ((uint32_t)pq[p + 2] << 8), nBits = hdr & 7u, minQ = (hdr >> 3) & 63u;
+            const uint64_t blk = ((uint64_t)nQs * nBits + 24) >> 3;
+            if (p + blk > end) break;
+            if (!nBits) run(par, minQ, pos, pos + nQs);
+            else {
+                uint64_t bit = 8 * (p + 1) + 9;
+                uint32_t q0 = 0, from = pos;
+                for (uint32_t i = 0; i < nQs; ++i, bit += nBits) {
+                    const uint64_t by = bit >> 3;
+                    const uint32_t w = pq[by] | (by + 1 < p + blk ? (uint32_t)pq[by + 1] << 8 : 0u);
+                    const uint32_t q = minQ + ((w >> (bit & 7)) & ((1u << nBits) - 1u));
+                    if (i && q != q0) { run(par, q0, from, pos + i); from = pos + i; }
+                    q0 = q;
+                }
+                run(par, q0, from, pos + nQs);
+            }
+            pos += nQs; p += blk;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 2 * QH_Q * (QH_POS + 1); i += blockDim.x) {
+        const int v = qh_lds[i];
+        if (!v) continue;
+        const uint32_t at = i % (QH_POS + 1), q = (i / (QH_POS + 1)) % QH_Q, par = i / ((QH_POS + 1) * QH_Q);
+        if (at <= max_len) atomicAdd((unsigned long long*)&diff[((uint64_t)par * 256 + q) * (max_len + 1) + at], (unsigned long long)(long long)v);
+    }
+}
+
 // One attempt to extend the path by one edge.  `path` points at the first edge of the path (room in front and behind is
 // the caller's business); returns true when an edge was added: left = true -> *first moved down by one and *offset grown.
 template <int K>

@@ -22,7 +22,7 @@ ENTRY_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("edge_id", "<u4"), ("coun
 
 EXPORTS = [
     "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_device",
-    "dfk_hint_file_range", "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
+    "dfk_hint_file_range", "dfk_qual_hist", "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
     "dfk_write_kvec", "dfk_write_kvec_part", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_begin_host", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_partition_begin", "dfk_shard_partition_end", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
     "dfk_shard_dict_share", "dfk_shard_dict_adopt", "dfk_shard_dict_whole",
@@ -134,12 +134,19 @@ class Dfk:
                                       C.c_uint64(read_len.numel())))
 
     def hint_file_range(self, array, fd, file_off=0):
-        """dfk_hint_file_range: `array` (a numpy array over a mapped file, e.g. np.memmap) is the bytes of descriptor `fd` from
-        `file_off` on; the host-buffer calls then read the file, and the mapping may go away while they run.  None forgets."""
+        """dfk_hint_file_range: `array` (a numpy array over a mapped file, e.g. np.memmap) is a mapping of a file.  fd >= 0: its
+        bytes are those of descriptor `fd` from `file_off` on, and the host-buffer calls read the file (the mapping may go away
+        while they run); fd = -1: they read the memory and drop the pages they have read from the page table.  None forgets."""
         if array is None:
             _check(lib().dfk_hint_file_range(self._ctx, None, C.c_uint64(0), C.c_int(-1), C.c_uint64(0)))
         else:
             _check(lib().dfk_hint_file_range(self._ctx, C.c_void_p(array.ctypes.data), C.c_uint64(array.nbytes), C.c_int(fd), C.c_uint64(file_off)))
+
+    def qual_hist(self, max_len):
+        """dfk_qual_hist: int64 [2][max_len][256] from the kept reads."""
+        out = np.zeros((2, max_len, 256), np.int64)
+        _check(lib().dfk_qual_hist(self._ctx, C.c_uint32(max_len), _p(out)))
+        return out
 
     def good_lens(self):
         n = self.stats()["n_reads"]

@@ -476,4 +476,12 @@ def test_hinted_file_ranges_are_read_from_the_file(oracle, tmp_path):
     d.count(arr["packed"], arr["base_off"], arr["read_len"], arr["pq_bytes"], arr["pq_off"], rs["bc"])
     assert d.stats()["n_solid"] == len(ref["solid"]) and np.array_equal(d.good_lens(), ref["good_len"])
     d.hint_file_range(None, -1)
-    d.close(); del arr, whole; m.close(); os.close(fd)
+    # without a descriptor: the memory is read (a shared mapping now, showing the file) and its pages are dropped behind the copy
+    m2 = mmap.mmap(fd, at, flags=mmap.MAP_SHARED, prot=mmap.PROT_READ)
+    whole2 = np.frombuffer(m2, np.uint8)
+    arr2 = {k: whole2[o:o + n].view(np.asarray(rs[k]).dtype) for k, (o, n) in where.items()}
+    d.hint_file_range(whole2, -1)
+    d.count(arr2["packed"], arr2["base_off"], arr2["read_len"], arr2["pq_bytes"], arr2["pq_off"], rs["bc"])
+    assert d.stats()["n_solid"] == len(ref["solid"]) and np.array_equal(d.good_lens(), ref["good_len"])
+    assert np.array_equal(arr2["read_len"], rs["read_len"])                 # (dropped pages come back from the file)
+    d.close(); del arr, whole, arr2, whole2; m.close(); m2.close(); os.close(fd)

@@ -176,3 +176,22 @@ def test_paths_edge_cases(oracle, tmp_path):
     with pytest.raises(DfkError):
         d.dups_write(os.path.join(tmp_path, "b.dup"))                      # ... but MarkDups works on pairs
     d.close()
+
+
+@pytest.mark.parametrize("per_base", [False, True])
+def test_quality_histogram_of_the_kept_reads(per_base):
+    """dfk_qual_hist (DF's frag_reads_orig.qhist) against a count over the decoded qualities."""
+    from oracle import paths_oracle
+    from superplus_amd.dfk import Dfk
+    rs = util.make_set(91, 40000, 3000, **(dict(ragged_frac=0.5) if per_base else {}))
+    reads, quals = paths_oracle.unpack_reads(rs)
+    max_len = max(len(q) for q in quals)
+    want = np.zeros((2, max_len, 256), np.int64)
+    for r, q in enumerate(quals):
+        for pos, v in enumerate(q): want[r & 1, pos, v] += 1
+    d = Dfk(K=48, keep_inputs=True)
+    d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    assert np.array_equal(d.qual_hist(max_len), want)
+    short = max(1, max_len - 7)                                            # positions from max_len on are left out
+    assert np.array_equal(d.qual_hist(short), want[:, :short])
+    d.close()
