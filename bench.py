@@ -81,7 +81,7 @@ def cpu_baseline_and_parity(rs, K, device, what):
                pq_off=pq_off.cpu().numpy().astype(np.uint64), bc=bc.cpu().numpy().astype(np.int32))
     cores = os.cpu_count() or 1
     refdrv = os.path.join(ROOT, "oracle", "_ref", "refdrv")
-    base, cpu_solid, cpu_hist = None, None, None
+    base, cpu_solid, cpu_hist, ref_files = None, None, None, None
     if os.path.exists(refdrv):
         try:
             with tempfile.TemporaryDirectory() as d:
@@ -93,8 +93,14 @@ def cpu_baseline_and_parity(rs, K, device, what):
                 feudal.write_bci(d + "/s.bci", bci)
                 os.makedirs(d + "/o")
                 threads = min(cores, 32)
-                out = subprocess.run([refdrv, "dict", str(K), d + "/s", d + "/o", "7", "3", "2", "1", str(threads)],
-                                     check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
+                # "graph" = dict, then the rest of buildReadQGraph48 and the two steps behind it through the reference's own
+                # containers and writers (oracle/ref_graph.cc): a.<K>/ with the graph, a.paths, a.paths.inv, a.countsb, a.dup --
+                # what rows f-1, f-2 and f-4 are compared with below.  Its time is not part of the baseline (createDict only).
+                out = subprocess.run([refdrv, "graph" if K == 48 else "dict", str(K), d + "/s", d + "/o", "7", "3", "2", "1", str(threads)],
+                                     check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900).stdout
+                adir = os.path.join(d, "o", f"a.{K}")
+                if os.path.isdir(adir):
+                    ref_files = {f: open(os.path.join(adir, f), "rb").read() for f in sorted(os.listdir(adir)) if f.startswith("a.") and os.path.isfile(os.path.join(adir, f))}   # (a.*: the stage's files; refdrv keeps its translation tables beside them)
                 # a MapReduceEngine run that overflowed a buffer has dropped barcodes (MapReduceEngine.h:533-538 prints it):
                 # not a reference answer (caveat 2)
                 if "buffer overflow" in out:
@@ -132,6 +138,16 @@ def cpu_baseline_and_parity(rs, K, device, what):
     ok_dict = d.solid_count() == len(cpu_solid) and d.digest() == digest_of(cpu_solid)
     parity = {"status": "ok" if (ok_hist and ok_dict) else "MISMATCH", "against": base["kind"], "reads": n,
               "solid": int(d.solid_count()), "spectrum_equal": ok_hist, "dictionary_digest_equal": ok_dict}
+    if ref_files:
+        # rows f-1, f-2, f-4 on the same reads: every file of the reference's a.<K>/ byte for byte
+        with tempfile.TemporaryDirectory() as t:
+            g = d.graph_build(); d.graph_write(t)
+            p = d.paths_build_device(packed, base_off, read_len, pq_bytes, pq_off)
+            d.paths_write(t + "/a.paths"); d.paths_index_write(t); n_dup = d.dups_write(t + "/a.dup")
+            same = {f: os.path.exists(os.path.join(t, f)) and open(os.path.join(t, f), "rb").read() == b for f, b in ref_files.items()}
+        parity["graph_paths_files"] = {"equal": sorted(f for f, ok in same.items() if ok), "differ": sorted(f for f, ok in same.items() if not ok),
+                                       "hbv_edges": g["n_edges"], "reads_placed": p["n_placed"], "dup_pairs": int(n_dup)}
+        if not all(same.values()): parity["status"] = "MISMATCH"
     d.close()
     return base, parity
 
