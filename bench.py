@@ -152,6 +152,30 @@ def cpu_baseline_and_parity(rs, K, device, what):
     return base, parity
 
 
+def bind_to_gpu_node(local):
+    """This process's threads (and those of the stage it starts) on the CPUs of the GPU's NUMA node, as a launcher's
+    `numactl --cpunodebind` would: what it writes into the page cache -- the DF leg's input files -- then lies on that node's
+    memory, and the stage's transfer lanes (which bind themselves the same way, df_main.cc) read it at the local rate rather
+    than over the socket link.  BENCH_NO_BIND=1 leaves the scheduler alone.  -> what was done, for the JSON."""
+    if os.environ.get("BENCH_NO_BIND"): return {"bound": False, "why": "BENCH_NO_BIND"}
+    try:
+        bus = torch.cuda.get_device_properties(local).pci_bus_id if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None
+        dom = getattr(torch.cuda.get_device_properties(local), "pci_domain_id", 0)
+        dev_id = getattr(torch.cuda.get_device_properties(local), "pci_device_id", 0)
+        if bus is None: return {"bound": False, "why": "no PCI bus id"}
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev_id:02x}.0/numa_node"
+        node = int(open(path).read())
+        if node < 0: return {"bound": False, "why": "no NUMA node recorded for the device"}
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        os.sched_setaffinity(0, cpus)
+        return {"bound": True, "numa_node": node, "cpus": len(cpus)}
+    except Exception as e:                      # (an unusual sysfs: measure unbound, and say so)
+        return {"bound": False, "why": str(e)[:120]}
+
+
 def timed_steps(d, shard, steps, warmup=1):
     """-> (seconds per step, stats of the last step) for a single-GPU context."""
     for _ in range(warmup):
@@ -393,6 +417,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    affinity = bind_to_gpu_node(local)
     multi = world > 1 or args.force_dist
     if multi:
         import torch.distributed as dist
@@ -510,6 +535,7 @@ def main():
                        "reads_total": 2 * total_pairs, "kmer_instances_total": n_inst, "K": args.K,
                        "parallelism": "single GPU, bucket-range passes" if world == 1 else
                                       f"{world} ranks: read shards, all-to-all of super-k-mer records by minimizer bucket"},
+            "host_affinity": affinity,                # (rank 0's; bind_to_gpu_node)
             "step_ms_each_rank0": each,
             "step_wall_s": elapsed / args.steps,      # one pass of the hot path, inputs resident in HBM (NOT the DF stage's wall-clock: see df_stage)
             **({"rehearsal": f"rank 0 of {args.emulate_world} against replicas of itself; per-rank time without the transfers"}

@@ -1,5 +1,5 @@
 // tools/fs_write_scaling.cc -- how fast can N threads fill ONE file (pwrite / shared mapping / after fallocate)?
-//   g++ -O2 -pthread -o /tmp/fsw tools/fs_write_scaling.cc && /tmp/fsw <threads> <0 pwrite|1 mmap|2 fallocate+pwrite> <GiB> <chunk MiB> [path]
+//   g++ -O2 -pthread -o /tmp/fsw tools/fs_write_scaling.cc && /tmp/fsw <threads> <0 pwrite|1 mmap|2 fallocate+pwrite|4 fallocate, then mmap (timed apart)> <GiB> <chunk MiB> [path]
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -16,7 +16,8 @@ int main(int argc, char** argv)
     const char* path = argc > 5 ? argv[5] : "/dev/shm/wtest.bin";
     int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
     if (mode != 3) ftruncate(fd, total);
-    char* map = mode == 1 ? (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : nullptr;
+    if (mode == 4) { auto ta = std::chrono::steady_clock::now(); posix_fallocate(fd, 0, total); printf("fallocate %.2f s (%.2f GB/s), not in the time below\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count(), total / 1e9 / std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count()); }
+    char* map = (mode == 1 || mode == 4) ? (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : nullptr;
     std::atomic<size_t> next{0};
     auto t0 = std::chrono::steady_clock::now();
     if (mode == 2) { posix_fallocate(fd, 0, total); printf("fallocate %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
@@ -24,7 +25,7 @@ int main(int argc, char** argv)
     for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
         char* buf = (char*)malloc(chunk); memset(buf, t + 1, chunk);
         for (size_t i; (i = next.fetch_add(1)) * chunk < total;) {
-            if (mode == 1) memcpy(map + i * chunk, buf, chunk);
+            if (mode == 1 || mode == 4) memcpy(map + i * chunk, buf, chunk);
             else pwrite(fd, buf, chunk, i * chunk);
         }
         free(buf);
