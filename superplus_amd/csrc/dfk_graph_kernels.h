@@ -522,10 +522,10 @@ k_graph_cycles(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t n_
 //   outside-in against the complement of the mirror base, which the first and the last k-mer of the walk decide
 //   (they differ as k-mers, so one of their K positions differs).
 // The store must be zero where no base is written (the last byte of an edge); the host clears it.  Lanes take edges off a
-// cursor like the counting walk's (`order`, if given, lists the edges to take).
+// cursor like the counting walk's.
 template <int K>
 __global__ void __launch_bounds__(256)
-k_graph_walk_write(PartTable pt_arg, EdgeRec* __restrict__ recs, const uint32_t* __restrict__ order, uint64_t e_lo, uint64_t e_hi,
+k_graph_walk_write(PartTable pt_arg, EdgeRec* __restrict__ recs, uint64_t e_lo, uint64_t e_hi,
                    uint8_t* __restrict__ store, unsigned long long* __restrict__ cursor, unsigned int* __restrict__ bad)
 {
     __shared__ PartLds pt;
@@ -579,7 +579,7 @@ k_graph_walk_write(PartTable pt_arg, EdgeRec* __restrict__ recs, const uint32_t*
             dry = base + __popcll(idle) >= n_todo;
             const uint64_t t = base + __popcll(idle & ((1ull << lane) - 1ull));
             if (!active && t < n_todo) {
-                eno = e_lo + (order ? order[t] : t);
+                eno = e_lo + t;
                 const EdgeRec R = recs[eno];
                 n = R.n; L = n + K - 1; g_start = R.g_start; rflags = R.flags;
                 out = store + R.byte_off;
