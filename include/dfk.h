@@ -205,6 +205,14 @@ int dfk_graph_build(dfk_ctx* ctx);
 int dfk_graph_stats(dfk_ctx* ctx, uint64_t* n_canonical_edges, uint64_t* n_vertices, uint64_t* n_edges);
 int dfk_graph_write(dfk_ctx* ctx, const char* dir);
 
+/* a.paths written WHILE the reads are being pathed: the next dfk_paths_build creates `path` and a thread of the library's
+ * takes every finished batch's variable data to its place in the file; dfk_paths_write(ctx, path) -- the same path -- then
+ * waits for that thread and adds what only the whole build knows (control block, offset table).  One file on a tmpfs takes
+ * what one writer gives (9 GB/s): this starts the 37 GB of configs[1] two seconds earlier.  path = NULL: back to
+ * dfk_paths_write writing everything.  A build that fails removes the file.  (ReadPathVec::WriteAll, 10X/WriteFiles.cc:78-82,
+ * writes after pathReads has returned.) */
+int dfk_paths_sink(dfk_ctx* ctx, const char* path);
+
 /* ---- read pathing ("correction by pathing") on the graph dfk_graph_build left in the context ----
  * dfk_paths_build replaces pathReads (paths/long/BuildReadQGraph48.cc:1420-1442) as buildReadQGraph48 calls it
  * (:1664-1665, with useNewAligner = True from StageBuildGraph, 10X/runstages/RunStages.cc:389-390): every read --

@@ -843,6 +843,7 @@ int main(int argc, char** argv)
                 // pathReads (BuildReadQGraph48.cc:1664-1665) and a.<K>/a.paths (10X/WriteFiles.cc:78-82)
                 t0 = now_s();
                 printf("%s: pathing reads\n", date().c_str());
+                if (dfk_paths_sink(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());      // (its data goes to the file batch by batch)
                 if (dfk_paths_build(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) throw std::runtime_error(dfk_last_error());
                 { dfk_stats ps{}; dfk_get_stats(ctx, &ps); t_p_dev = 1e-6 * (double)ps.reserved[3]; }
                 printf("%s: writing paths\n", date().c_str());

@@ -16,6 +16,7 @@
 #include <string>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>

@@ -22,7 +22,7 @@ ENTRY_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("edge_id", "<u4"), ("coun
 
 EXPORTS = [
     "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_device",
-    "dfk_hint_file_range", "dfk_qual_hist", "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
+    "dfk_hint_file_range", "dfk_qual_hist", "dfk_paths_sink", "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
     "dfk_write_kvec", "dfk_write_kvec_part", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_begin_host", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_partition_begin", "dfk_shard_partition_end", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
     "dfk_shard_dict_share", "dfk_shard_dict_adopt", "dfk_shard_dict_whole",
@@ -228,6 +228,10 @@ class Dfk:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(lib().dfk_paths_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
         return dict(n_reads=a.value, n_placed=b.value, n_path_edges=c.value)
+
+    def paths_sink(self, path):
+        """dfk_paths_sink: the next paths_build streams a.paths' variable data into `path`; paths_write(path) completes it."""
+        _check(lib().dfk_paths_sink(self._ctx, None if path is None else path.encode()))
 
     def paths_write(self, path):
         """a.paths (feudal file of ReadPath) as WriteAssemblyFiles writes it."""

@@ -30,15 +30,18 @@ def test_paths_file_matches_reference_fixture(golden_dir, tmp_path, monkeypatch,
     exp = open(os.path.join(golden_dir, case, "a.paths"), "rb").read()
     # one part / several parts; reads re-uploaded / kept; room for two parts a read (batches done again with all of it) and no
     # filter in front of the index
-    for extra in (dict(), dict(passes=3, inst_per_item=1500, keep_inputs=True), dict(slots=2)):
+    # ... and a.paths streamed into its file while the reads are pathed (dfk_paths_sink)
+    for extra in (dict(), dict(passes=3, inst_per_item=1500, keep_inputs=True), dict(sink=True), dict(slots=2)):
         extra = dict(extra)
+        sink = extra.pop("sink", False)
         if extra.pop("slots", None):
-            monkeypatch.setenv("DFK_PATH_SLOTS", "2"); monkeypatch.setenv("DFK_NO_FILTER", "1")
+            monkeypatch.setenv("DFK_PATH_SLOTS", "2"); monkeypatch.setenv("DFK_NO_FILTER", "1"); sink = True
         d = Dfk(K=K, **kw, **extra)
         d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], None if nobc else rs["bc"])
         d.graph_build()
-        st = d.paths_build() if extra.get("keep_inputs") else d.paths_build(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"])
         out = os.path.join(tmp_path, "a.paths")
+        if sink: d.paths_sink(out)
+        st = d.paths_build() if extra.get("keep_inputs") else d.paths_build(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"])
         d.paths_write(out)
         got = open(out, "rb").read()
         assert got == exp, f"{case} {extra}: " + explain(got, exp)
