@@ -4,8 +4,11 @@
 //
 //   the reference reads both gz files once per barcode BUCKET (NUM_BUCKETS passes over the input), keeps each
 //   barcode's pairs in a list it insertion-sorts (quadratic per barcode), writes one temporary file set per bucket
-//   and merges them; here the files are read ONCE (one thread per file), pairs are grouped by barcode, each group is
-//   stable-sorted, qualities are encoded on all threads and the three files are written directly.
+//   and merges them; here the files are read ONCE (one thread per file) when their decompressed reads fit the memory
+//   allowed, pairs are grouped by barcode, each group is stable-sorted, qualities are encoded on all threads and the three
+//   files are written directly.  When they do not fit, the first pass keeps the barcodes and lengths only, and the files
+//   are read again once per GROUP of buckets -- as many consecutive buckets as the memory holds -- each group appended
+//   to the output as it is done: the reference's bound on memory with (usually far) fewer passes than NUM_BUCKETS.
 //
 // What must come out the same, byte for byte (checked against the reference's own binary, oracle/_ref/
 // ParseBarcodedFastqs, built single-threaded -- a threaded reference run appends the buckets in the order its threads
@@ -36,7 +39,13 @@
 
 namespace {
 
-[[noreturn]] void die(const std::string& m) { fprintf(stderr, "ParseBarcodedFastqs: %s\n", m.c_str()); exit(1); }
+std::vector<std::string> g_partial;          // output files begun and not finished: a run that gives up takes them along
+[[noreturn]] void die(const std::string& m)
+{
+    fprintf(stderr, "ParseBarcodedFastqs: %s\n", m.c_str());
+    for (const std::string& p : g_partial) remove(p.c_str());
+    exit(1);
+}
 
 std::vector<std::string> parse_set(std::string s)
 {
@@ -47,12 +56,14 @@ std::vector<std::string> parse_set(std::string s)
     return out;
 }
 
-struct Fastq {                               // one file: per read its barcode, base codes and qualities
-    std::vector<int64_t> bc;
-    std::vector<uint8_t> bases, quals;       // concatenated
-    std::vector<uint64_t> off{0};            // [n+1] into bases / quals
+struct Fastq {                               // one file: per read its barcode; base codes and qualities of the reads that are HELD
+    std::vector<int64_t> bc;                 // of every read (first pass)
+    std::vector<uint16_t> len;               // of every read (first pass)
+    std::vector<uint8_t> bases, quals;       // concatenated, held reads only
+    std::vector<uint64_t> off{0};            // [held + 1] into bases / quals
     std::string error;
     uint64_t counted = 0;                    // bases already added to g_held
+    bool spilled = false;                    // the first pass gave the bases up (the set does not fit): bc and len are complete, the rest empty
 };
 
 // "...#b1_b2_b3/1\t..." -> b1*1537^2 + b2*1537 + b3  (10X/Barcode.cc:3-13: three integers, one separator character each)
@@ -70,51 +81,69 @@ bool barcode_of(const char* line, int64_t* out)
     return true;
 }
 
-// Memory: this program holds BOTH decompressed files (a byte per base and a byte per quality) and then the encoded reads
-// twice while it writes -- about 3.5 bytes per base plus ~100 per read, where the reference bounds its own use by
-// re-reading the inputs once per barcode bucket (10X/ParseBarcodedFastqs.cc:434-449).  g_mem_limit (MAX_MEM_GB, or the
-// machine's memory) is checked while the files are read and before the encode: a set that does not fit ends with a
-// message, not with the kernel's OOM killer.
+// Memory: the reads that are held cost a byte per base and a byte per quality, and then their encoded form twice while a
+// group is written -- about 3.5 bytes per base plus ~100 per read.  g_mem_limit (MAX_MEM_GB, or the machine's memory) is
+// what all of it may take: a first pass that outgrows it drops the bases (g_spill) and only scans on, and the buckets are
+// then done in groups that fit (the reference bounds its own use by re-reading the inputs once per bucket,
+// 10X/ParseBarcodedFastqs.cc:434-449).  Only a SINGLE bucket too large for the memory ends the program, with a message
+// that says so rather than with the kernel's OOM killer.
 std::atomic<uint64_t> g_held{0};
+std::atomic<bool> g_spill{false};
 uint64_t g_mem_limit = 0;
 bool over_budget(uint64_t bases, uint64_t reads) { return g_mem_limit && 7 * bases / 2 + 100 * reads > g_mem_limit; }
 std::string budget_message(uint64_t bases, uint64_t reads)
 {
-    return "this input needs about " + std::to_string((7 * bases / 2 + 100 * reads) >> 30) + " GiB (3.5 bytes per base + 100 per read: the decompressed reads are held in "
-           "memory), more than the " + std::to_string(g_mem_limit >> 30) + " GiB allowed (MAX_MEM_GB, or the machine's memory); run it on a machine with more memory or split the input";
+    return "one barcode bucket needs about " + std::to_string((7 * bases / 2 + 100 * reads) >> 30) + " GiB (3.5 bytes per base + 100 per read: a bucket's decompressed reads are held in "
+           "memory), more than the " + std::to_string(g_mem_limit >> 30) + " GiB allowed (MAX_MEM_GB, or the machine's memory); raise NUM_BUCKETS (256 at most) or the memory";
 }
 
-void read_fastq(const std::string& path, Fastq* f)
+// want = nullptr: the first pass -- every read's barcode and length; its bases and qualities too until the budget says no.
+// want != nullptr: a group's pass -- bases and qualities of the reads i (numbered as they stand in this file) with (*want)[i];
+// nothing else is stored.
+void read_fastq(const std::string& path, Fastq* f, const std::vector<uint8_t>* want)
 {
     gzFile g = gzopen(path.c_str(), "rb");
     if (!g) { f->error = "cannot open " + path; return; }
     gzbuffer(g, 1 << 20);
     std::vector<char> line(1 << 16);
     auto get = [&]() -> bool { return gzgets(g, line.data(), (int)line.size()) != nullptr; };
+    uint64_t i = 0;                                                                    // reads seen
     while (get()) {
         if (line[0] != '@') { f->error = "out of sync reading line: " + path + ": " + line.data(); break; }
-        int64_t bc;
-        if (!barcode_of(line.data(), &bc)) { f->error = "cannot parse the barcode of " + std::string(line.data()); break; }
+        int64_t bc = 0;
+        if (!want && !barcode_of(line.data(), &bc)) { f->error = "cannot parse the barcode of " + std::string(line.data()); break; }
         if (!get()) { f->error = "truncated record in " + path; break; }
-        for (const char* p = line.data(); *p && *p != '\n' && *p != '\r'; ++p) {
+        const bool hold = want ? (i < want->size() && (*want)[i]) : !f->spilled;
+        size_t nb = 0;
+        for (const char* p = line.data(); *p && *p != '\n' && *p != '\r'; ++p, ++nb) {
             uint8_t v;
             switch (*p) { case 'A': case 'a': case 'N': case 'n': v = 0; break; case 'C': case 'c': v = 1; break;
                           case 'G': case 'g': v = 2; break; case 'T': case 't': v = 3; break;
                           default: f->error = std::string("unexpected base '") + *p + "' in " + path; v = 0; }
-            f->bases.push_back(v);
+            if (hold) f->bases.push_back(v);
         }
         if (!get() || !get()) { f->error = "truncated record in " + path; break; }       // '+' line, then the qualities
         size_t nq = 0;
-        for (const char* p = line.data(); *p; ++p) if (*p != '\n' && *p != '\r') { f->quals.push_back((uint8_t)(*p - 33)); ++nq; }
-        if (nq != f->bases.size() - f->off.back()) { f->error = "a read of " + path + " has " + std::to_string(nq) + " qualities for " + std::to_string(f->bases.size() - f->off.back()) + " bases"; break; }
-        f->bc.push_back(bc);
-        f->off.push_back(f->bases.size());
+        for (const char* p = line.data(); *p; ++p) if (*p != '\n' && *p != '\r') { if (hold) f->quals.push_back((uint8_t)(*p - 33)); ++nq; }
+        if (nq != nb) { f->error = "a read of " + path + " has " + std::to_string(nq) + " qualities for " + std::to_string(nb) + " bases"; break; }
+        if (!want) {
+            if (nb > 65535) { f->error = "a read of " + path + " has " + std::to_string(nb) + " bases (65535 at most)"; break; }
+            f->bc.push_back(bc); f->len.push_back((uint16_t)nb);
+        }
+        if (hold) f->off.push_back(f->bases.size());
+        ++i;
         if (!f->error.empty()) break;
-        if ((f->bc.size() & 0xFFFF) == 0) {                                           // (both reader threads add to one total)
-            const uint64_t mine = f->bases.size();
-            const uint64_t all = g_held.fetch_add(mine - f->counted) + (mine - f->counted);
-            f->counted = mine;
-            if (over_budget(all, 0)) { f->error = "stopped reading " + path + ": " + budget_message(all, 0); break; }
+        if (!want && (i & 0xFFFF) == 0) {                                              // (both reader threads add to one total)
+            if (!f->spilled) {
+                const uint64_t mine = f->bases.size();
+                const uint64_t all = g_held.fetch_add(mine - f->counted) + (mine - f->counted);
+                f->counted = mine;
+                if (over_budget(all, 0)) g_spill = true;
+            }
+            if (g_spill && !f->spilled) {                                              // the set does not fit: scan on, hold nothing
+                f->spilled = true;
+                std::vector<uint8_t>().swap(f->bases); std::vector<uint8_t>().swap(f->quals); std::vector<uint64_t>(1, 0).swap(f->off);
+            }
         }
     }
     gzclose(g);
@@ -200,18 +229,22 @@ int main(int argc, char** argv)
     }
     // ---- both files, one thread each
     Fastq f1, f2;
-    { std::thread t(read_fastq, fq[1], &f2); read_fastq(fq[0], &f1); t.join(); }
+    { std::thread t(read_fastq, fq[1], &f2, nullptr); read_fastq(fq[0], &f1, nullptr); t.join(); }
     if (!f1.error.empty()) die(f1.error);
     if (!f2.error.empty()) die(f2.error);
     if (f1.bc.size() != f2.bc.size()) die("something not match with pair file: " + fq[0] + " or " + fq[1]);
     const size_t n_pairs = f1.bc.size();
     for (size_t i = 0; i < n_pairs; ++i) if (f1.bc[i] != f2.bc[i]) die("something not match with pair file: " + fq[0] + " or " + fq[1]);
     fprintf(stderr, "total reads: %zu\n", 2 * n_pairs);
-    if (over_budget(f1.bases.size() + f2.bases.size(), 2 * n_pairs)) die(budget_message(f1.bases.size() + f2.bases.size(), 2 * n_pairs));
+    // (one reader may have reached the budget's check after the other had finished: both or neither hold their reads)
+    const bool spilled = f1.spilled || f2.spilled || over_budget(f1.bases.size() + f2.bases.size(), 2 * n_pairs);
+    if (spilled) for (Fastq* f : {&f1, &f2}) { std::vector<uint8_t>().swap(f->bases); std::vector<uint8_t>().swap(f->quals); std::vector<uint64_t>(1, 0).swap(f->off); }
+    const std::vector<int64_t>& bc = f1.bc;
+    std::vector<int64_t>().swap(f2.bc);
 
     // ---- buckets of barcodes (:311-336): the distinct barcodes in the container's iteration order, cut into equal runs
     std::unordered_set<int64_t> bc_set;
-    for (size_t i = 0; i < n_pairs; ++i) bc_set.emplace(f1.bc[i]);
+    for (size_t i = 0; i < n_pairs; ++i) bc_set.emplace(bc[i]);
     fprintf(stderr, "total barcodes: %zu\n", bc_set.size());
     std::vector<std::vector<int64_t>> buckets;
     if (!bc_set.empty()) {
@@ -227,82 +260,167 @@ int main(int argc, char** argv)
             else buckets.back().insert(buckets.back().end(), cur.begin(), cur.end());
         }
     }
-    // ---- pairs grouped by barcode, in file order
-    std::unordered_map<int64_t, std::vector<uint32_t>> group;
-    for (size_t i = 0; i < n_pairs; ++i) group[f1.bc[i]].push_back((uint32_t)i);
-    auto seq = [](const Fastq& f, uint32_t i) { return std::make_pair(f.bases.data() + f.off[i], f.bases.data() + f.off[i + 1]); };
-    auto pair_greater = [&](uint32_t x, uint32_t y) {                  // (read 1, read 2) of x above those of y, as base-code sequences
-        const auto x1 = seq(f1, x), y1 = seq(f1, y);
-        if (std::lexicographical_compare(y1.first, y1.second, x1.first, x1.second)) return true;
-        if (std::lexicographical_compare(x1.first, x1.second, y1.first, y1.second)) return false;
-        const auto x2 = seq(f2, x), y2 = seq(f2, y);
-        return std::lexicographical_compare(y2.first, y2.second, x2.first, x2.second);
-    };
-    // ---- output order of the pairs and the barcode index
-    std::vector<uint32_t> order; order.reserve(n_pairs);
-    std::vector<int64_t> bci{0};
-    if (group.count(0)) order = group[0];
-    bci.push_back((int64_t)(2 * order.size()));
-    {
-        std::vector<std::vector<uint32_t>*> to_sort;
-        for (auto& kv : group) if (kv.first != 0) to_sort.push_back(&kv.second);
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < threads; ++t)
-            th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < to_sort.size();) std::stable_sort(to_sort[i]->begin(), to_sort[i]->end(), pair_greater); });
-        for (auto& x : th) x.join();
-    }
-    for (const std::vector<int64_t>& bucket : buckets) {
-        std::set<int64_t> sorted(bucket.begin(), bucket.end());
-        for (int64_t b : sorted) {
-            if (b == 0) continue;
-            const std::vector<uint32_t>& g = group[b];
-            if (reads_per_bc && 2 * g.size() >= reads_per_bc) continue;
-            order.insert(order.end(), g.begin(), g.end());
-            bci.push_back((int64_t)(2 * order.size()));
+
+    // ---- the output, appended to as the units are done: the unbarcoded pairs in file order (unit 0), then one unit per bucket
+    const std::string head = a["OUT_HEAD"];
+    { const size_t slash = head.rfind('/');
+      if (slash != std::string::npos) { std::string d = head.substr(0, slash); for (size_t i = 1; i <= d.size(); ++i) if (i == d.size() || d[i] == '/') mkdir(d.substr(0, i).c_str(), 0777); } }
+    struct Appender {                                                           // a feudal file whose variable data comes in pieces
+        FILE* f = nullptr; std::string path; std::vector<uint64_t> off{24};
+        void open(const std::string& p) { path = p; f = fopen(p.c_str(), "wb"); g_partial.push_back(p); const char z[24] = {0}; if (!f || fwrite(z, 1, 24, f) != 24) die("cannot create " + p); }
+        void add(const std::vector<uint8_t>& v) { if (!v.empty() && fwrite(v.data(), 1, v.size(), f) != v.size()) die("short write " + path); off.push_back(off.back() + v.size()); }
+        void finish(const void* fixed, size_t fixed_bytes, uint8_t szFixed, uint8_t szX, uint8_t szA)
+        {
+            const uint64_t n = off.size() - 1;
+            feudal::Header h{(uint32_t)n, 1, szFixed, szX, szA, off[n], off[n] + 8 * (n + 1)};
+            bool ok = fwrite(off.data(), 8, n + 1, f) == n + 1 && (fixed_bytes == 0 || fwrite(fixed, 1, fixed_bytes, f) == fixed_bytes);
+            ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, 24, 1, f) == 1;
+            ok = (fclose(f) == 0) && ok; f = nullptr;
+            if (!ok) die("short write " + path);
         }
-    }
+    } out_b, out_q;
+    out_b.open(head + ".fastb"); out_q.open(head + ".qualp");
+    std::vector<uint32_t> lens;
+    std::vector<int64_t> bci{0};
+    size_t n_barcodes = 0;
     // (= mergeBarcodedReadFiles' index, :251-288: 0, then the start of every barcode -- the first start is the number of
     // unbarcoded reads -- then the read count)
 
-    // ---- encode: 2-bit bases and PQVec blocks per read, on all threads
-    const size_t n_reads = 2 * order.size();
-    std::vector<std::vector<uint8_t>> pk(n_reads), pq(n_reads);
-    std::vector<uint32_t> lens(n_reads);
-    {
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < threads; ++t)
-            th.emplace_back([&] {
-                std::vector<unsigned> cost; std::vector<PqBlock> blocks;
-                for (size_t r; (r = next.fetch_add(256)) < n_reads;)
-                    for (size_t k = r; k < std::min(n_reads, r + 256); ++k) {
-                        const Fastq& f = (k & 1) ? f2 : f1;
-                        const uint32_t i = order[k >> 1];
-                        const uint8_t* b = f.bases.data() + f.off[i];
-                        const uint32_t L = (uint32_t)(f.off[i + 1] - f.off[i]);
-                        lens[k] = L;
-                        pk[k].assign((L + 3) / 4, 0);
-                        for (uint32_t j = 0; j < L; ++j) pk[k][j >> 2] |= (uint8_t)(b[j] << (2 * (j & 3)));
-                        pq_encode(f.quals.data() + f.off[i], L, cost, blocks, &pq[k]);
-                    }
-            });
-        for (auto& x : th) x.join();
+    // The reads held in g1 / g2 are those of the pairs `held` names (ascending; nullptr = all pairs).  Writes the units [u0, u1):
+    // unit 0 = the unbarcoded pairs among them, unit u = bucket u - 1.
+    auto emit = [&](const Fastq& g1, const Fastq& g2, const std::vector<uint32_t>* held, size_t u0, size_t u1, bool first_of_unit0, bool last_of_unit0) {
+        const size_t m = held ? held->size() : n_pairs;
+        auto pair_no = [&](size_t k) { return held ? (size_t)(*held)[k] : k; };
+        // ---- pairs grouped by barcode, in file order
+        std::unordered_map<int64_t, std::vector<uint32_t>> group;
+        for (size_t k = 0; k < m; ++k) group[bc[pair_no(k)]].push_back((uint32_t)k);
+        auto seq = [](const Fastq& f, uint32_t i) { return std::make_pair(f.bases.data() + f.off[i], f.bases.data() + f.off[i + 1]); };
+        auto pair_greater = [&](uint32_t x, uint32_t y) {              // (read 1, read 2) of x above those of y, as base-code sequences
+            const auto x1 = seq(g1, x), y1 = seq(g1, y);
+            if (std::lexicographical_compare(y1.first, y1.second, x1.first, x1.second)) return true;
+            if (std::lexicographical_compare(x1.first, x1.second, y1.first, y1.second)) return false;
+            const auto x2 = seq(g2, x), y2 = seq(g2, y);
+            return std::lexicographical_compare(y2.first, y2.second, x2.first, x2.second);
+        };
+        // ---- output order of the pairs and the barcode index
+        std::vector<uint32_t> order; order.reserve(m);
+        const uint64_t reads_before = out_b.off.size() - 1;
+        if (u0 == 0) {
+            (void)first_of_unit0;
+            if (group.count(0)) order = group[0];
+            if (last_of_unit0) bci.push_back((int64_t)(reads_before + 2 * order.size()));
+        }
+        {
+            std::vector<std::vector<uint32_t>*> to_sort;
+            for (auto& kv : group) if (kv.first != 0) to_sort.push_back(&kv.second);
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < threads; ++t)
+                th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < to_sort.size();) std::stable_sort(to_sort[i]->begin(), to_sort[i]->end(), pair_greater); });
+            for (auto& x : th) x.join();
+        }
+        for (size_t u = std::max<size_t>(u0, 1); u < u1; ++u) {
+            const std::vector<int64_t>& bucket = buckets[u - 1];
+            std::set<int64_t> sorted(bucket.begin(), bucket.end());
+            for (int64_t b : sorted) {
+                if (b == 0) continue;
+                const std::vector<uint32_t>& g = group[b];
+                if (reads_per_bc && 2 * g.size() >= reads_per_bc) continue;
+                order.insert(order.end(), g.begin(), g.end());
+                bci.push_back((int64_t)(reads_before + 2 * order.size()));
+                ++n_barcodes;
+            }
+        }
+        // ---- encode: 2-bit bases and PQVec blocks per read, on all threads
+        const size_t n_reads = 2 * order.size();
+        std::vector<std::vector<uint8_t>> pk(n_reads), pq(n_reads);
+        const size_t lens0 = lens.size();
+        lens.resize(lens0 + n_reads);
+        {
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < threads; ++t)
+                th.emplace_back([&] {
+                    std::vector<unsigned> cost; std::vector<PqBlock> blocks;
+                    for (size_t r; (r = next.fetch_add(256)) < n_reads;)
+                        for (size_t k = r; k < std::min(n_reads, r + 256); ++k) {
+                            const Fastq& f = (k & 1) ? g2 : g1;
+                            const uint32_t i = order[k >> 1];
+                            const uint8_t* b = f.bases.data() + f.off[i];
+                            const uint32_t L = (uint32_t)(f.off[i + 1] - f.off[i]);
+                            lens[lens0 + k] = L;
+                            pk[k].assign((L + 3) / 4, 0);
+                            for (uint32_t j = 0; j < L; ++j) pk[k][j >> 2] |= (uint8_t)(b[j] << (2 * (j & 3)));
+                            pq_encode(f.quals.data() + f.off[i], L, cost, blocks, &pq[k]);
+                        }
+                });
+            for (auto& x : th) x.join();
+        }
+        for (size_t k = 0; k < n_reads; ++k) { out_b.add(pk[k]); out_q.add(pq[k]); }
+    };
+
+    if (!spilled) emit(f1, f2, nullptr, 0, buckets.size() + 1, true, true);
+    else {
+        // ---- the set does not fit: groups of consecutive units that do, the inputs read again for each (held reads only)
+        std::vector<uint16_t> len1, len2; len1.swap(f1.len); len2.swap(f2.len);
+        // what the tables kept for the whole run take (barcodes, lengths, the flags of a pass, the output's offsets and lengths)
+        const uint64_t tables = (uint64_t)n_pairs * (8 + 2 + 2 + 1 + 1 + 2 * 20);
+        if (g_mem_limit && tables >= g_mem_limit) die("the tables of " + std::to_string(n_pairs) + " pairs alone take " + std::to_string(tables >> 30) + " GiB, more than MAX_MEM_GB (or the machine's memory) allows");
+        std::unordered_map<int64_t, uint32_t> unit_of;                          // barcode -> unit
+        for (size_t u = 0; u < buckets.size(); ++u) for (int64_t b : buckets[u]) unit_of[b] = (uint32_t)(u + 1);
+        unit_of[0] = 0;
+        std::vector<uint64_t> unit_bases(buckets.size() + 1, 0), unit_pairs(buckets.size() + 1, 0);
+        for (size_t i = 0; i < n_pairs; ++i) { const uint32_t u = unit_of[bc[i]]; unit_bases[u] += (uint64_t)len1[i] + len2[i]; ++unit_pairs[u]; }
+        auto fits = [&](uint64_t bases, uint64_t pairs) { return !g_mem_limit || 7 * bases / 2 + 200 * pairs + tables <= g_mem_limit; };
+        auto pass = [&](const std::vector<uint8_t>& want, const std::vector<uint32_t>& held, size_t u0, size_t u1, bool first0, bool last0) {
+            Fastq g1, g2;
+            { std::thread t(read_fastq, fq[1], &g2, &want); read_fastq(fq[0], &g1, &want); t.join(); }
+            if (!g1.error.empty()) die(g1.error);
+            if (!g2.error.empty()) die(g2.error);
+            if (g1.off.size() - 1 != held.size() || g2.off.size() - 1 != held.size()) die("the input changed between two passes over it");
+            emit(g1, g2, &held, u0, u1, first0, last0);
+        };
+        size_t passes = 0;
+        // unit 0 keeps the file's order: it may be cut anywhere
+        {
+            size_t i = 0;
+            bool first = true;
+            const bool any0 = unit_pairs[0] != 0;
+            if (!any0) bci.push_back(0);
+            while (any0 && i < n_pairs) {
+                std::vector<uint8_t> want(n_pairs, 0); std::vector<uint32_t> held;
+                uint64_t bases = 0;
+                for (; i < n_pairs; ++i) {
+                    if (bc[i] != 0) continue;
+                    const uint64_t add = (uint64_t)len1[i] + len2[i];
+                    if (!held.empty() && !fits(bases + add, held.size() + 1)) break;
+                    bases += add; want[i] = 1; held.push_back((uint32_t)i);
+                }
+                if (held.empty()) break;
+                bool more = false;
+                for (size_t j = i; j < n_pairs && !more; ++j) more = bc[j] == 0;
+                pass(want, held, 0, 1, first, !more); ++passes;
+                first = false;
+            }
+        }
+        for (size_t u = 1; u <= buckets.size();) {
+            size_t v = u; uint64_t bases = 0, pairs = 0;
+            while (v <= buckets.size() && (v == u || fits(bases + unit_bases[v], pairs + unit_pairs[v]))) { bases += unit_bases[v]; pairs += unit_pairs[v]; ++v; }
+            if (!fits(bases, pairs)) die(budget_message(bases, 2 * pairs));
+            std::vector<uint8_t> want(n_pairs, 0); std::vector<uint32_t> held;
+            for (size_t i = 0; i < n_pairs; ++i) { const uint32_t w = unit_of[bc[i]]; if (w >= u && w < v) { want[i] = 1; held.push_back((uint32_t)i); } }
+            pass(want, held, u, v, false, false); ++passes;
+            u = v;
+        }
+        fprintf(stderr, "the reads do not fit the memory allowed: %zu more passes over the input\n", passes);
     }
-    std::vector<uint8_t> var_b, var_q;
-    std::vector<uint64_t> off_b{0}, off_q{0};
-    for (size_t k = 0; k < n_reads; ++k) {
-        var_b.insert(var_b.end(), pk[k].begin(), pk[k].end()); off_b.push_back(var_b.size());
-        var_q.insert(var_q.end(), pq[k].begin(), pq[k].end()); off_q.push_back(var_q.size());
-    }
+    const size_t n_reads = out_b.off.size() - 1;
     try {
-        const std::string head = a["OUT_HEAD"];
-        const size_t slash = head.rfind('/');
-        if (slash != std::string::npos) { std::string d = head.substr(0, slash); for (size_t i = 1; i <= d.size(); ++i) if (i == d.size() || d[i] == '/') mkdir(d.substr(0, i).c_str(), 0777); }
-        feudal::write_fastb(head + ".fastb", var_b.data(), off_b, lens);
-        feudal::write_qualp(head + ".qualp", var_q.data(), off_q);
+        out_b.finish(lens.data(), 4 * lens.size(), 4, 16, 1);
+        out_q.finish(nullptr, 0, 0, 8, 1);
         feudal::BinWriter w(head + ".bci"); w.vec(bci);
     } catch (const std::exception& e) { die(e.what()); }
-    fprintf(stderr, "wrote %zu reads, %zu barcodes\n", n_reads, bci.size() - 2);
+    g_partial.clear();
+    fprintf(stderr, "wrote %zu reads, %zu barcodes\n", n_reads, n_barcodes);
     return 0;
 }

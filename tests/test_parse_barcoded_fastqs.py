@@ -82,9 +82,30 @@ def test_output_feeds_the_df_front_end(tmp_path):
     same_files(f"{tmp_path}/tmp/GapToy/1/data/frag_reads_orig", f"{tmp_path}/tmp/reads")
 
 
+@pytest.mark.parametrize("mem_mb,extra", [(1.3, ("NUM_BUCKETS=8",)), (0.7, ("NUM_BUCKETS=16",)), (1.0, ("NUM_BUCKETS=9", "READS_PER_BC=400")),
+                                          (0.3, ("NUM_BUCKETS=64",))])            # (the last: the unbarcoded pairs alone take several pieces)
+def test_a_set_larger_than_max_mem_gb_is_done_in_groups_of_buckets(tmp_path, mem_mb, extra):
+    """The reads do not fit MAX_MEM_GB: the first pass keeps barcodes and lengths, the inputs are read again once per group of
+    consecutive buckets that fits (the unbarcoded pairs, which keep the file's order, in as many pieces as it takes) -- and the
+    three files come out as when everything is held at once (and as the reference's binary writes them)."""
+    fq1, fq2 = f"{tmp_path}/a_1.fq.gz", f"{tmp_path}/a_2.fq.gz"
+    make_fastq(fq1, fq2, 3000, 41, n_bc=40, ragged=True)
+    whole = run(OURS, fq1, fq2, f"{tmp_path}/whole/reads", "NUM_THREADS=3", *extra)
+    assert whole.returncode == 0 and "more passes" not in whole.stderr, whole.stderr
+    o = run(OURS, fq1, fq2, f"{tmp_path}/groups/reads", "NUM_THREADS=3", f"MAX_MEM_GB={mem_mb / 1024}", *extra)
+    assert o.returncode == 0, o.stderr
+    n_passes = int(o.stderr.split("allowed: ")[1].split()[0])
+    assert n_passes >= 3, o.stderr
+    same_files(f"{tmp_path}/groups/reads", f"{tmp_path}/whole/reads")
+    if os.path.exists(REF):
+        r = run(REF, fq1, fq2, f"{tmp_path}/ref/reads", "NUM_THREADS=1", *extra)
+        assert r.returncode == 0, r.stdout + r.stderr
+        same_files(f"{tmp_path}/groups/reads", f"{tmp_path}/ref/reads")
+
+
 def test_refuses_an_input_that_does_not_fit_max_mem_gb(tmp_path):
-    """The decompressed reads are held in memory (unlike the reference, which re-reads per bucket): a set that does not fit
-    MAX_MEM_GB ends with a message saying so, not with the OOM killer."""
+    """A SINGLE bucket whose reads do not fit MAX_MEM_GB ends the run with a message saying so (and no half-written files),
+    not with the OOM killer."""
     from tests.fastq_synth import make_fastq
     make_fastq(f"{tmp_path}/a_1.fq.gz", f"{tmp_path}/a_2.fq.gz", 3000, 5, n_bc=6)
     r = subprocess.run([OURS, "FASTQS={" + f"{tmp_path}/a_1.fq.gz,{tmp_path}/a_2.fq.gz" + "}", f"OUT_HEAD={tmp_path}/o", "NUM_BUCKETS=2", "MAX_MEM_GB=0.0005"],
