@@ -304,7 +304,9 @@ def df_stage_wall(args, dev, local):
                f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}",
                "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (GRAPH=True: rows f-1, f-2, f-4 -- edges + HBV + read paths + paths index + duplicate marks -> a.<K>/)
         if link: cmd.append("LINK_READS=True")
-        env = dict(os.environ, DFK_HOST_THREADS=os.environ.get("DFK_HOST_THREADS", str(min(args.df_threads, 16))))
+        # transfer lanes per copy: four (each keeps a DMA in flight and spins on it; three copies run side by side in the stage's last
+        # phase, and the box gives the command 16 CPUs -- measured at full size: 16 lanes 17.1 s, 8: 16.7, 6: 17.0, 4: 15.6-16.2)
+        env = dict(os.environ, DFK_HOST_THREADS=os.environ.get("DFK_HOST_THREADS", str(min(args.df_threads, 4))))
         if args.df_gpus > 1 or args.df_transport:
             # the C++ multi-GPU host (df_shard.h): DF forks one rank per GPU and moves the records over RCCL itself;
             # `loopback` runs the ranks as threads on ONE GPU (the rehearsal a one-GPU box allows)

@@ -24,6 +24,7 @@ def views(path, fixed):
     fd = os.open(path, os.O_RDONLY)
     size = os.fstat(fd).st_size
     m = mmap.mmap(fd, size, flags=mmap.MAP_SHARED, prot=mmap.PROT_READ)
+    if os.environ.get("UPL_SEQ"): m.madvise(mmap.MADV_SEQUENTIAL)
     whole = np.frombuffer(m, np.uint8)
     cnt, _, _, _, _, var_tab, fixed_off = struct.unpack("<IBBBBQQ", bytes(whole[:24]))
     off = whole[var_tab:var_tab + 8 * (n + 1)].view(np.uint64)
@@ -31,7 +32,7 @@ def views(path, fixed):
     return fd, m, whole, off, fx
 
 
-for mode in ("plain", "file", "drop", "plain"):
+for mode in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("plain", "file", "drop", "plain")):
     fb = views(head + ".fastb", True); qp = views(head + ".qualp", False)
     d = Dfk(K=48)
     if mode != "plain":
