@@ -111,8 +111,10 @@ int dfk_qual_hist(dfk_ctx* ctx, uint32_t max_len, int64_t* hist);
  *            may unmap the range while the call runs (the descriptor must stay open).  A failing read is DFK_E_INPUT,
  *            never a quiet fall back to the memory.  (Measured: 15 GB/s whatever the number of lanes.)
  *   fd = -1  the library reads the memory and DROPS what it has read from the caller's page table (MADV_DONTNEED: the file
- *            keeps the pages; a later access faults them in again) -- each transfer lane its own chunks.  The mapping must
- *            stay until the call returns.  (Measured: as fast as without the hint, 22-27 GB/s.)
+ *            keeps the pages; a later access faults them in again) -- each transfer lane its own chunks -- and marks the
+ *            mapping MADV_SEQUENTIAL, without which every page that leaves a page table is marked accessed under one lock
+ *            (a freshly written tmpfs file: 25 against 130 GB/s for its first reading).  The mapping must stay until the
+ *            call returns.  (Measured: 40-50 GB/s.)
  * base = NULL forgets all hints; at most 8 are kept; dfk_destroy forgets them.  Replaces nothing in the reference (LoadData
  * reads its files through read(2) into vectors, feudal/FeudalFileReader.cc). */
 int dfk_hint_file_range(dfk_ctx* ctx, const void* base, uint64_t bytes, int fd, uint64_t file_off);

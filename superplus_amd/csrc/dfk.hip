@@ -1953,6 +1953,13 @@ int dfk_hint_file_range(dfk_ctx* c, const void* base, uint64_t bytes, int fd, ui
     if (!bytes) return fail(DFK_E_ARG, "a hinted range needs a length");
     if (c->file_ranges.size() >= 8) return fail(DFK_E_ARG, "8 hinted ranges are kept at most");
     c->file_ranges.push_back(dfk_ctx::FileRange{(const char*)base, bytes, fd, file_off});
+    if (fd < 0) {
+        // VM_SEQ_READ on the caller's mapping: pages that leave the page table (the MADV_DONTNEED behind every copy, the caller's
+        // munmap) are then not marked accessed one by one -- on a freshly written tmpfs file that is 25 against 130 GB/s for the
+        // reading and seconds for the unmapping (tools/fs_read_after_write.cc)
+        const uintptr_t page = 4096, lo = (uintptr_t)base & ~(page - 1), hi = ((uintptr_t)base + bytes + page - 1) & ~(page - 1);
+        (void)madvise((void*)lo, hi - lo, MADV_SEQUENTIAL);
+    }
     return 0;
 }
 
