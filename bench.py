@@ -299,7 +299,14 @@ def df_stage_wall(args, dev, local):
         t_files = time.perf_counter() - t0
         in_bytes = sum(os.path.getsize(root + "/reads" + e) for e in (".fastb", ".qualp", ".bci"))
         del rs
+        held = torch.cuda.memory_reserved(local)
         torch.cuda.synchronize(); torch.cuda.empty_cache()
+        # The device memory this process has just given back (the read generator's, ~230 GB) is wiped by the driver before
+        # anybody gets it again, at about 33 GB/s (tools/vram_alloc_cost.hip: a 180-GiB hipMalloc right behind the release of
+        # one takes 5.4 s): started at once, the stage's own allocations would wait for the harness's leftovers -- its count
+        # ended 7.7 s after the start whenever its upload did.  A pipeline's DF starts on a quiet device; so does this one.
+        quiesce = float(os.environ.get("BENCH_QUIESCE_S", min(15.0, held / 25e9)))
+        time.sleep(quiesce)
         cmd = [os.path.join(ROOT, "superplus_amd", "DF"), f"ROOT={root}", f"LR={root}/reads.fastb", "PIPELINE=cs", "ALIGN=False",
                f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}",
                "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (GRAPH=True: rows f-1, f-2, f-4 -- edges + HBV + read paths + paths index + duplicate marks -> a.<K>/)
@@ -343,10 +350,11 @@ def df_stage_wall(args, dev, local):
                               "(10X/DF.cc:541-561: graph, read paths, paths index, duplicate marks)" if args.df_graph else ", kmers.kvec") +
                               " -- ingest + StageBuildGraph, not the other seven DF stages",
                 "frag_reads_orig": "hard links to the inputs (LINK_READS=True: byte-identical files, no second copy in RAM)" if link else "copies of the inputs",
+                "device_quiesce_s": round(quiesce, 1),   # waited before the stage started: the driver wiping what THIS process had released
                 "host_memory": dict(mem, estimated_need=int(2 * pairs * (per_read_link if link else per_read_copy))),
                 "kmers_per_s_whole_stage": (timing.get("kmer_instances", 0) / wall) if wall > 0 else None,
                 "breakdown_s": {k: timing.get(k) for k in ("spawn_to_main_s", "open_validate_s", "ingest_outputs_s", "upload_s", "count_s",
-                                                           "spectrum_kvec_write_s", "total_s", "exit_to_reaped_s")},
+                                                           "spectrum_kvec_write_s", "qual_hist_s", "destroy_s", "background_join_s", "total_s", "exit_to_reaped_s")},
                 "graph": ({"graph_s": timing.get("graph_s"), "device_s": timing.get("graph_device_s"), "host_s": timing.get("graph_host_s"),
                            "write_s": timing.get("graph_write_s"), "edges": timing.get("graph_edges"), "vertices": timing.get("graph_vertices")}
                           if args.df_graph else None),

@@ -684,7 +684,7 @@ int main(int argc, char** argv)
         // ---- barcode expansion (DF.cc:447-452) and createDict on the GPU.  With the inputs mapped in place (fast path) the upload
         //      and the count start NOW, in a thread of their own, while this one computes the side files below; otherwise
         //      they run where the reference has them.
-        std::vector<int32_t> bc;
+        std::unique_ptr<int32_t[]> bc;                                          // (not a vector: 7 GB need not be zeroed by one thread first)
         dfk_config cfg{};
         cfg.abi_version = DFK_ABI_VERSION; cfg.K = K; cfg.min_qual = (uint32_t)atoi(a["MIN_QUAL"].c_str());
         cfg.min_freq = (uint32_t)atoi(a["MIN_FREQ"].c_str()); cfg.min_bc = (uint32_t)atoi(a["MIN_BC"].c_str());
@@ -703,26 +703,32 @@ int main(int argc, char** argv)
         // count, once this thread has been through the read lengths; counted here when the device keeps nothing
         const bool device_hist = fast && !sharded && !truthy(a["EXIT_LOAD"]) && want_paths && !getenv("DF_HOST_QHIST");
         std::atomic<int> max_len_known{-1};
-        std::vector<int64_t> qh_dev; std::string qh_err;
+        std::vector<int64_t> qh_dev; std::string qh_err; double t_qhist = 0;
         auto count_job = [&] {
-            bc.assign(n_reads, 0);
+            const double tj0 = now_s();
+            bc.reset(new int32_t[std::max<uint64_t>(1, n_reads)]);
+            parallel_ranges(n_reads, [&](unsigned, uint64_t lo, uint64_t hi) { memset(bc.get() + lo, 0, 4 * (hi - lo)); });      // (reads no barcode's range holds: 0)
             parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t lo, uint64_t hi) {
                 for (uint64_t b = lo; b < hi; ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
             }, 1024);
+            const double tj1 = now_s();
             if (dfk_create(&cfg, &ctx)) { create_failed = true; count_err = dfk_last_error(); return; }
+            if (getenv("DFK_TRACE")) fprintf(stderr, "[DF] barcodes expanded in %.3f s, dfk_create %.3f s, %.3f s after the process started\n", tj1 - tj0, now_s() - tj1, now_s() - t_start);
             if (fast)                                                           // the arrays are maps of these files: what has been uploaded leaves the page table (see below)
                 for (const Mapped* m : {&ins[0].fb.m, &ins[0].qp.m})
                     if (m->p && dfk_hint_file_range(ctx, m->p, m->n, -1, 0)) { create_failed = true; count_err = dfk_last_error(); return; }
             printf("%s: building dictionary on the GPU\n", date().c_str());
             const double tc = now_s();
-            count_rc = dfk_count(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bc.data(), n_reads);
+            count_rc = dfk_count(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bc.get(), n_reads);
             if (count_rc) count_err = dfk_last_error();
             t_count = now_s() - tc;
             if (!count_rc && device_hist) {
                 while (max_len_known.load() < 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));
                 const int ml = max_len_known.load();
                 qh_dev.assign((size_t)2 * ml * 256, 0);
+                const double tq = now_s();
                 if (ml && dfk_qual_hist(ctx, (uint32_t)ml, qh_dev.data())) qh_err = dfk_last_error();
+                t_qhist = now_s() - tq;
             }
         };
         std::thread count_thread;
@@ -805,7 +811,7 @@ int main(int argc, char** argv)
         if (rc) { fprintf(stderr, "DF: %s\n", count_err.c_str()); join_background(); return rc == DFK_E_NOMEM ? 185 : 1; }        // Martian::exit code
         dfk_stats st{}; dfk_get_stats(ctx, &st);
         T.upload = 1e-3 * st.ms_upload; T.count = t_count - T.upload;
-        { std::vector<int32_t>().swap(bc); }
+        bc.reset();
         if (fast) {
             // The mapped inputs are on the device (and stay there for the pathing), and the transfer lanes have dropped what they
             // copied from the page table (the hint above): unmapping them is cheap now, where it would have been three seconds
@@ -874,8 +880,11 @@ int main(int argc, char** argv)
             }
             t_g_write = tw_graph;
         }
+        const double t_d0 = now_s();
         dfk_destroy(ctx);
+        const double t_destroy = now_s() - t_d0;
         join_background();
+        const double t_joined = now_s() - t_d0 - t_destroy;
         T.total = now_s() - t_start;
         printf("%s: dictionary covers %llu kmers\n", date().c_str(), (unsigned long long)nk);
         printf("%s: %llu k-mer instances, GPU %.1f ms (count kernel %.1f ms), ingest+count stage %.2f s wall\n", date().c_str(),
@@ -883,10 +892,10 @@ int main(int argc, char** argv)
         // one machine-readable line (bench.py reads it): where the stage's wall time went
         printf("DF_TIMING {\"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"threads\": %u, \"open_validate_s\": %.3f, "
                "\"ingest_outputs_s\": %.3f, \"upload_s\": %.3f, \"count_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, \"graph_s\": %.3f, \"graph_device_s\": %.3f, \"graph_host_s\": %.3f, \"graph_write_s\": %.3f, "
-               "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"paths_s\": %.3f, \"paths_device_s\": %.3f, \"paths_write_s\": %.3f, \"reads_placed\": %llu, \"path_edges\": %llu, \"paths_index_s\": %.3f, \"mark_dups_s\": %.3f, \"dup_pairs\": %llu, \"total_s\": %.3f, \"fast_path\": %s}\n",
+               "\"graph_edges\": %llu, \"graph_vertices\": %llu, \"paths_s\": %.3f, \"paths_device_s\": %.3f, \"paths_write_s\": %.3f, \"reads_placed\": %llu, \"path_edges\": %llu, \"paths_index_s\": %.3f, \"mark_dups_s\": %.3f, \"dup_pairs\": %llu, \"qual_hist_s\": %.3f, \"destroy_s\": %.3f, \"background_join_s\": %.3f, \"total_s\": %.3f, \"fast_path\": %s}\n",
                (unsigned long long)n_reads, (unsigned long long)st.n_inst, (unsigned long long)nk, g_threads, T.read, T.ingest_out,
                T.upload, T.count, T.fetch_write, t_graph, t_g_dev, t_g_host, t_g_write, (unsigned long long)g_e, (unsigned long long)g_v,
-               t_paths, t_p_dev, t_p_write, (unsigned long long)p_placed, (unsigned long long)p_edges, t_index, t_dups, (unsigned long long)n_dup, T.total, fast ? "true" : "false");
+               t_paths, t_p_dev, t_p_write, (unsigned long long)p_placed, (unsigned long long)p_edges, t_index, t_dups, (unsigned long long)n_dup, t_qhist, t_destroy, t_joined, T.total, fast ? "true" : "false");
         { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); printf("DF_EXIT_EPOCH %.3f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());
