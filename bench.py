@@ -80,6 +80,11 @@ def cpu_baseline_and_parity(rs, K, device, what):
                read_len=read_len.cpu().numpy().astype(np.uint32), pq_bytes=pq_bytes.cpu().numpy(),
                pq_off=pq_off.cpu().numpy().astype(np.uint64), bc=bc.cpu().numpy().astype(np.int32))
     cores = os.cpu_count() or 1
+    try:                                             # (a cgroup's CPU quota is what the threads really get: 16 of the box's 256 here)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max": cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
     refdrv = os.path.join(ROOT, "oracle", "_ref", "refdrv")
     base, cpu_solid, cpu_hist, ref_files = None, None, None, None
     if os.path.exists(refdrv):
