@@ -249,8 +249,50 @@ int dfk_paths_fetch(dfk_ctx* ctx, int32_t* offsets, uint64_t* first_edge, int32_
  * dfk_dups_write         MarkDups (10X/SecretOps.cc:410-566): a.dup, one byte per PAIR -- reads with the same first edge, offset
  *                        and first five bases of their mate are duplicates; the one whose pair has the highest quality sum (the
  *                        lowest read id among equals) stays.  Grouped in a hash table on the device instead of sorted. */
+/* Limits, refused loudly (DFK_E_ARG) rather than wrapped: fewer than 2^32 path entries over all reads (the index sorts pairs of
+ * 32-bit words; the reference's PathsIndex.cc is 64-bit throughout), fewer than 2^29 HBV edges and offsets within +-2^24 (the
+ * duplicate key).  dir / path NULL: everything but the files (dfk_paths_digest). */
 int dfk_paths_index_write(dfk_ctx* ctx, const char* dir);
 int dfk_dups_write(dfk_ctx* ctx, const char* path, uint64_t* n_marked_pairs);
+
+/* ---- rows f-1 / f-2 / f-4 checked where no oracle runs (tests/test_gpu_fullsize_graph.py; DF prints the digests) ----
+ * Replaces nothing in the reference (its nearest thing is hbv.CheckSum() / Validate(hbv, paths), 10X/DF.cc:597-598).
+ * dfk_paths_digest  fills out[DFK_CHECK_WORDS] with digests that depend on the CONTENT of a.paths, a.paths.inv, a.countsb and
+ *                   a.dup only -- not on the batches the reads were pathed in, the passes the dictionary was counted in or the
+ *                   entry numbering the k-mer index holds -- and with the graph's identities:
+ *   DFK_CK_PATHS_SUM/XOR    over reads r of h(r, offset, lastSkip, edge ids...), the element as a.paths holds it (after dfk_paths_build)
+ *   DFK_CK_N_READS / N_PLACED / N_PATH_EDGES
+ *   DFK_CK_INV_SUM/XOR      over positions i of a.paths.inv's data of h(i, read id); DFK_CK_INV_STARTS over edges e of h(e, first
+ *                           position of e's list); DFK_CK_INV_ENTRIES = the lists' total length     (after dfk_paths_index_write)
+ *   DFK_CK_COUNTSB_DIGEST   over edges of h(e, a.countsb[e]); DFK_CK_COUNTSB_SUM their plain sum; DFK_CK_SELF_INVERSE = entries on
+ *                           edges that are their own involution: COUNTSB_SUM = 2 * INV_ENTRIES - SELF_INVERSE
+ *   DFK_CK_DUP_DIGEST       over pairs p of h(p, a.dup[p]); DFK_CK_DUP_MARKED the number marked               (after dfk_dups_write)
+ *   DFK_CK_EDGE_KMERS       sum of the canonical edges' k-mers (= DFK_CK_N_SOLID: every solid k-mer lies on exactly one edge);
+ *   DFK_CK_INV_VIOLATIONS   HBV edges e with inv(inv(e)) != e or inv(e) out of range; DFK_CK_N_EDGES
+ *   DFK_CK_VALID            DFK_CK_HAS_* bits: which of the three groups are filled
+ *   dfk_paths_index_write(ctx, NULL) / dfk_dups_write(ctx, NULL, &n) do everything but write the files.
+ * dfk_paths_verify  a second look at every placed read by a kernel that shares no code with the pather (k_path_verify,
+ *                   csrc/dfk_check_kernels.h): out[8] = reads placed; paths with an edge id out of range, two consecutive edges
+ *                   that do not meet at a vertex (pathPartsToReadPath cuts there, BuildReadQGraph48.cc:1365-1402) or an offset
+ *                   behind the first edge; k-mers of placed reads found in the dictionary at a position the path covers; those
+ *                   whose (edge, position) is what the path implies there; placed reads with NO such k-mer (the seed a path was
+ *                   built from always is one); placed reads all of whose hits agree; dictionary entries whose edge bases are not
+ *                   the k-mer; hits at positions outside the path.  [1], [4], [6] must be 0.  Before dfk_paths_index_write /
+ *                   dfk_dups_write (they give the k-mer index back).  The reads are those given to dfk_paths_build*. */
+#define DFK_CHECK_WORDS 20
+enum { DFK_CK_PATHS_SUM = 0, DFK_CK_PATHS_XOR = 1, DFK_CK_N_READS = 2, DFK_CK_N_PLACED = 3, DFK_CK_N_PATH_EDGES = 4,
+       DFK_CK_INV_SUM = 5, DFK_CK_INV_XOR = 6, DFK_CK_INV_STARTS = 7, DFK_CK_INV_ENTRIES = 8,
+       DFK_CK_COUNTSB_DIGEST = 9, DFK_CK_COUNTSB_SUM = 10, DFK_CK_SELF_INVERSE = 11,
+       DFK_CK_DUP_DIGEST = 12, DFK_CK_DUP_MARKED = 13,
+       DFK_CK_EDGE_KMERS = 14, DFK_CK_N_SOLID = 15, DFK_CK_INV_VIOLATIONS = 16, DFK_CK_N_EDGES = 17, DFK_CK_VALID = 18 };
+#define DFK_CK_HAS_PATHS 1u
+#define DFK_CK_HAS_INDEX 2u
+#define DFK_CK_HAS_DUPS  4u
+int dfk_paths_digest(dfk_ctx* ctx, uint64_t* out /* [DFK_CHECK_WORDS] */);
+int dfk_paths_verify(dfk_ctx* ctx, const uint8_t* packed_bases, const uint64_t* base_off, const uint32_t* read_len, uint64_t n_reads,
+              uint64_t* out /* [8] */);
+int dfk_paths_verify_device(dfk_ctx* ctx, const void* d_packed_bases, uint64_t packed_bytes, const void* d_base_off, const void* d_read_len,
+              uint64_t n_reads, uint64_t* out /* [8] */);
 
 /* ---- multi-GPU pieces (one process per GPU; the caller owns the RCCL exchange) ----
  * The reference's only exchange is MapReduceEngine's thread all-to-all ("swizzle",

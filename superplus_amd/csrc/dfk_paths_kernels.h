@@ -467,8 +467,8 @@ __global__ void __launch_bounds__(256)
 k_path_slots(const uint32_t* __restrict__ read_len, uint64_t r0, uint64_t nb, uint32_t K, uint32_t cap, uint64_t* __restrict__ slots)
 {
     // low half: the parts (and path edges) a read gets room for -- one per k-mer position covers every case, `cap` nearly every
-    // read at a fraction of the room; high half: its bases (the decoded qualities).  One scan gives both offsets: a batch holds
-    // at most 2^24 reads of at most 255 bases.
+    // read at a fraction of the room; high half: its bases (the decoded qualities).  One scan gives both offsets: the host
+    // sizes a batch from the longest read so that neither sum reaches 2^32 (paths_build_typed, nb_bound).
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
         const uint32_t L = read_len[r0 + i], s = L >= K ? L - K + 1 : 1;
         slots[i] = (uint64_t)(s < cap ? s : cap) | ((uint64_t)((L + 3u) & ~3u) << 32);

@@ -27,7 +27,15 @@ EXPORTS = [
     "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
     "dfk_shard_dict_share", "dfk_shard_dict_adopt", "dfk_shard_dict_whole",
     "dfk_paths_build", "dfk_paths_build_device", "dfk_paths_stats", "dfk_paths_write", "dfk_paths_fetch", "dfk_paths_index_write", "dfk_dups_write",
+    "dfk_paths_digest", "dfk_paths_verify", "dfk_paths_verify_device",
 ]
+
+# dfk_paths_digest's words (include/dfk.h, DFK_CK_*) and dfk_paths_verify's counters
+CHECK_WORDS = 20
+CK = ["PATHS_SUM", "PATHS_XOR", "N_READS", "N_PLACED", "N_PATH_EDGES", "INV_SUM", "INV_XOR", "INV_STARTS", "INV_ENTRIES",
+      "COUNTSB_DIGEST", "COUNTSB_SUM", "SELF_INVERSE", "DUP_DIGEST", "DUP_MARKED", "EDGE_KMERS", "N_SOLID", "INV_VIOLATIONS",
+      "N_EDGES", "VALID"]
+VERIFY = ["placed", "broken", "hits", "consistent", "no_anchor", "all_consistent", "dict_bad", "outside"]
 
 
 class DfkError(RuntimeError):
@@ -238,14 +246,34 @@ class Dfk:
         _check(lib().dfk_paths_write(self._ctx, path.encode()))
 
     def paths_index_write(self, directory):
-        """a.paths.inv and a.countsb (writePathsIndex) into `directory`."""
-        _check(lib().dfk_paths_index_write(self._ctx, directory.encode()))
+        """a.paths.inv and a.countsb (writePathsIndex) into `directory`; None = everything but the files (paths_digest)."""
+        _check(lib().dfk_paths_index_write(self._ctx, None if directory is None else directory.encode()))
 
     def dups_write(self, path):
-        """a.dup (MarkDups); returns the number of pairs marked."""
+        """a.dup (MarkDups); returns the number of pairs marked.  None = no file."""
         n = C.c_uint64()
-        _check(lib().dfk_dups_write(self._ctx, path.encode(), C.byref(n)))
+        _check(lib().dfk_dups_write(self._ctx, None if path is None else path.encode(), C.byref(n)))
         return n.value
+
+    def paths_digest(self):
+        """dfk_paths_digest: {name: word} -- content digests of a.paths / a.paths.inv / a.countsb / a.dup and the graph's identities."""
+        out = (C.c_uint64 * CHECK_WORDS)()
+        _check(lib().dfk_paths_digest(self._ctx, out))
+        return {k: int(out[i]) for i, k in enumerate(CK)}
+
+    def paths_verify(self, packed, base_off, read_len):
+        """dfk_paths_verify on numpy host arrays (the reads that were pathed): {counter: value}."""
+        packed = np.ascontiguousarray(packed, np.uint8); base_off = np.ascontiguousarray(base_off, np.uint64)
+        read_len = np.ascontiguousarray(read_len, np.uint32)
+        out = (C.c_uint64 * 8)()
+        _check(lib().dfk_paths_verify(self._ctx, _p(packed), _p(base_off), _p(read_len), C.c_uint64(len(read_len)), out))
+        return {k: int(out[i]) for i, k in enumerate(VERIFY)}
+
+    def paths_verify_device(self, packed, base_off, read_len):
+        out = (C.c_uint64 * 8)()
+        _check(lib().dfk_paths_verify_device(self._ctx, C.c_void_p(packed.data_ptr()), C.c_uint64(packed.numel()), C.c_void_p(base_off.data_ptr()),
+                                             C.c_void_p(read_len.data_ptr()), C.c_uint64(read_len.numel()), out))
+        return {k: int(out[i]) for i, k in enumerate(VERIFY)}
 
     def paths(self):
         """-> (offsets i32[n], first_edge u64[n+1], edges i32[...])"""

@@ -1,0 +1,78 @@
+"""Rows f-1 / f-2 / f-4 at a size the bench runs them at and no oracle reaches: a 2.3 Gb genome at 30x -- 6.9e8 reads pathed over
+a dictionary of 2.3e9 k-mers, so that the k-mer index has more than 2^32 slots, entry ids run past 2^31 and the paths index sorts
+~7e8 pairs.  What is checked:
+
+  (a) geometry invariance: the content digests of a.paths, a.paths.inv, a.countsb and a.dup (dfk_paths_digest) are identical for
+      the default run, for two slots a read without the k-mer filter (every batch pathed twice, every miss through the index)
+      and for twice the count passes (another part layout, so other entry ids in every index slot and every link);
+  (b) an independent look at every placed read (dfk_paths_verify, a kernel that shares no code with the pather): no path whose
+      consecutive edges do not meet, no offset behind its first edge, no placed read without a k-mer where its path says, no
+      dictionary entry whose edge bases are not its k-mer -- and the same eight counters from all three runs;
+  (c) identities: every solid k-mer on exactly one edge, the involution its own inverse, the index lists as long as the paths,
+      a.countsb summing to twice that minus the self-inverse edges' share, no more duplicate marks than pairs placed.
+
+The digests and the verifier are pinned on the reference-written fixtures by tests/test_gpu_verify.py."""
+import os
+
+import pytest
+import torch
+
+from superplus_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+G, K = 2_300_000_000, 48
+PAIRS = 30 * G // 200
+
+
+def _run(shard, passes=0):
+    from superplus_amd.dfk import Dfk
+    packed, base_off, read_len, pq_bytes, pq_off, bc = shard
+    d = Dfk(K=K, device=0, passes=passes)
+    d.count_device(*shard)
+    st = d.stats()
+    g = d.graph_build()
+    p = d.paths_build_device(packed, base_off, read_len, pq_bytes, pq_off)
+    v = d.paths_verify_device(packed, base_off, read_len)
+    d.paths_index_write(None)
+    d.dups_write(None)
+    ck = d.paths_digest()
+    d.close()
+    torch.cuda.empty_cache()
+    return dict(passes=st["n_passes"], n_solid=st["n_solid"], graph=g, paths=p, verify=v, ck=ck)
+
+
+def test_graph_paths_index_dups_at_bench_size(monkeypatch):
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 240e9:
+        pytest.skip("needs a whole MI355X (%.0f GB free)" % (free / 1e9))
+    genome = synth.make_genome(G, 20261104, device=dev)
+    rs = synth.make_reads(genome, PAIRS, 20261121)
+    del genome
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    shard = (rs.packed, rs.base_off, rs.read_len, rs.pq_bytes, rs.pq_off, rs.bc)
+
+    a = _run(shard)
+    ck, v = a["ck"], a["verify"]
+    assert 2 * a["n_solid"] > 1 << 32                                      # the k-mer index (load 1/2) has more than 2^32 slots
+    assert a["n_solid"] > 1 << 31                                          # ... and entry ids pass 2^31
+    # (c) identities
+    assert ck["EDGE_KMERS"] == ck["N_SOLID"] == a["n_solid"] and ck["INV_VIOLATIONS"] == 0 and ck["N_EDGES"] == a["graph"]["n_edges"]
+    assert ck["VALID"] == 7 and ck["N_READS"] == 2 * PAIRS and ck["N_PLACED"] == a["paths"]["n_placed"]
+    assert ck["INV_ENTRIES"] == ck["N_PATH_EDGES"] == a["paths"]["n_path_edges"]
+    assert ck["COUNTSB_SUM"] == 2 * ck["INV_ENTRIES"] - ck["SELF_INVERSE"]
+    assert ck["DUP_MARKED"] <= ck["N_PLACED"] // 2 + 1
+    assert ck["N_PLACED"] > 0.9 * ck["N_READS"]
+    # (b) the independent verifier
+    assert v["placed"] == ck["N_PLACED"]
+    assert v["broken"] == 0 and v["no_anchor"] == 0 and v["dict_bad"] == 0, v
+    assert v["consistent"] > 0.99 * v["hits"] and v["hits"] > 30 * v["placed"], v
+    # (a) geometry invariance
+    monkeypatch.setenv("DFK_PATH_SLOTS", "2"); monkeypatch.setenv("DFK_NO_FILTER", "1")
+    b = _run(shard)
+    monkeypatch.delenv("DFK_PATH_SLOTS"); monkeypatch.delenv("DFK_NO_FILTER")
+    assert b["ck"] == ck and b["verify"] == v, "two slots a read, no filter"
+    c = _run(shard, passes=2 * a["passes"])
+    assert c["passes"] == 2 * a["passes"]
+    assert c["ck"] == ck and c["verify"] == v, "twice the count passes"
