@@ -41,6 +41,7 @@
 #include <sstream>
 #include <string>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <signal.h>
 #include <sys/wait.h>
@@ -316,6 +317,23 @@ void bind_to_gpu_node(int device)
     if (n_cpus && sched_setaffinity(0, sizeof set, &set) == 0 && getenv("DFK_TRACE")) fprintf(stderr, "[DF] bound to NUMA node %d (%d CPUs) of device %d\n", node, n_cpus, device);
 }
 
+// One machine-readable line with the content digests of a.paths / a.paths.inv / a.countsb / a.dup and the graph's identities
+// (dfk_paths_digest): what two runs of a stage this size are compared by (the reference prints hbv.CheckSum() for the same
+// purpose, 10X/DF.cc:598).
+void print_digests(dfk_ctx* ctx)
+{
+    uint64_t w[DFK_CHECK_WORDS] = {};
+    if (dfk_paths_digest(ctx, w)) return;
+    printf("DF_DIGESTS {\"a.paths\": \"%016llx%016llx\", \"a.paths.inv\": \"%016llx%016llx%016llx\", \"a.countsb\": \"%016llx\", \"a.dup\": \"%016llx\", "
+           "\"reads\": %llu, \"placed\": %llu, \"path_edges\": %llu, \"index_entries\": %llu, \"countsb_sum\": %llu, \"self_inverse_entries\": %llu, \"dup_pairs\": %llu, "
+           "\"edge_kmers\": %llu, \"solid\": %llu, \"involution_violations\": %llu, \"hbv_edges\": %llu}\n",
+           (unsigned long long)w[DFK_CK_PATHS_SUM], (unsigned long long)w[DFK_CK_PATHS_XOR], (unsigned long long)w[DFK_CK_INV_SUM], (unsigned long long)w[DFK_CK_INV_XOR],
+           (unsigned long long)w[DFK_CK_INV_STARTS], (unsigned long long)w[DFK_CK_COUNTSB_DIGEST], (unsigned long long)w[DFK_CK_DUP_DIGEST],
+           (unsigned long long)w[DFK_CK_N_READS], (unsigned long long)w[DFK_CK_N_PLACED], (unsigned long long)w[DFK_CK_N_PATH_EDGES], (unsigned long long)w[DFK_CK_INV_ENTRIES],
+           (unsigned long long)w[DFK_CK_COUNTSB_SUM], (unsigned long long)w[DFK_CK_SELF_INVERSE], (unsigned long long)w[DFK_CK_DUP_MARKED],
+           (unsigned long long)w[DFK_CK_EDGE_KMERS], (unsigned long long)w[DFK_CK_N_SOLID], (unsigned long long)w[DFK_CK_INV_VIOLATIONS], (unsigned long long)w[DFK_CK_N_EDGES]);
+}
+
 int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::string& work_dir, const std::string& head, int rank, int world,
               dfkx::LoopbackHub* hub)
 {
@@ -411,6 +429,7 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
                     if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());
                     dfk_paths_stats(ctx, nullptr, &p_placed, nullptr);
                     if (dfk_paths_index_write(ctx, dir.c_str()) || dfk_dups_write(ctx, (dir + "/a.dup").c_str(), nullptr)) throw std::runtime_error(dfk_last_error());
+                    print_digests(ctx);
                     t_paths = now_s() - t0;
                 }
             }
@@ -539,10 +558,16 @@ int main(int argc, char** argv)
         for (double f : select_frac) if (f < 1.0) give_up("NUM_GPUS > 1 needs LR_SELECT_FRAC = 1 (the ranks count the input as it is)");
         if (!loopback) {
             unlink((work_dir + "/.dfk_rccl_id").c_str());
+            const pid_t parent_pid = getpid();
             for (int r = 0; r < num_gpus; ++r) {
                 const pid_t pid = fork();
                 if (pid < 0) { watch.kill_all(); give_up("cannot fork"); }
                 if (pid == 0) {
+                    // A rank must not outlive this process: ChildWatch covers a rank that dies, this covers the parent being
+                    // killed outright (a harness timeout, the OOM killer) while the ranks sit in a collective that has no
+                    // timeout and hold their GPUs.  Set before the exec (it survives it) and before any GPU call.
+                    prctl(PR_SET_PDEATHSIG, SIGKILL);
+                    if (getppid() != parent_pid) _exit(1);                   // (the parent went away between the fork and the prctl)
                     setenv("DF_RANK", std::to_string(r).c_str(), 1); setenv("DF_WORLD", std::to_string(num_gpus).c_str(), 1);
                     execv("/proc/self/exe", argv);
                     _exit(127);
@@ -877,6 +902,7 @@ int main(int argc, char** argv)
                 t_p_write = tw_paths;
                 t_paths = now_s() - t0;
                 printf("%.2f%% of pairs appear to be duplicates\n", n_reads ? 100.0 * (double)n_dup / (double)(n_reads / 2) : 0.0);
+                print_digests(ctx);
             }
             t_g_write = tw_graph;
         }

@@ -1094,6 +1094,124 @@ __device__ __forceinline__ uint32_t wave_count_chunk(const uint4* __restrict__ r
     return end_u - first_u;
 }
 
+// ---- two consecutive k-mers of a record per lane (k_count's main path; -DDFK_NO_PAIRS restores one k-mer per lane)
+// Rebuilding a k-mer from the 2-bit stream is two fifths of the insert path's vector instructions (fetch ~12, extraction
+// ~99 of ~267 per 64 instances), and nearly half of THAT is the 128-bit group reversal that turns the stream into KMer's
+// big-endian order.  The k-mer that follows in the same record needs none of it: its forward value is the predecessor's
+// shifted by one base with the next base appended -- KMer::toSuccessor, kmers/KMer.h:189-201, which is how the reference's own
+// Kmerizer::map walks a read (BuildReadQGraph48.cc:148-165) -- and its reverse complement is the next window of the
+// complemented stream.  So a lane takes instances (2j, 2j+1) of a record: one fetch, one full extraction, one rolled one,
+// two inserts.  A record of nk k-mers takes ceil(nk/2) lane slots; with nk odd the last slot's second half is idle (one
+// insert slot in 2 nk: 2 % at the 12.8 k-mers a record holds on average).
+struct PairRegs { uint32_t hdr, tag, q; u128 X, F; };
+
+// Stage records as wave_stage_piece does, indexing PAIR SLOTS instead of instances: returns the number of slots staged.
+template <int K>
+__device__ __forceinline__ uint32_t wave_stage_pairs(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
+                                                     WaveStage<K>* __restrict__ st, int lane)
+{
+    static_assert(COUNT_CHUNK == 32, "one uint4 per lane");
+    const uint64_t hidx = 2 * rb + lane;
+    uint4 v{0, 0, 0, 0};
+    if (hidx < 2 * re) v = records[hidx];
+    reinterpret_cast<uint4*>(st->rec)[lane] = v;
+    st->msk[lane] = 0;
+    wave_sync();
+    const uint32_t nk = lane < COUNT_CHUNK ? (st->rec[8 * lane] & 63u) : 0u;
+    const uint32_t np = (nk + 1u) >> 1;
+    const uint32_t incl = wave_incl_scan(np, lane);
+    const uint32_t start = incl - np;
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (lane < COUNT_CHUNK) st->starts[lane] = start;
+    if (np) atomicOr(&st->msk[start >> 5], 1u << (start & 31u));
+    wave_sync();
+    const uint32_t c0 = __popc(tld(&st->msk[lane]));
+    st->pc[lane] = wave_incl_scan(c0, lane) - c0;
+    wave_sync();
+    return total;
+}
+
+// first k-mer of pair slot t: the full extraction (as make_probe), keeping the window and the forward value for the second
+template <int K>
+__device__ __forceinline__ Probe pair_first(const WaveStage<K>* __restrict__ st, uint32_t t, uint32_t S, bool active, PairRegs* keep)
+{
+    const uint32_t w = t >> 5;
+    const uint32_t bits = tld(&st->msk[w]) & (0xFFFFFFFFu >> (31u - (t & 31u)));
+    const uint32_t r = st->pc[w] + __popc(bits) - 1u;
+    const uint32_t q = 2u * (t - st->starts[r]);
+    const uint32_t* rec = st->rec + 8 * r;
+    const uint32_t* p = rec + 2 + (q >> 4);
+    const uint32_t hdr = rec[0], p0 = p[0], p1 = p[1], p2 = p[2], p3 = p[3], p4 = p[4];
+    const uint32_t nk = hdr & 63u;
+    // bits [2q, 2q + 128) of the payload: pred, K bases, succ, and the base after it (K + 3 bases: 2K + 6 <= 126 bits)
+    const uint32_t sh = (2u * q) & 31u;
+    const uint32_t x0 = alignbit(p1, p0, sh), x1 = alignbit(p2, p1, sh), x2 = alignbit(p3, p2, sh), x3 = alignbit(p4, p3, sh);
+    const u128 X{(uint64_t)x0 | ((uint64_t)x1 << 32), (uint64_t)x2 | ((uint64_t)x3 << 32)};
+    const uint32_t pred = x0 & 3u;
+    const u128 ks = shr128(X, 2);
+    constexpr int SB = 2 * K + 2;
+    const uint32_t succ = (uint32_t)(SB >= 64 ? (X.hi >> (SB - 64)) : (X.lo >> SB)) & 3u;
+    const u128 m = KTraits<K>::mask();
+    const u128 R{~ks.lo & m.lo, ~ks.hi & m.hi};
+    const u128 rv{rev2_64(ks.hi), rev2_64(ks.lo)};
+    const u128 F = shr128(rv, 128 - KTraits<K>::BITS);                  // (the masked-off bases above the k-mer fall out at the bottom)
+    const bool rev = lt128(R, F);
+    uint32_t ctx = 0;
+    if (q > 0 || (hdr & 64u)) ctx |= 0x10u << pred;
+    if (q + 1 < nk || (hdr & 128u)) ctx |= 1u << succ;
+    if (rev) ctx = ctx_rc(ctx);
+    *keep = PairRegs{hdr, rec[1], q, X, F};
+    return probe_begin(rev ? R : F, ctx, (int32_t)rec[1], S, active);
+}
+
+// second k-mer of the slot: KMer::toSuccessor on the forward value, the next window of the complemented stream
+template <int K>
+__device__ __forceinline__ Probe pair_second(const PairRegs& k, uint32_t S, bool active)
+{
+    const uint32_t nk = k.hdr & 63u, q = k.q + 1u;
+    const u128 m = KTraits<K>::mask();
+    constexpr int SB = 2 * K + 2;
+    const uint32_t base_in = (uint32_t)(SB >= 64 ? (k.X.hi >> (SB - 64)) : (k.X.lo >> SB)) & 3u;       // the first k-mer's successor
+    const uint32_t succ = (uint32_t)(SB + 2 >= 64 ? (k.X.hi >> (SB + 2 - 64)) : (k.X.lo >> (SB + 2))) & 3u;
+    const uint32_t pred = (uint32_t)(k.X.lo >> 2) & 3u;                  // the first k-mer's first base
+    const u128 ks = shr128(k.X, 4);
+    const u128 R{~ks.lo & m.lo, ~ks.hi & m.hi};
+    u128 F = shl128(k.F, 2); F.lo |= base_in; F.lo &= m.lo; F.hi &= m.hi;
+    const bool rev = lt128(R, F);
+    uint32_t ctx = 0x10u << pred;                                        // (q >= 1: there is a predecessor in the record)
+    if (q + 1 < nk || (k.hdr & 128u)) ctx |= 1u << succ;
+    if (rev) ctx = ctx_rc(ctx);
+    return probe_begin(rev ? R : F, ctx, (int32_t)k.tag, S, active && q < nk);
+}
+
+template <int K, int NBC, bool SUB>
+__device__ __forceinline__ void wave_count_chunk_pairs(const uint4* __restrict__ records, uint64_t rb, uint64_t re,
+                                                       WaveStage<K>* __restrict__ st, int lane,
+                                                       uint32_t* keys, uint32_t* cnt, uint32_t* ctxs, uint32_t* bcw,
+                                                       uint32_t S, uint32_t* n_fill, uint32_t* overflow, uint32_t sub)
+{
+    const uint32_t sel_mask = (1u << (sub >> 8)) - 1u, sel = sub & 0xFFu;
+    auto selected = [&](const Probe& A) { return ((((A.k0 * 0x9E3779B1u) ^ (A.k1 * 0x85EBCA77u) ^ (A.k2 * 0xC2B2AE3Du) ^ (A.k3 * 0x27D4EB2Fu)) >> 24) & sel_mask) == sel; };
+    const uint32_t total = wave_stage_pairs<K>(records, rb, re, st, lane);
+    bool ok = true;
+    uint32_t n_claimed = 0;
+    const uint32_t end_u = __builtin_amdgcn_readfirstlane(total);       // scalar loop control
+    for (uint32_t t0 = 0; t0 < end_u; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        PairRegs keep;
+        Probe A = pair_first<K>(st, min(t, end_u - 1u), S, t < end_u, &keep);
+        if (SUB) A.active = A.active && selected(A);
+        ok = table_insert<KTraits<K>::KW, NBC, true>(keys, cnt, ctxs, bcw, S, A, n_claimed) && ok;
+        Probe B = pair_second<K>(keep, S, t < end_u);
+        if (SUB) B.active = B.active && selected(B);
+        ok = table_insert<KTraits<K>::KW, NBC, true>(keys, cnt, ctxs, bcw, S, B, n_claimed) && ok;
+    }
+    n_claimed = wave_sum(n_claimed);
+    if (lane == 0 && n_claimed) atomicAdd(n_fill, n_claimed);
+    if (!ok) atomicOr(overflow, 1u);
+    wave_sync();
+}
+
 constexpr int BIG_TICKET_CHUNKS = 4;                 // chunks a wave takes per ticket
 
 // item that owns position x of the concatenated chunk / slot space (pre[] ascending, pre[0] = 0, pre[n] = total)
@@ -1584,8 +1702,13 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         } else
         for (uint32_t at = w_lo; at < w_hi; at += COUNT_CHUNK) {
             if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
+#ifdef DFK_NO_PAIRS
             wave_count_chunk<K, NBC, true, SUB>(records, rb + at, rb + w_hi, st, lane, keys, cnt, ctxs, bcw, S,
                                              &ctl[CTL_FILL], &ctl[CTL_OVF], sub);
+#else
+            wave_count_chunk_pairs<K, NBC, SUB>(records, rb + at, rb + w_hi, st, lane, keys, cnt, ctxs, bcw, S,
+                                                &ctl[CTL_FILL], &ctl[CTL_OVF], sub);
+#endif
             if (lane == 0 && tld(&ctl[CTL_FILL]) > (S / 4) * 3) tst(&ctl[CTL_OVF], 1u);   // stop when 3/4 full
         }
         PH(2);

@@ -59,7 +59,7 @@ def test_reads_longer_than_255_bases(oracle, tmp_path):
     from oracle import graph_oracle, paths_oracle
     from superplus_amd.dfk import Dfk
     from tests import util
-    rs = util.make_set(611, 60000, 2500, read_len=300)
+    rs = util.make_long_set(611, 60000, 2500, read_len=300)
     ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
     g = graph_oracle.run(ref["solid"], 48)
     reads, quals = paths_oracle.unpack_reads(rs)
@@ -73,7 +73,7 @@ def test_reads_longer_than_255_bases(oracle, tmp_path):
             out = os.path.join(tmp_path, "a.paths"); d.paths_write(out)
             assert open(out, "rb").read() == exp
             v = d.paths_verify(rs["packed"], rs["base_off"], rs["read_len"])
-            assert v["broken"] == 0 and v["no_anchor"] == 0 and v["dict_bad"] == 0 and v["placed"] > 4000
+            assert v["broken"] == 0 and v["no_anchor"] == 0 and v["dict_bad"] == 0 and v["placed"] > 4000, v
             d.close()
         finally:
             os.environ.pop("DFK_PATH_SLOTS", None)

@@ -10,6 +10,36 @@ def make_set(seed, genome_size, n_pairs, read_len=100, **kw):
     return synth.make_reads(genome, n_pairs, seed + 1, read_len=read_len, **kw).numpy()
 
 
+def make_long_set(seed, genome_size, n_pairs, read_len=300, err=0.005):
+    """Pairs of reads longer than one PQVec block (nQs is a byte: 255), built on the host with the small-test encoder
+    (feudal.pq_encode): random genome, substitutions, a Q2 tail on a third of the reads, a few barcodes."""
+    from superplus_amd import feudal
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, genome_size, dtype=np.uint8)
+    L = read_len
+    codes, pqs = [], []
+    for _ in range(n_pairs):
+        a = int(rng.integers(0, genome_size - 2 * L - 200))
+        ins = L + int(rng.integers(0, 200))
+        r1 = genome[a:a + L].copy()
+        r2 = (3 - genome[a + ins:a + ins + L][::-1]).astype(np.uint8)
+        if rng.random() < 0.5: r1, r2 = r2, r1
+        for r in (r1, r2):
+            hit = rng.random(L) < err
+            r[hit] = (r[hit] + rng.integers(1, 4, int(hit.sum()))) & 3
+            q = np.full(L, int(rng.choice([30, 35, 37])), np.uint8)
+            q[rng.integers(0, L, 3)] = 20                                        # (mixed blocks among the constant runs)
+            if rng.random() < 0.33: q[L - int(rng.integers(5, 40)):] = 2
+            codes.append(r); pqs.append(np.frombuffer(feudal.pq_encode(q), np.uint8))
+    n = 2 * n_pairs
+    packed = feudal.pack_bases(np.stack(codes)).reshape(-1)
+    read_len_a = np.full(n, L, np.uint32)
+    base_off = (np.arange(n + 1, dtype=np.uint64) * np.uint64((L + 3) // 4)).astype(np.uint64)
+    pq_off = np.concatenate([[0], np.cumsum([len(x) for x in pqs])]).astype(np.uint64)
+    bc = np.repeat(rng.integers(0, 40, n_pairs).astype(np.int32), 2)            # 0 = unbarcoded
+    return dict(packed=packed, base_off=base_off, read_len=read_len_a, pq_bytes=np.concatenate(pqs), pq_off=pq_off, bc=bc, n_reads=n)
+
+
 def assert_same_solid(a, b, what=""):
     assert len(a) == len(b), f"{what}: {len(a)} vs {len(b)} solid k-mers"
     for f in ("w0", "w1", "edge_id", "count_ctx", "bc", "pad"):
