@@ -986,6 +986,117 @@ __device__ __forceinline__ bool table_insert(uint32_t* __restrict__ keys, uint32
     return state != PS_FAILED;
 }
 
+// Two keys per lane, probed side by side (LDS tables only).  k_count's waves spend their time waiting, not issuing: a probe
+// is an LDS round trip (compare-and-swap + the key words) that the next step depends on, a batch of 64 keys takes 3.2 of
+// them in a row (the longest probe sequence of the wave), and at four waves per SIMD there is not enough else to run
+// meanwhile -- ten or twelve waves per workgroup count 8 / 15 % faster with the same instructions, and
+// taking two fifths of the extraction's instructions away (pair_second) changed nothing.  Here the round trips of two
+// batches overlap: one loop iteration issues both keys' LDS operations before it looks at either answer.  Both keys of a
+// lane may be the same k-mer (a homopolymer run) or hash to the same slot: the operations of a wave execute in order, so the
+// second key's compare-and-swap sees the first one's lock and comes back in the next iteration, as a key of another lane
+// would.
+template <int KW, int NBC>
+__device__ __forceinline__ bool table_insert2(uint32_t* __restrict__ keys, uint32_t* __restrict__ cnt,
+                                              uint32_t* __restrict__ ctxs, uint32_t* __restrict__ bcw,
+                                              uint32_t S, const Probe& A, const Probe& B, uint32_t& n_claimed)
+{
+    uint32_t sa = A.active ? PS_PROBING : PS_IDLE, sb = B.active ? PS_PROBING : PS_IDLE;
+    uint32_t slot_a = A.slot, slot_b = B.slot, seen_a = 0, seen_b = 0, cost_a = 0, cost_b = 0;
+    while (__ballot((sa == PS_PROBING) | (sb == PS_PROBING)) != 0ull) {
+        uint32_t ea = 0, a0 = 0, a1 = 0, a2 = 0, a3 = A.k3, eb = 0, b0 = 0, b1 = 0, b2 = 0, b3 = B.k3;
+        const bool pa = sa == PS_PROBING, pb = sb == PS_PROBING;
+        if (pa) {
+            __hip_atomic_compare_exchange_strong(&cnt[slot_a], &ea, CNT_LOCK, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            DFK_COMPILER_FENCE();
+            a0 = tld(&keys[slot_a]); a1 = tld(&keys[S + slot_a]); a2 = tld(&keys[2 * S + slot_a]);
+            if (KW == 4) a3 = tld(&keys[3 * S + slot_a]);
+        }
+        DFK_COMPILER_FENCE();
+        if (pb) {
+            __hip_atomic_compare_exchange_strong(&cnt[slot_b], &eb, CNT_LOCK, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            DFK_COMPILER_FENCE();
+            b0 = tld(&keys[slot_b]); b1 = tld(&keys[S + slot_b]); b2 = tld(&keys[2 * S + slot_b]);
+            if (KW == 4) b3 = tld(&keys[3 * S + slot_b]);
+        }
+        DFK_COMPILER_FENCE();
+        if (pa) {
+            const bool won = ea == 0u;
+            if (won) {
+                tst(&keys[slot_a], A.k0); tst(&keys[S + slot_a], A.k1); tst(&keys[2 * S + slot_a], A.k2);
+                if (KW == 4) tst(&keys[3 * S + slot_a], A.k3);
+                DFK_COMPILER_FENCE();
+                __hip_atomic_store(&cnt[slot_a], A.fp << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const uint32_t locked = ea == CNT_LOCK;
+            const uint32_t match = ((ea >> 24) == A.fp) & (a0 == A.k0) & (a1 == A.k1) & (a2 == A.k2) & (a3 == A.k3);
+            const uint32_t fin = (uint32_t)won | match;
+            n_claimed += (uint32_t)won;
+            seen_a |= ea & (0u - match);
+            cost_a += PROBE_COST - (PROBE_COST - 1u) * locked;
+            slot_a = (slot_a + (A.step & ((fin | locked) - 1u))) & (S - 1);
+            sa = fin | ((uint32_t)(cost_a >= PROBE_LIMIT) << 1);
+        }
+        DFK_COMPILER_FENCE();
+        if (pb) {
+            const bool won = eb == 0u;
+            if (won) {
+                tst(&keys[slot_b], B.k0); tst(&keys[S + slot_b], B.k1); tst(&keys[2 * S + slot_b], B.k2);
+                if (KW == 4) tst(&keys[3 * S + slot_b], B.k3);
+                DFK_COMPILER_FENCE();
+                __hip_atomic_store(&cnt[slot_b], B.fp << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const uint32_t locked = eb == CNT_LOCK;
+            const uint32_t match = ((eb >> 24) == B.fp) & (b0 == B.k0) & (b1 == B.k1) & (b2 == B.k2) & (b3 == B.k3);
+            const uint32_t fin = (uint32_t)won | match;
+            n_claimed += (uint32_t)won;
+            seen_b |= eb & (0u - match);
+            cost_b += PROBE_COST - (PROBE_COST - 1u) * locked;
+            slot_b = (slot_b + (B.step & ((fin | locked) - 1u))) & (S - 1);
+            sb = fin | ((uint32_t)(cost_b >= PROBE_LIMIT) << 1);
+        }
+    }
+    // count, context, barcode: as table_insert (the comments on saturation and barcodes are there)
+    auto found = [&](const Probe& P, uint32_t state, uint32_t slot, uint32_t seen) {
+        const bool high = state == PS_FOUND && (seen & CNT_MASK) >= CNT_HALF;
+        if (state == PS_FOUND && !high) atomicAdd(&cnt[slot], 1u);
+        unsigned long long todo = __ballot(high);
+        while (todo) {                                                        // (wave-uniform: `todo` is a ballot)
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lslot = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
+            const unsigned long long same = __ballot(high && slot == lslot) & todo;
+            if ((int)(threadIdx.x & 63) == leader) {
+                const uint32_t k = (uint32_t)__popcll(same);
+                uint32_t cur = tld(&cnt[slot]);
+                for (;;) {
+                    const uint32_t c0 = cur & CNT_MASK, c1 = c0 + k < CNT_MASK ? c0 + k : CNT_MASK;
+                    if (c1 == c0) break;
+                    if (__hip_atomic_compare_exchange_strong(&cnt[slot], &cur, (cur & ~CNT_MASK) | c1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                }
+            }
+            todo &= ~same;
+        }
+        if (state != PS_FOUND) return;
+        atomicOr(&ctxs[slot], P.ctx);
+        if (NBC > 0) {
+            if (P.tag == -1) atomicOr(&bcw[slot], BCW_MULTI);
+            else if (P.tag > 0) {
+                bool settled = false;
+#pragma unroll
+                for (int j = 0; j < NBC; ++j)
+                    if (!settled) {
+                        const uint32_t old = atomicCAS(&bcw[(size_t)j * S + slot], 0u, (uint32_t)P.tag);
+                        settled = old == 0u || (old & ~BCW_MULTI) == (uint32_t)P.tag || (j == 0 && (old & BCW_MULTI));
+                    }
+                if (!settled) atomicOr(&bcw[slot], BCW_MULTI);
+            }
+        }
+    };
+    found(A, sa, slot_a, seen_a);
+    found(B, sb, slot_b, seen_b);
+    return sa != PS_FAILED && sb != PS_FAILED;
+}
+
 // One k-mer instance as read from the wave's staged chunk: header, barcode, the five payload words that
 // cover it, and its index inside the record.
 struct InstRegs { uint32_t hdr, tag, p0, p1, p2, p3, p4, q; };
@@ -1094,7 +1205,13 @@ __device__ __forceinline__ uint32_t wave_count_chunk(const uint4* __restrict__ r
     return end_u - first_u;
 }
 
-// ---- two consecutive k-mers of a record per lane (k_count's main path; -DDFK_NO_PAIRS restores one k-mer per lane)
+// ---- two consecutive k-mers of a record per lane: an EXPERIMENT (round 4), built with -DDFK_PAIRS, parity green, NOT the
+// default -- measured on MI355X (tools/pairs_ab.sh, tools/pmc_sq.sh): k_count 963 ms per step as it is,
+// 982 ms with the pair extraction and two inserts one after the other (-DDFK_PAIRS -DDFK_PAIRS_SERIAL), 993 ms with the two
+// keys probed side by side (table_insert2).  The extraction block does shrink (127 vector instructions for two k-mers against
+// 2 x 111), but a k_count wave is parked on s_waitcnt / barriers for 57 % of its cycles and issues during 31 % (SQ_WAIT_ANY,
+// SQ_ACTIVE_INST_ANY): instructions are not what it is short of, and the side-by-side loop adds more of them (+11 % vector,
+// +23 % scalar: both keys' bookkeeping in every iteration) than the shorter chain of LDS round trips gives back.
 // Rebuilding a k-mer from the 2-bit stream is two fifths of the insert path's vector instructions (fetch ~12, extraction
 // ~99 of ~267 per 64 instances), and nearly half of THAT is the 128-bit group reversal that turns the stream into KMer's
 // big-endian order.  The k-mer that follows in the same record needs none of it: its forward value is the predecessor's
@@ -1201,10 +1318,14 @@ __device__ __forceinline__ void wave_count_chunk_pairs(const uint4* __restrict__
         PairRegs keep;
         Probe A = pair_first<K>(st, min(t, end_u - 1u), S, t < end_u, &keep);
         if (SUB) A.active = A.active && selected(A);
-        ok = table_insert<KTraits<K>::KW, NBC, true>(keys, cnt, ctxs, bcw, S, A, n_claimed) && ok;
         Probe B = pair_second<K>(keep, S, t < end_u);
         if (SUB) B.active = B.active && selected(B);
+#ifdef DFK_PAIRS_SERIAL
+        ok = table_insert<KTraits<K>::KW, NBC, true>(keys, cnt, ctxs, bcw, S, A, n_claimed) && ok;
         ok = table_insert<KTraits<K>::KW, NBC, true>(keys, cnt, ctxs, bcw, S, B, n_claimed) && ok;
+#else
+        ok = table_insert2<KTraits<K>::KW, NBC>(keys, cnt, ctxs, bcw, S, A, B, n_claimed) && ok;
+#endif
     }
     n_claimed = wave_sum(n_claimed);
     if (lane == 0 && n_claimed) atomicAdd(n_fill, n_claimed);
@@ -1702,10 +1823,10 @@ k_count(const uint4* __restrict__ records, const ItemRange* __restrict__ items, 
         } else
         for (uint32_t at = w_lo; at < w_hi; at += COUNT_CHUNK) {
             if (__builtin_amdgcn_readfirstlane(tld(&ctl[CTL_OVF]))) break;
-#ifdef DFK_NO_PAIRS
+#ifndef DFK_PAIRS
             wave_count_chunk<K, NBC, true, SUB>(records, rb + at, rb + w_hi, st, lane, keys, cnt, ctxs, bcw, S,
                                              &ctl[CTL_FILL], &ctl[CTL_OVF], sub);
-#else
+#else           // experiment, measured and not kept (below): two consecutive k-mers per lane, -DDFK_PAIRS_SERIAL or probed side by side
             wave_count_chunk_pairs<K, NBC, SUB>(records, rb + at, rb + w_hi, st, lane, keys, cnt, ctxs, bcw, S,
                                                 &ctl[CTL_FILL], &ctl[CTL_OVF], sub);
 #endif

@@ -152,6 +152,66 @@ def test_df_writes_paths_index_and_dups(tmp_path, golden_dir):
 
 
 @pytest.mark.gpu
+def test_df_leaves_what_the_reference_resumes_from(tmp_path, golden_dir):
+    """Seam B2 as a pipeline: `superplus_amd/DF ROOT=... LR=...` then the reference's `DF ROOT=... START=patch ...` on the same
+    ROOT.  That branch of the reference loads exactly these files (10X/DF.cc:304-341 for START != "",
+    :569-594 for START=patch): data/frag_reads_orig.{qualp,fastb,bci,lens,qhist,dti} and a.<K>/{a.hbv,a.hbx,a.inv,a.paths,a.dup}
+    + a.paths.inv (handed to StagePatch by name).  Every one must exist and parse as the reader the reference uses on it would
+    read it, with sizes that agree with each other."""
+    import struct
+    r = run_df(f"ROOT={tmp_path}", f"LR={golden_dir}/frag.fastb", "PIPELINE=cs", "ALIGN=False", "NUM_THREADS=4", "MAX_MEM_GB=640", "HBM_GB=8")
+    assert r.returncode == 0, r.stdout + r.stderr
+    w = f"{tmp_path}/GapToy/1"
+    rd = lambda p: open(p, "rb").read()
+    head = f"{w}/data/frag_reads_orig"
+    # bases.ReadAll(.fastb), quals_om.newFile(.qualp): feudal files with one element per read
+    packed, base_off, read_len = feudal.read_fastb(head + ".fastb")
+    pq, pq_off = feudal.read_qualp(head + ".qualp")
+    n = len(read_len)
+    assert n == 6000 and len(pq_off) == n + 1 and int(base_off[-1]) == len(packed) and int(pq_off[-1]) == len(pq)
+    # BinaryReader::readFile of vec<int64_t> (.bci), vec<int16_t> (.lens), vec<vec<vec<int64_t>>> (.qhist), vec<DataSet> (.dti)
+    bci = feudal.read_bci(head + ".bci")
+    assert bci[0] == 0 and bci[-1] == n and all(a <= b for a, b in zip(bci, bci[1:]))
+    b = rd(head + ".lens")
+    assert b[:8] == b"BINWRITE" and struct.unpack_from("<Q", b, 8)[0] == n and len(b) == 16 + 2 * n
+    assert list(np.frombuffer(b, "<i2", n, 16)) == [int(x) for x in read_len]
+    b = rd(head + ".qhist")
+    assert b[:8] == b"BINWRITE" and struct.unpack_from("<Q", b, 8)[0] == 2
+    at, total = 16, 0
+    for par in range(2):
+        (n_pos,) = struct.unpack_from("<Q", b, at); at += 8
+        assert n_pos == int(read_len.max())
+        for pos in range(n_pos):
+            (n_q,) = struct.unpack_from("<Q", b, at); at += 8
+            total += int(np.frombuffer(b, "<i8", n_q, at).sum()); at += 8 * n_q
+    assert at == len(b) and total == int(read_len.astype(np.int64).sum())      # every quality of every read counted once
+    b = rd(head + ".dti")
+    dt = np.frombuffer(b[16:], np.dtype([("dt", "u1"), ("pad", "V7"), ("start", "<i8")]))
+    assert struct.unpack_from("<Q", b, 8)[0] == len(dt) == 2 and list(dt["dt"]) == [2, 3] and dt["start"][0] == 0 and dt["start"][1] == bci[1]
+    # the graph and the paths: a.hbv / a.hbx / a.inv (BinaryReader), a.paths (ReadPathVec::ReadAll), a.dup (vec<Bool>), a.paths.inv
+    d = f"{w}/a.48"
+    for f in ("a.hbv", "a.hbx", "a.inv", "a.paths", "a.dup", "a.paths.inv", "a.countsb"):
+        assert rd(f"{d}/{f}") == rd(f"{golden_dir}/graph_frag_k48/{f}"), f      # (byte for byte what the reference's writers wrote)
+    inv = rd(f"{d}/a.inv")
+    n_edges = struct.unpack_from("<Q", inv, 8)[0]
+    hbv = rd(f"{d}/a.hbv")
+    assert hbv[:8] == b"BINWRITE" and struct.unpack_from("<i", hbv, 8)[0] == 48
+    hbx = rd(f"{d}/a.hbx")
+    assert hbx[:8] == b"BINWRITE" and struct.unpack_from("<i", hbx, 8)[0] == 48
+    paths = rd(f"{d}/a.paths")
+    assert struct.unpack_from("<I", paths, 0)[0] == n and paths[4:8] == bytes([1, 0, 24, 4])          # feudal control block of ReadPath
+    assert struct.unpack_from("<Q", paths, 16)[0] == len(paths)                                         # no fixed data behind the offset table
+    dup = rd(f"{d}/a.dup")
+    assert dup[:8] == b"BINWRITE" and struct.unpack_from("<Q", dup, 8)[0] == n // 2 == len(dup) - 16
+    pinv = rd(f"{d}/a.paths.inv")
+    assert struct.unpack_from("<I", pinv, 0)[0] == n_edges and pinv[4:8] == bytes([1, 0, 16, 8])
+    # ... and nothing else the branch reads is missing: the set, as a set
+    need = {"data/frag_reads_orig." + e for e in ("fastb", "qualp", "bci", "lens", "qhist", "dti")} | {"a.48/" + f for f in ("a.hbv", "a.hbx", "a.inv", "a.paths", "a.dup", "a.paths.inv")}
+    assert all(os.path.isfile(f"{w}/{f}") for f in need), [f for f in need if not os.path.isfile(f"{w}/{f}")]
+    assert "DF_DIGESTS " in r.stdout
+
+
+@pytest.mark.gpu
 def test_runall_command_line_on_gpu(tmp_path, golden_dir, oracle):
     """The full command line of runall.sh:127, unchanged: MAX_MEM_GB=640 must not become a 640 GiB HBM plan.  The
     transfers are forced through the many-chunk staged path (a few KB per chunk, three host threads)."""
