@@ -138,6 +138,18 @@ int dfk_count(dfk_ctx* ctx,
               const uint8_t* packed_bases, const uint64_t* base_off, const uint32_t* read_len,
               const uint8_t* pq_bytes, const uint64_t* pq_off, const int32_t* bc,
               uint64_t n_reads);
+/* What need not cross PCIe (DF, 10X/DF.cc:300-452, holds both in this form when it reaches createDict):
+ *   base_off == NULL (either call)  the bases are DENSE: read r starts where read r-1 ended, ceil(read_len/4) bytes each, read 0
+ *                                   at packed_bases -- what BaseVec's feudal writer produces (feudal/FeudalFileWriter.cc:100-121).
+ *                                   The offset table is derived on the device from read_len (8 bytes a read not uploaded).
+ *   dfk_count_bci                   takes the barcode INDEX of head.bci / frag_reads_orig.bci (n_bci entries, ascending, bci[0] = 0:
+ *                                   reads [bci[b], bci[b+1]) carry barcode b) in place of the vector DF expands it to at
+ *                                   10X/DF.cc:447-452; the expansion runs on the device (4 bytes a read not uploaded, and not
+ *                                   written by the host first).  Reads beyond bci[n_bci-1] are unbarcoded (0). */
+int dfk_count_bci(dfk_ctx* ctx,
+              const uint8_t* packed_bases, const uint64_t* base_off, const uint32_t* read_len,
+              const uint8_t* pq_bytes, const uint64_t* pq_off, const int64_t* bci, uint64_t n_bci,
+              uint64_t n_reads);
 
 /* Same call with every array already resident in this context's device memory (bench.py's
  * timed region; multi-GPU shards).  packed_bytes / pq_nbytes are the allocation sizes. */

@@ -729,13 +729,19 @@ int main(int argc, char** argv)
         const bool device_hist = fast && !sharded && !truthy(a["EXIT_LOAD"]) && want_paths && !getenv("DF_HOST_QHIST");
         std::atomic<int> max_len_known{-1};
         std::vector<int64_t> qh_dev; std::string qh_err; double t_qhist = 0;
+        // The barcode expansion of DF.cc:447-452 (7 GB of int32 at configs[1]) and the .fastb offset table (14 GB: a running sum of
+        // the read lengths, as the validation above has just established) are made on the device from the 80 MB index and the
+        // lengths (dfk_count_bci, base_off = NULL): neither is written by the host or crosses PCIe.  DF_HOST_BC=1: as before.
+        const bool host_bc = getenv("DF_HOST_BC") != nullptr;
         auto count_job = [&] {
             const double tj0 = now_s();
-            bc.reset(new int32_t[std::max<uint64_t>(1, n_reads)]);
-            parallel_ranges(n_reads, [&](unsigned, uint64_t lo, uint64_t hi) { memset(bc.get() + lo, 0, 4 * (hi - lo)); });      // (reads no barcode's range holds: 0)
-            parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t lo, uint64_t hi) {
-                for (uint64_t b = lo; b < hi; ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
-            }, 1024);
+            if (host_bc) {
+                bc.reset(new int32_t[std::max<uint64_t>(1, n_reads)]);
+                parallel_ranges(n_reads, [&](unsigned, uint64_t lo, uint64_t hi) { memset(bc.get() + lo, 0, 4 * (hi - lo)); });      // (reads no barcode's range holds: 0)
+                parallel_ranges(bci.size() - 1, [&](unsigned, uint64_t lo, uint64_t hi) {
+                    for (uint64_t b = lo; b < hi; ++b) for (int64_t r = bci[b]; r < bci[b + 1]; ++r) bc[r] = (int32_t)b;
+                }, 1024);
+            }
             const double tj1 = now_s();
             if (dfk_create(&cfg, &ctx)) { create_failed = true; count_err = dfk_last_error(); return; }
             if (getenv("DFK_TRACE")) fprintf(stderr, "[DF] barcodes expanded in %.3f s, dfk_create %.3f s, %.3f s after the process started\n", tj1 - tj0, now_s() - tj1, now_s() - t_start);
@@ -744,7 +750,9 @@ int main(int argc, char** argv)
                     if (m->p && dfk_hint_file_range(ctx, m->p, m->n, -1, 0)) { create_failed = true; count_err = dfk_last_error(); return; }
             printf("%s: building dictionary on the GPU\n", date().c_str());
             const double tc = now_s();
-            count_rc = dfk_count(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bc.get(), n_reads);
+            if (host_bc) count_rc = dfk_count(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bc.get(), n_reads);
+            else if (fast) count_rc = dfk_count_bci(ctx, h_packed + (n_reads ? ld64(h_boff) : 0), nullptr, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bci.data(), bci.size(), n_reads);   // (dense: validated above)
+            else count_rc = dfk_count_bci(ctx, h_packed, (const uint64_t*)h_boff, (const uint32_t*)h_len, h_pq, (const uint64_t*)h_qoff, bci.data(), bci.size(), n_reads);
             if (count_rc) count_err = dfk_last_error();
             t_count = now_s() - tc;
             if (!count_rc && device_hist) {

@@ -1963,38 +1963,64 @@ int dfk_hint_file_range(dfk_ctx* c, const void* base, uint64_t bytes, int fd, ui
     return 0;
 }
 
-int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const uint32_t* read_len,
-              const uint8_t* pq, const uint64_t* pq_off, const int32_t* bc, uint64_t n_reads)
+// dfk_count / dfk_count_bci: the reads from host memory.  base_off == NULL: dense bases, the table derived on the device;
+// bci != NULL: the barcode index, expanded on the device (neither then crosses PCIe: 14 + 7 GB of configs[1]'s 95).
+static int count_host(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const uint32_t* read_len,
+                      const uint8_t* pq, const uint64_t* pq_off, const int32_t* bc, const int64_t* bci, uint64_t n_bci, uint64_t n_reads)
 {
-    return guarded([&]() -> int {
     if (!c) return fail(DFK_E_ARG, "null context");
-    if (n_reads && (!packed || !base_off || !read_len || !pq || !pq_off)) return fail(DFK_E_ARG, "null input array");
+    if (n_reads && (!packed || !read_len || !pq || !pq_off)) return fail(DFK_E_ARG, "null input array");
+    if (n_reads >= (1ull << 32)) return fail(DFK_E_ARG, "more than 2^32-1 reads in one shard");
+    if (bci && n_bci < 2) return fail(DFK_E_ARG, "a barcode index has at least two entries (bci[0] = 0, bci[last] = the number of reads)");
     HIP_TRY(hipSetDevice(c->device));
     c->release_all();
     c->drop_kept();
     // (the host tables may sit at any address -- e.g. inside a mapped feudal file -- so they are not dereferenced as u64)
     uint64_t pb = 0, qb = 0;
-    if (n_reads) { int r1 = host_read(c, &pb, (const char*)base_off + 8 * n_reads, 8); if (!r1) r1 = host_read(c, &qb, (const char*)pq_off + 8 * n_reads, 8); if (r1) return r1; }
+    if (n_reads) { int r1 = base_off ? host_read(c, &pb, (const char*)base_off + 8 * n_reads, 8) : 0; if (!r1) r1 = host_read(c, &qb, (const char*)pq_off + 8 * n_reads, 8); if (r1) return r1; }
     // staging copies live outside the context's run allocations (release_all() at the start of a run)
-    void *d_packed = nullptr, *d_boff = nullptr, *d_len = nullptr, *d_pq = nullptr, *d_poff = nullptr, *d_bc = nullptr;
+    void *d_packed = nullptr, *d_boff = nullptr, *d_len = nullptr, *d_pq = nullptr, *d_poff = nullptr, *d_bc = nullptr, *d_bci = nullptr;
     Timer t(c->stream);
     t.start();
     int rc = 0;
-    auto up = [&](void** d, const void* h, size_t bytes) {
+    auto room = [&](void** d, size_t bytes) {
         if (rc) return;
         // (64 bytes of slack: the kernels read the 2-bit stream as aligned 32-bit words, up to 3 bytes past its end)
-        if (hipMalloc(d, bytes + 64) != hipSuccess) { (void)hipGetLastError(); rc = fail(DFK_E_NOMEM, "no room on the device for %zu bytes of input", bytes); return; }
+        if (hipMalloc(d, bytes + 64) != hipSuccess) { (void)hipGetLastError(); rc = fail(DFK_E_NOMEM, "no room on the device for %zu bytes of input", bytes); }
+    };
+    auto up = [&](void** d, const void* h, size_t bytes) {
+        room(d, bytes);
+        if (rc) return;
         const auto t0 = std::chrono::steady_clock::now();
         rc = upload(c, *d, h, bytes);
         TRACE("uploaded %.2f GB in %.3f s", bytes / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     };
-    up(&d_packed, packed, pb);
-    up(&d_boff, base_off, (n_reads + 1) * 8);
+    const unsigned cus = (unsigned)c->prop.multiProcessorCount;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_reads + 256) / 256, 32ull * cus));
+    auto derive = [&]() -> int {                                         // (the kernels of the derived arrays run under the uploads that follow)
+        if (!base_off) {
+            hipLaunchKernelGGL(k_dense_sizes, dim3(grid), dim3(256), 0, c->stream, (const uint32_t*)d_len, n_reads, (uint64_t*)d_boff);
+            HIP_TRY(hipGetLastError());
+            int r = device_scan(c, (const uint64_t*)d_boff, (uint64_t*)d_boff, n_reads + 1); if (r) return r;
+            HIP_TRY(hipMemcpyAsync(&pb, (const uint64_t*)d_boff + n_reads, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        if (bci) {
+            hipLaunchKernelGGL(k_expand_bci, dim3(grid), dim3(256), 0, c->stream, (const int64_t*)d_bci, n_bci, n_reads, (int32_t*)d_bc);
+            HIP_TRY(hipGetLastError());
+        }
+        return 0;
+    };
     up(&d_len, read_len, n_reads * 4);
+    if (base_off) up(&d_boff, base_off, (n_reads + 1) * 8); else room(&d_boff, (n_reads + 1) * 8);
+    if (bci) { up(&d_bci, bci, n_bci * 8); room(&d_bc, n_reads * 4); }
+    if (!rc && (!base_off || bci)) { rc = derive(); c->drop_empty_chunks(); }     // (the scan's scratch came from the arena: the run's first chunk is still to be sized)
+    up(&d_packed, packed, pb);
     up(&d_pq, pq, qb);
     up(&d_poff, pq_off, (n_reads + 1) * 8);
-    if (bc) up(&d_bc, bc, n_reads * 4);
+    if (bc && !bci) up(&d_bc, bc, n_reads * 4);
     float ms_up = t.stop();
+    if (d_bci) { (void)hipFree(d_bci); d_bci = nullptr; }
     if (!rc) {
         uint64_t staged = pb + qb + (n_reads + 1) * 16 + n_reads * 8 + 6 * 64;
         uint64_t saved = c->budget;
@@ -2014,6 +2040,20 @@ int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const
     }
     (void)hipFree(d_packed); (void)hipFree(d_boff); (void)hipFree(d_len); (void)hipFree(d_pq); (void)hipFree(d_poff); (void)hipFree(d_bc);
     return rc;
+}
+
+int dfk_count(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const uint32_t* read_len,
+              const uint8_t* pq, const uint64_t* pq_off, const int32_t* bc, uint64_t n_reads)
+{
+    return guarded([&]() -> int { return count_host(c, packed, base_off, read_len, pq, pq_off, bc, nullptr, 0, n_reads); });
+}
+
+int dfk_count_bci(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_off, const uint32_t* read_len,
+                  const uint8_t* pq, const uint64_t* pq_off, const int64_t* bci, uint64_t n_bci, uint64_t n_reads)
+{
+    return guarded([&]() -> int {
+        if (!bci) return fail(DFK_E_ARG, "null barcode index");
+        return count_host(c, packed, base_off, read_len, pq, pq_off, nullptr, bci, n_bci, n_reads);
     });
 }
 

@@ -2708,6 +2708,27 @@ k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx,
 }
 
 // ============================================================================ small utilities
+// dfk_count with base_off == NULL: reads stored one behind the other, ceil(len/4) bytes each (what BaseVec's feudal writer
+// produces) -- the sizes here, their exclusive scan (device_scan, in place) is the offset table
+__global__ void __launch_bounds__(256)
+k_dense_sizes(const uint32_t* __restrict__ read_len, uint64_t n, uint64_t* __restrict__ out /* [n + 1] */)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * 256) out[i] = i < n ? ((uint64_t)read_len[i] + 3) >> 2 : 0;
+}
+
+// DF.cc:447-452 on the device: bc[r] = the barcode whose range [bci[b], bci[b+1]) holds read r (0 for reads no range holds).
+// Neighbouring reads take the same path through the index, which stays in the caches.
+__global__ void __launch_bounds__(256)
+k_expand_bci(const int64_t* __restrict__ bci, uint64_t n_bci, uint64_t n_reads, int32_t* __restrict__ bc)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * 256) {
+        // the last b with bci[b] <= r (bci ascending, bci[0] = 0); empty barcodes (bci[b] == bci[b+1]) are stepped over by taking the last
+        uint64_t lo = 0, hi = n_bci;                                  // bci[lo] <= r < bci[hi] (hi = n_bci: beyond the table)
+        while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if ((uint64_t)bci[mid] <= r) lo = mid; else hi = mid; }
+        bc[r] = (lo + 1 < n_bci && r < (uint64_t)bci[lo + 1]) ? (int32_t)lo : 0;
+    }
+}
+
 __global__ void k_fill_u64(uint64_t* p, uint64_t n, uint64_t v)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

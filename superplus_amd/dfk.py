@@ -21,7 +21,7 @@ ENTRY_DTYPE = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("edge_id", "<u4"), ("coun
                         ("bc", "<i4"), ("pad", "<u4")])
 
 EXPORTS = [
-    "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_device",
+    "dfk_create", "dfk_destroy", "dfk_last_error", "dfk_abi_version", "dfk_count", "dfk_count_bci", "dfk_count_device",
     "dfk_hint_file_range", "dfk_qual_hist", "dfk_paths_sink", "dfk_good_lens", "dfk_spectrum", "dfk_spectrum_json", "dfk_solid_count", "dfk_solid_fetch", "dfk_solid_fetch_unsorted", "dfk_solid_digest",
     "dfk_write_kvec", "dfk_write_kvec_part", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_begin_host", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_partition_begin", "dfk_shard_partition_end", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
@@ -123,12 +123,21 @@ class Dfk:
             pass
 
     def count(self, packed, base_off, read_len, pq_bytes, pq_off, bc):
-        packed = np.ascontiguousarray(packed, np.uint8); base_off = np.ascontiguousarray(base_off, np.uint64)
+        packed = np.ascontiguousarray(packed, np.uint8); base_off = None if base_off is None else np.ascontiguousarray(base_off, np.uint64)
         read_len = np.ascontiguousarray(read_len, np.uint32); pq_bytes = np.ascontiguousarray(pq_bytes, np.uint8)
         pq_off = np.ascontiguousarray(pq_off, np.uint64)
         bc = None if bc is None else np.ascontiguousarray(bc, np.int32)
         _check(lib().dfk_count(self._ctx, _p(packed), _p(base_off), _p(read_len), _p(pq_bytes), _p(pq_off), _p(bc),
                                C.c_uint64(len(read_len))))
+
+    def count_bci(self, packed, base_off, read_len, pq_bytes, pq_off, bci):
+        """dfk_count_bci: the barcode index (as read from .bci) instead of the expanded vector; base_off None = dense bases."""
+        packed = np.ascontiguousarray(packed, np.uint8); read_len = np.ascontiguousarray(read_len, np.uint32)
+        base_off = None if base_off is None else np.ascontiguousarray(base_off, np.uint64)
+        pq_bytes = np.ascontiguousarray(pq_bytes, np.uint8); pq_off = np.ascontiguousarray(pq_off, np.uint64)
+        bci = np.ascontiguousarray(bci, np.int64)
+        _check(lib().dfk_count_bci(self._ctx, _p(packed), _p(base_off), _p(read_len), _p(pq_bytes), _p(pq_off), _p(bci),
+                                   C.c_uint64(len(bci)), C.c_uint64(len(read_len))))
 
     def count_device(self, packed, base_off, read_len, pq_bytes, pq_off, bc):
         """torch tensors on the GPU: packed u8, base_off i64[n+1], read_len i32[n], pq_bytes u8,

@@ -485,3 +485,36 @@ def test_hinted_file_ranges_are_read_from_the_file(oracle, tmp_path):
     assert d.stats()["n_solid"] == len(ref["solid"]) and np.array_equal(d.good_lens(), ref["good_len"])
     assert np.array_equal(arr2["read_len"], rs["read_len"])                 # (dropped pages come back from the file)
     d.close(); del arr, whole, arr2, whole2; m.close(); m2.close(); os.close(fd)
+
+
+def test_dense_bases_and_barcode_index_are_expanded_on_the_device(oracle):
+    """dfk_count with base_off = NULL (dense bases: the table is the running sum of ceil(len/4)) and dfk_count_bci (the barcode
+    index of .bci instead of DF's expanded vector, DF.cc:447-452): the same dictionary as the explicit arrays give."""
+    from superplus_amd.dfk import Dfk
+    rs = util.make_set(93, 50000, 3000, ragged_frac=0.3)
+    # ragged lengths: cut every seventh read short (dense layout again afterwards)
+    from oracle import paths_oracle
+    from superplus_amd import feudal
+    reads, quals = paths_oracle.unpack_reads(rs)
+    for i in range(0, len(reads), 7):
+        reads[i] = reads[i][:61 + i % 30]; quals[i] = quals[i][:61 + i % 30]
+    packed = np.concatenate([feudal.pack_bases(np.frombuffer(r, np.uint8)[None, :])[0] for r in reads])
+    read_len = np.array([len(r) for r in reads], np.uint32)
+    base_off = np.concatenate([[0], np.cumsum((read_len.astype(np.uint64) + 3) // 4)]).astype(np.uint64)
+    pqs = [np.frombuffer(feudal.pq_encode(np.asarray(q, np.uint8)), np.uint8) for q in quals]
+    pq_bytes = np.concatenate(pqs); pq_off = np.concatenate([[0], np.cumsum([len(x) for x in pqs])]).astype(np.uint64)
+    # a barcode index with empty barcodes and a tail of reads beyond the last range
+    n = len(read_len)
+    cuts = sorted({0, 300, 300, 1200, 1210, 2500, n - 400})
+    bci = np.array([0, 300, 300, 1200, 1210, 1210, 2500, n - 400], np.int64)
+    bc = np.zeros(n, np.int32)
+    for b in range(len(bci) - 1):
+        bc[bci[b]:bci[b + 1]] = b
+    ref = oracle.run(packed, base_off, read_len, pq_bytes, pq_off, bc, K=48, min_bc=1)
+    for how in ("dense", "bci", "both"):
+        d = Dfk(K=48, min_bc=1, keep_pre_adjacency=True)
+        if how == "dense": d.count(packed, None, read_len, pq_bytes, pq_off, bc)
+        elif how == "bci": d.count_bci(packed, base_off, read_len, pq_bytes, pq_off, bci)
+        else: d.count_bci(packed, None, read_len, pq_bytes, pq_off, bci)
+        util.check_parity(ref, d)
+        d.close()
