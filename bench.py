@@ -295,6 +295,9 @@ def df_stage_wall(args, dev, local):
         pairs = max(1000, int(mem["usable"] / 1.25 / per_read_link / 2))
     Gd = max(1000, int(G * pairs / total_pairs))
     root = tempfile.mkdtemp(prefix="dfk_df_", dir=args.df_dir if os.path.isdir(args.df_dir) else None)
+    # a second, smaller input for the stage as the reference's DF leaves it by default -- frag_reads_orig.{fastb,qualp} COPIED
+    # (10X/DfTools.cc:164-167), not linked: as many pairs as fit the allowance with the copies (half of configs[1] on this box)
+    pairs_c = min(pairs // 2, max(1000, int(mem["usable"] / 1.25 / per_read_copy / 2)))
     try:
         genome = synth.make_genome(Gd, SEED, device=dev)
         rs = synth.make_reads(genome, pairs, SEED + 17)
@@ -303,59 +306,85 @@ def df_stage_wall(args, dev, local):
         write_read_files(rs, root + "/reads")
         t_files = time.perf_counter() - t0
         in_bytes = sum(os.path.getsize(root + "/reads" + e) for e in (".fastb", ".qualp", ".bci"))
+        have_c = link and args.df_copies and not (args.df_gpus > 1 or args.df_transport)
+        if have_c:                                               # the first pairs_c pairs of the same reads: the same genome at a lower coverage
+            write_read_files(rs.head(pairs_c), root + "/half")
         del rs
         held = torch.cuda.memory_reserved(local)
         torch.cuda.synchronize(); torch.cuda.empty_cache()
         # The device memory this process has just given back (the read generator's, ~230 GB) is wiped by the driver before
         # anybody gets it again, at about 33 GB/s (tools/vram_alloc_cost.hip: a 180-GiB hipMalloc right behind the release of
-        # one takes 5.4 s): started at once, the stage's own allocations would wait for the harness's leftovers -- its count
-        # ended 7.7 s after the start whenever its upload did.  A pipeline's DF starts on a quiet device; so does this one.
+        # one takes 5.4 s): started at once, the stage's own allocations wait for the harness's leftovers.  A pipeline's DF
+        # starts on a quiet device.  BOTH clocks are reported: the run started at once (cold) and the run started after the wait.
         quiesce = float(os.environ.get("BENCH_QUIESCE_S", min(15.0, held / 25e9)))
-        time.sleep(quiesce)
-        cmd = [os.path.join(ROOT, "superplus_amd", "DF"), f"ROOT={root}", f"LR={root}/reads.fastb", "PIPELINE=cs", "ALIGN=False",
-               f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}",
-               "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (GRAPH=True: rows f-1, f-2, f-4 -- edges + HBV + read paths + paths index + duplicate marks -> a.<K>/)
-        if link: cmd.append("LINK_READS=True")
         # transfer lanes per copy: four (each keeps a DMA in flight and spins on it; three copies run side by side in the stage's last
         # phase, and the box gives the command 16 CPUs -- measured at full size: 16 lanes 17.1 s, 8: 16.7, 6: 17.0, 4: 15.6-16.2)
         env = dict(os.environ, DFK_HOST_THREADS=os.environ.get("DFK_HOST_THREADS", str(min(args.df_threads, 4))))
-        if args.df_gpus > 1 or args.df_transport:
-            # the C++ multi-GPU host (df_shard.h): DF forks one rank per GPU and moves the records over RCCL itself;
-            # `loopback` runs the ranks as threads on ONE GPU (the rehearsal a one-GPU box allows)
-            cmd.append(f"NUM_GPUS={max(1, args.df_gpus)}")
-            if args.df_transport == "loopback": env["DF_TRANSPORT"] = "loopback"
-            elif args.df_gpus <= 1: env["DF_FORCE_SHARDED"] = "1"
-        t0 = time.perf_counter(); e0 = time.time()
-        if os.environ.get("DF_TASKSET"): cmd = ["taskset", "-c", os.environ["DF_TASKSET"]] + cmd      # (an experiment's switch: bind the stage's threads)
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
-        wall = time.perf_counter() - t0; e1 = time.time()
-        if os.environ.get("DFK_TRACE") and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # the child's trace, for whoever asked for it
-            with open(os.path.join(ROOT, "gpurun_out", "df_child_trace.txt"), "w") as f: f.write(r.stderr)
-        if r.returncode != 0:
-            return {"error": f"DF exited {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
-        timing = {}
-        for line in r.stdout.splitlines():
-            if line.startswith("DF_MAIN_EPOCH "): timing["spawn_to_main_s"] = round(float(line.split()[1]) - e0, 3)
-            if line.startswith("DF_EXIT_EPOCH "): timing["exit_to_reaped_s"] = round(e1 - float(line.split()[1]), 3)
-            if line.startswith("DF_TIMING "):
-                o = json.loads(line[len("DF_TIMING "):])
-                if "rank0" in o:                     # the C++ sharded host: rank 0's phases, beside the parent's line
-                    timing["shard"] = dict(o["rank0"], ranks=o.get("ranks"))
-                    for k in ("kmer_instances", "solid"): timing.setdefault(k, o.get(k))
-                else: timing.update(o)
-        w = root + "/GapToy/1"
-        out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(w) for f in fs)
+
+        def run_stage(head, n_pairs, linked, wait_s):
+            """one run of the child process on the files `head`.*; the work directory is removed afterwards"""
+            cmd = [os.path.join(ROOT, "superplus_amd", "DF"), f"ROOT={root}", f"LR={head}.fastb", "PIPELINE=cs", "ALIGN=False",
+                   f"NUM_THREADS={args.df_threads}", "MAX_MEM_GB=640", f"DEVICE={local}", f"K={args.K}",
+                   "GRAPH=True" if args.df_graph else "GRAPH=False"]   # (GRAPH=True: rows f-1, f-2, f-4 -- edges + HBV + read paths + paths index + duplicate marks -> a.<K>/)
+            if linked: cmd.append("LINK_READS=True")
+            if args.df_gpus > 1 or args.df_transport:
+                # the C++ multi-GPU host (df_shard.h): DF forks one rank per GPU and moves the records over RCCL itself;
+                # `loopback` runs the ranks as threads on ONE GPU (the rehearsal a one-GPU box allows)
+                cmd.append(f"NUM_GPUS={max(1, args.df_gpus)}")
+                if args.df_transport == "loopback": env["DF_TRANSPORT"] = "loopback"
+                elif args.df_gpus <= 1: env["DF_FORCE_SHARDED"] = "1"
+            if os.environ.get("DF_TASKSET"): cmd = ["taskset", "-c", os.environ["DF_TASKSET"]] + cmd      # (an experiment's switch: bind the stage's threads)
+            time.sleep(wait_s)
+            t0 = time.perf_counter(); e0 = time.time()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+            wall = time.perf_counter() - t0; e1 = time.time()
+            if os.environ.get("DFK_TRACE") and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # the child's trace, for whoever asked for it
+                with open(os.path.join(ROOT, "gpurun_out", "df_child_trace.txt"), "a") as f: f.write(r.stderr)
+            w = root + "/GapToy/1"
+            if r.returncode != 0:
+                shutil.rmtree(root + "/GapToy", ignore_errors=True)
+                return {"error": f"DF exited {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+            timing, digests = {}, None
+            for line in r.stdout.splitlines():
+                if line.startswith("DF_MAIN_EPOCH "): timing["spawn_to_main_s"] = round(float(line.split()[1]) - e0, 3)
+                if line.startswith("DF_EXIT_EPOCH "): timing["exit_to_reaped_s"] = round(e1 - float(line.split()[1]), 3)
+                if line.startswith("DF_DIGESTS "): digests = json.loads(line[len("DF_DIGESTS "):])
+                if line.startswith("DF_TIMING "):
+                    o = json.loads(line[len("DF_TIMING "):])
+                    if "rank0" in o:                     # the C++ sharded host: rank 0's phases, beside the parent's line
+                        timing["shard"] = dict(o["rank0"], ranks=o.get("ranks"))
+                        for k in ("kmer_instances", "solid"): timing.setdefault(k, o.get(k))
+                    else: timing.update(o)
+            # what the stage WROTE: hard links to the inputs (LINK_READS) are not output
+            out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(w) for f in fs
+                            if not (linked and os.stat(os.path.join(dp, f)).st_nlink > 1))
+            shutil.rmtree(root + "/GapToy", ignore_errors=True)
+            return {"wall_s": round(wall, 3), "waited_before_s": round(wait_s, 1), "pairs": n_pairs, "timing": timing, "digests": digests, "output_bytes": out_bytes,
+                    "frag_reads_orig": "hard links to the inputs (LINK_READS=True: byte-identical files, no second copy in RAM)" if linked else "copies of the inputs (the reference's default)"}
+
+        cold = run_stage(root + "/reads", pairs, link, 0.0)                              # started at once, behind the harness's own release
+        if "error" in cold: return cold
+        # (the child has just released its own ~270 GB: the same wait again before the run that is the headline)
+        main = run_stage(root + "/reads", pairs, link, quiesce)
+        if "error" in main: return main
+        for e in (".fastb", ".qualp", ".bci"): os.unlink(root + "/reads" + e)
+        copies = run_stage(root + "/half", pairs_c, False, quiesce) if have_c else None
+        wall, timing = main["wall_s"], main["timing"]
         full = pairs == 900_000_000 and Gd == 3_100_000_000
-        return {"df_stage_wall_s": round(wall, 3),
+        return {"df_stage_wall_s": wall,
+                "df_stage_wall_cold_s": cold["wall_s"],
+                "df_stage_wall_copies_s": (wall if not link else None) if not copies else copies.get("wall_s"),
                 "workload": ("BASELINE configs[1]" if full else "BASELINE configs[1] scaled to fit the host memory cap") +
                             f": {pairs} pairs 2x100 bp over a {Gd / 1e6:g} Mb random genome ({200.0 * pairs / Gd:.1f}x), K={args.K}",
                 "definition": "wall time of the child process `DF ROOT= LR= PIPELINE=cs ALIGN=False NUM_THREADS= MAX_MEM_GB=640` "
-                              "(runall.sh:127) from start to exit: map inputs, re-emit frag_reads_orig.*, lens/qhist/dti, upload, "
+                              "(runall.sh:127) from start to exit: map inputs, frag_reads_orig.* (" + main["frag_reads_orig"] + "), lens/qhist/dti, upload, "
                               "createDict on the GPU, spectrum JSON" + (", then what buildReadQGraph48's second half, writePathsIndex and MarkDups leave in a.<K>/ "
                               "(10X/DF.cc:541-561: graph, read paths, paths index, duplicate marks)" if args.df_graph else ", kmers.kvec") +
-                              " -- ingest + StageBuildGraph, not the other seven DF stages",
-                "frag_reads_orig": "hard links to the inputs (LINK_READS=True: byte-identical files, no second copy in RAM)" if link else "copies of the inputs",
-                "device_quiesce_s": round(quiesce, 1),   # waited before the stage started: the driver wiping what THIS process had released
+                              " -- ingest + StageBuildGraph, not the other seven DF stages.  df_stage_wall_s: started on a quiet device "
+                              "(device_quiesce_s after the previous holder of the HBM let go); df_stage_wall_cold_s: started at once; "
+                              "df_stage_wall_copies_s: frag_reads_orig.{fastb,qualp} written as copies (the reference's default), on `copies.pairs` pairs",
+                "frag_reads_orig": main["frag_reads_orig"],
+                "device_quiesce_s": round(quiesce, 1),   # waited before the stage started: the driver wiping what the previous process had released
                 "host_memory": dict(mem, estimated_need=int(2 * pairs * (per_read_link if link else per_read_copy))),
                 "kmers_per_s_whole_stage": (timing.get("kmer_instances", 0) / wall) if wall > 0 else None,
                 "breakdown_s": {k: timing.get(k) for k in ("spawn_to_main_s", "open_validate_s", "ingest_outputs_s", "upload_s", "count_s",
@@ -366,9 +395,15 @@ def df_stage_wall(args, dev, local):
                 "paths": ({"paths_s": timing.get("paths_s"), "device_s": timing.get("paths_device_s"), "write_s": timing.get("paths_write_s"),
                            "reads_placed": timing.get("reads_placed"), "path_edges": timing.get("path_edges"),
                            "paths_index_s": timing.get("paths_index_s"), "mark_dups_s": timing.get("mark_dups_s"), "dup_pairs": timing.get("dup_pairs")} if args.df_graph else None),
+                # content digests of a.paths / a.paths.inv / a.countsb / a.dup and the graph's identities (dfk_paths_digest): the two
+                # full-size runs must agree
+                "digests": main["digests"], "digests_equal_cold_run": main["digests"] == cold["digests"],
+                "cold": {k: cold[k] for k in ("wall_s", "waited_before_s")} | {"breakdown_s": {k: cold["timing"].get(k) for k in ("upload_s", "count_s", "graph_s", "paths_s", "total_s")}},
+                "copies": None if not copies else ({"error": copies["error"]} if "error" in copies else
+                          {k: copies[k] for k in ("wall_s", "waited_before_s", "pairs", "output_bytes", "frag_reads_orig")} | {"breakdown_s": {k: copies["timing"].get(k) for k in ("upload_s", "count_s", "graph_s", "paths_s", "ingest_outputs_s", "background_join_s", "total_s")}}),
                 "host": ("C++ sharded host, %d rank(s), transport %s" % (max(1, args.df_gpus), args.df_transport or "rccl")) if (args.df_gpus > 1 or args.df_transport) else "single GPU (dfk_count)",
                 "shard_times_s": timing.get("shard"),
-                "input_bytes": in_bytes, "output_bytes": out_bytes, "files_on": root, "host_threads": args.df_threads,
+                "input_bytes": in_bytes, "output_bytes": main["output_bytes"], "files_on": root, "host_threads": args.df_threads,
                 "solid": timing.get("solid"), "kmer_instances": timing.get("kmer_instances"),
                 "input_files_written_in_s": round(t_files, 2)}
     finally:
@@ -408,6 +443,8 @@ def main():
     ap.add_argument("--df-graph", action=argparse.BooleanOptionalAction, default=True,
                     help="DF leg: GRAPH=True -- the graph, the read paths, the paths index and the duplicate marks in a.<K>/ (rows f-1, f-2, f-4); "
                          "--no-df-graph: ingest + count + kmers.kvec only")
+    ap.add_argument("--df-copies", action=argparse.BooleanOptionalAction, default=True,
+                    help="DF leg: also run the stage with frag_reads_orig.{fastb,qualp} as copies (the reference's default) on as many pairs as fit")
     ap.add_argument("--df-gpus", type=int, default=1, help="DF leg: NUM_GPUS of the C++ multi-GPU host (DF forks one rank per GPU, RCCL directly)")
     ap.add_argument("--df-transport", default="", choices=["", "rccl", "loopback"],
                     help="DF leg: run the C++ sharded host even with one rank (rccl), or all ranks as threads on one GPU (loopback)")
@@ -669,7 +706,9 @@ def main():
                 out["df_stage"] = df_stage_wall(args, dev, local)
             except Exception as e:
                 out["df_stage"] = {"error": repr(e)}
-            out["df_stage_wall_s"] = out["df_stage"].get("df_stage_wall_s")
+            for k in ("df_stage_wall_s", "df_stage_wall_cold_s", "df_stage_wall_copies_s"):
+                out[k] = out["df_stage"].get(k)
+            out["df_stage_device_quiesce_s"] = out["df_stage"].get("device_quiesce_s")
         print(json.dumps(out))
     if multi:
         dist.destroy_process_group()

@@ -26,6 +26,18 @@ class ReadSet:
     bci: np.ndarray           # i64[n_barcodes+1]   .bci
     n_reads: int
 
+    def head(self, n_pairs):
+        """The first n_pairs pairs as a read set of their own (views of the same tensors): the barcode index cut at the last
+        read kept -- a barcode cut in two keeps an even number of reads, pairs being whole."""
+        n = 2 * int(n_pairs)
+        if n >= self.n_reads:
+            return self
+        bci = [int(b) for b in self.bci if int(b) <= n]
+        if bci[-1] != n:
+            bci.append(n)
+        return ReadSet(packed=self.packed, base_off=self.base_off[: n + 1], read_len=self.read_len[:n], pq_bytes=self.pq_bytes,
+                       pq_off=self.pq_off[: n + 1], bc=self.bc[:n], bci=np.asarray(bci, np.int64), n_reads=n)
+
     def numpy(self):
         return dict(
             packed=self.packed.cpu().numpy(),
