@@ -306,6 +306,40 @@ int dfk_paths_verify(dfk_ctx* ctx, const uint8_t* packed_bases, const uint64_t* 
 int dfk_paths_verify_device(dfk_ctx* ctx, const void* d_packed_bases, uint64_t packed_bytes, const void* d_base_off, const void* d_read_len,
               uint64_t n_reads, uint64_t* out /* [8] */);
 
+/* ---- the data-parallel half of ParseBarcodedFastqs (10X/ParseBarcodedFastqs.cc:306-539) ----
+ * The host inflates the two .gz files, cuts them into lines and decides where every barcode stands in the output (the buckets
+ * are the iteration order of a std::unordered_set, :311-336: a container's business).  For one group of pairs it holds, the
+ * device then does the rest:
+ *   the order of the pairs   by the place of their barcode, inside a barcode DEScending by (read 1, read 2) as base sequences,
+ *                            equal pairs in file order (the list insertion of :434-449) -- a stable radix sort on the sequences
+ *   bases -> 2-bit codes     N -> A (:407-412), LSB-first as BaseVec stores them (feudal/FieldVec.h:766-770)
+ *   qualities -> PQVec       PQVecEncoder::init/encode (feudal/PQVec.cc:18-127), the block choice AND its cut-back rule
+ * dfk_pbf_run takes the reads as the fastq has them (ASCII) and returns the group's share of OUT_HEAD.fastb / .qualp ready to be
+ * appended: the pairs' order, the reads' lengths, both files' variable data with their offsets.  Errors as the reference's:
+ * DFK_E_INPUT for a quality above 63 ("Your input reads are funny", PQVec.cc:30-35) or a character that is no base.
+ * Any context will do (K plays no part); its HBM budget bounds the group. */
+#define DFK_PBF_DROP 0xFFFFFFFFu
+typedef struct dfk_pbf_input {
+    const uint8_t*  seq[2];      /* file 1 / file 2: the held reads' base characters, one read behind the other */
+    const uint8_t*  qual[2];     /* their quality characters (phred + 33), same layout */
+    const uint64_t* off[2];      /* [m + 1]: where read i starts in seq / qual */
+    const uint32_t* rank;        /* [m]: the place of pair i's barcode in the output; 0 = unbarcoded (file order kept);
+                                    DFK_PBF_DROP = the pair is left out (READS_PER_BC, :328) */
+    uint64_t m;                  /* pairs held */
+} dfk_pbf_input;
+typedef struct dfk_pbf_output {
+    uint64_t n_pairs;            /* pairs written: 2 * n_pairs reads, read 2k = read 1 of pair order[k], 2k+1 its mate */
+    const uint32_t* order;       /* [n_pairs] */
+    const uint32_t* read_len;    /* [2 n_pairs]: the .fastb fixed data */
+    const uint8_t*  fastb_var;  const uint64_t* fastb_off;   /* [2 n_pairs + 1], relative to fastb_var */
+    const uint8_t*  qualp_var;  const uint64_t* qualp_off;
+    float ms_sort, ms_encode, ms_total;   /* device time: the order; packing + PQVec; the whole call with its transfers */
+} dfk_pbf_output;
+typedef struct dfk_pbf dfk_pbf;
+int  dfk_pbf_run(dfk_ctx* ctx, const dfk_pbf_input* in, dfk_pbf** out);
+int  dfk_pbf_result(const dfk_pbf* r, dfk_pbf_output* o);      /* pointers stay valid until dfk_pbf_free */
+void dfk_pbf_free(dfk_pbf* r);
+
 /* ---- multi-GPU pieces (one process per GPU; the caller owns the RCCL exchange) ----
  * The reference's only exchange is MapReduceEngine's thread all-to-all ("swizzle",
  * MapReduceEngine.h:345-388): every key goes to the thread that owns hash % T.  Here every

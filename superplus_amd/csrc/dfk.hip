@@ -17,6 +17,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -2225,3 +2226,4 @@ int dfk_get_stats(dfk_ctx* c, dfk_stats* out)
 #include "dfk_shard.inc"
 #include "dfk_graph.inc"
 #include "dfk_paths.inc"
+#include "dfk_pbf.inc"

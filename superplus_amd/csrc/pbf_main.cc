@@ -23,6 +23,7 @@
 //     container gives the same order
 //   * .qualp: PQVecEncoder's block choice (feudal/PQVec.cc:18-85, restated in pq_encode below)
 //   * .bci: BINWRITE | u64 count | i64 offsets: 0, #unbarcoded reads, then the end of every barcode
+#include "../../include/dfk.h"
 #include "feudal_io.h"
 
 #include <algorithm>
@@ -63,6 +64,7 @@ struct Fastq {                               // one file: per read its barcode; 
     std::vector<uint64_t> off{0};            // [held + 1] into bases / quals
     std::string error;
     uint64_t counted = 0;                    // bases already added to g_held
+    bool raw = false;                        // device path: bases and quals keep the file's characters (the device turns them into codes)
     bool spilled = false;                    // the first pass gave the bases up (the set does not fit): bc and len are complete, the rest empty
 };
 
@@ -115,6 +117,10 @@ void read_fastq(const std::string& path, Fastq* f, const std::vector<uint8_t>* w
         if (!get()) { f->error = "truncated record in " + path; break; }
         const bool hold = want ? (i < want->size() && (*want)[i]) : !f->spilled;
         size_t nb = 0;
+        if (f->raw) {                                                                   // the line as it is: the device looks at the characters
+            nb = strcspn(line.data(), "\r\n");
+            if (hold) f->bases.insert(f->bases.end(), (const uint8_t*)line.data(), (const uint8_t*)line.data() + nb);
+        } else
         for (const char* p = line.data(); *p && *p != '\n' && *p != '\r'; ++p, ++nb) {
             uint8_t v;
             switch (*p) { case 'A': case 'a': case 'N': case 'n': v = 0; break; case 'C': case 'c': v = 1; break;
@@ -124,6 +130,9 @@ void read_fastq(const std::string& path, Fastq* f, const std::vector<uint8_t>* w
         }
         if (!get() || !get()) { f->error = "truncated record in " + path; break; }       // '+' line, then the qualities
         size_t nq = 0;
+        if (f->raw) {
+            for (const char* p = line.data(); *p; ++p) if (*p != '\n' && *p != '\r') { if (hold) f->quals.push_back((uint8_t)*p); ++nq; }
+        } else
         for (const char* p = line.data(); *p; ++p) if (*p != '\n' && *p != '\r') { if (hold) f->quals.push_back((uint8_t)(*p - 33)); ++nq; }
         if (nq != nb) { f->error = "a read of " + path + " has " + std::to_string(nq) + " qualities for " + std::to_string(nb) + " bases"; break; }
         if (!want) {
@@ -203,7 +212,7 @@ void pq_encode(const uint8_t* q, uint32_t len, std::vector<unsigned>& cost, std:
 int main(int argc, char** argv)
 {
     std::map<std::string, std::string> a = {{"FASTQS", ""}, {"OUT_HEAD", ""}, {"NUM_BUCKETS", "256"}, {"READS_PER_BC", "0"},
-                                            {"NUM_THREADS", "0"}, {"MAX_MEM_GB", "0"}, {"MERGE_HEADS", ""}};
+                                            {"NUM_THREADS", "0"}, {"MAX_MEM_GB", "0"}, {"MERGE_HEADS", ""}, {"HOST", "False"}, {"DEVICE", "0"}};
     for (int i = 1; i < argc; ++i) {
         const std::string s = argv[i]; const size_t eq = s.find('=');
         if (eq == std::string::npos) die("arguments are KEY=VALUE; got '" + s + "'");
@@ -227,8 +236,20 @@ int main(int argc, char** argv)
         const uint64_t phys = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)sysconf(_SC_PAGE_SIZE);
         g_mem_limit = gb > 0 ? std::min<uint64_t>(phys, (uint64_t)(gb * 1073741824.0)) : phys;
     }
+    // ---- where the data-parallel half runs.  The product is the device (dfk_pbf_run: pair order, 2-bit packing, PQVec encoding on
+    //      the MI355X) and a run without one fails; HOST=True is this file's own host code for all of it, chosen explicitly --
+    //      what the byte-for-byte comparisons with the reference's binary run on in the build container, which has no GPU.
+    const bool host_only = a["HOST"] == "True" || a["HOST"] == "true" || a["HOST"] == "1";
+    dfk_ctx* ctx = nullptr;
+    if (!host_only) {
+        dfk_config cfg{};
+        cfg.abi_version = DFK_ABI_VERSION; cfg.K = 48; cfg.min_qual = 7; cfg.min_freq = 3; cfg.min_bc = 2; cfg.device = atoi(a["DEVICE"].c_str());
+        if (dfk_create(&cfg, &ctx)) die(std::string(dfk_last_error()) + " (HOST=True runs the packing and encoding on the host)");
+    }
+    double dev_ms[3] = {0, 0, 0};
     // ---- both files, one thread each
     Fastq f1, f2;
+    f1.raw = f2.raw = !host_only;
     { std::thread t(read_fastq, fq[1], &f2, nullptr); read_fastq(fq[0], &f1, nullptr); t.join(); }
     if (!f1.error.empty()) die(f1.error);
     if (!f2.error.empty()) die(f2.error);
@@ -269,6 +290,12 @@ int main(int argc, char** argv)
         FILE* f = nullptr; std::string path; std::vector<uint64_t> off{24};
         void open(const std::string& p) { path = p; f = fopen(p.c_str(), "wb"); g_partial.push_back(p); const char z[24] = {0}; if (!f || fwrite(z, 1, 24, f) != 24) die("cannot create " + p); }
         void add(const std::vector<uint8_t>& v) { if (!v.empty() && fwrite(v.data(), 1, v.size(), f) != v.size()) die("short write " + path); off.push_back(off.back() + v.size()); }
+        void add_many(const uint8_t* var, const uint64_t* rel, uint64_t n)       // n elements whose bytes lie one behind the other in var, at rel[0..n]
+        {
+            if (rel[n] && fwrite(var, 1, rel[n], f) != rel[n]) die("short write " + path);
+            const uint64_t base = off.back();
+            for (uint64_t i = 1; i <= n; ++i) off.push_back(base + rel[i]);
+        }
         void finish(const void* fixed, size_t fixed_bytes, uint8_t szFixed, uint8_t szX, uint8_t szA)
         {
             const uint64_t n = off.size() - 1;
@@ -291,6 +318,48 @@ int main(int argc, char** argv)
     auto emit = [&](const Fastq& g1, const Fastq& g2, const std::vector<uint32_t>* held, size_t u0, size_t u1, bool first_of_unit0, bool last_of_unit0) {
         const size_t m = held ? held->size() : n_pairs;
         auto pair_no = [&](size_t k) { return held ? (size_t)(*held)[k] : k; };
+        if (ctx) {
+            // ---- the device path: this side decides only WHERE every barcode stands (unit 0 = the unbarcoded pairs in file order, then
+            //      the buckets in order, inside a bucket the barcodes ascending, :346) and how many pairs each has (the index); the
+            //      order inside a barcode, the 2-bit bases and the PQVec streams come from dfk_pbf_run
+            std::unordered_map<int64_t, uint32_t> count;
+            for (size_t k = 0; k < m; ++k) ++count[bc[pair_no(k)]];
+            std::unordered_map<int64_t, uint32_t> place;
+            const uint64_t reads_before = out_b.off.size() - 1;
+            uint64_t pairs_so_far = 0;
+            if (u0 == 0) {
+                if (count.count(0)) { place[0] = 0; pairs_so_far += count[0]; }
+                if (last_of_unit0) bci.push_back((int64_t)(reads_before + 2 * pairs_so_far));
+            }
+            uint32_t next_place = 1;
+            for (size_t u = std::max<size_t>(u0, 1); u < u1; ++u) {
+                const std::vector<int64_t>& bucket = buckets[u - 1];
+                std::set<int64_t> sorted(bucket.begin(), bucket.end());
+                for (int64_t b : sorted) {
+                    if (b == 0) continue;
+                    const uint32_t n_b = count.count(b) ? count[b] : 0;
+                    if (reads_per_bc && 2 * (size_t)n_b >= reads_per_bc) continue;
+                    place[b] = next_place++;
+                    pairs_so_far += n_b;
+                    bci.push_back((int64_t)(reads_before + 2 * pairs_so_far));
+                    ++n_barcodes;
+                }
+            }
+            std::vector<uint32_t> rank(m);
+            for (size_t k = 0; k < m; ++k) { const auto it = place.find(bc[pair_no(k)]); rank[k] = it == place.end() ? DFK_PBF_DROP : it->second; }
+            dfk_pbf_input in{{g1.bases.data(), g2.bases.data()}, {g1.quals.data(), g2.quals.data()}, {g1.off.data(), g2.off.data()}, rank.data(), (uint64_t)m};
+            dfk_pbf* res = nullptr;
+            if (dfk_pbf_run(ctx, &in, &res)) die(dfk_last_error());
+            dfk_pbf_output o{};
+            dfk_pbf_result(res, &o);
+            if (o.n_pairs != pairs_so_far) die("the device wrote " + std::to_string(o.n_pairs) + " pairs where the barcode index counts " + std::to_string(pairs_so_far));
+            lens.insert(lens.end(), o.read_len, o.read_len + 2 * o.n_pairs);
+            out_b.add_many(o.fastb_var, o.fastb_off, 2 * o.n_pairs);
+            out_q.add_many(o.qualp_var, o.qualp_off, 2 * o.n_pairs);
+            dev_ms[0] += o.ms_sort; dev_ms[1] += o.ms_encode; dev_ms[2] += o.ms_total;
+            dfk_pbf_free(res);
+            return;
+        }
         // ---- pairs grouped by barcode, in file order
         std::unordered_map<int64_t, std::vector<uint32_t>> group;
         for (size_t k = 0; k < m; ++k) group[bc[pair_no(k)]].push_back((uint32_t)k);
@@ -421,6 +490,7 @@ int main(int argc, char** argv)
         feudal::BinWriter w(head + ".bci"); w.vec(bci);
     } catch (const std::exception& e) { die(e.what()); }
     g_partial.clear();
+    if (ctx) { fprintf(stderr, "device: pair order %.1f ms, packing + PQVec %.1f ms, with transfers %.1f ms\n", dev_ms[0], dev_ms[1], dev_ms[2]); dfk_destroy(ctx); }
     fprintf(stderr, "wrote %zu reads, %zu barcodes\n", n_reads, n_barcodes);
     return 0;
 }

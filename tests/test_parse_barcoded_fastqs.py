@@ -1,7 +1,8 @@
 """ParseBarcodedFastqs: stLFR fastq.gz pairs -> barcode-sorted .fastb/.qualp/.bci, byte for byte against
 the reference's own binary -- oracle/_ref/ParseBarcodedFastqs, built from 10X/ParseBarcodedFastqs.cc where it lies
 (flags only) -- when it is there (the build container), and against the fixture it wrote (tests/golden/pbf/) anywhere.
-Host-only: runs on the CPU."""
+These run the program's HOST=True path (its own host code for the pair order, the packing and the PQVec encoder), on the
+CPU; the default path -- the same three steps on the MI355X (dfk_pbf_run) -- is compared with both in tests/test_gpu_pbf.py."""
 import os
 import subprocess
 
@@ -16,8 +17,9 @@ OURS = os.path.join(ROOT, "superplus_amd", "ParseBarcodedFastqs")
 REF = os.path.join(ROOT, "oracle", "_ref", "ParseBarcodedFastqs")
 
 
-def run(binary, fq1, fq2, head, *extra):
-    return subprocess.run([binary, "FASTQS={" + fq1 + "," + fq2 + "}", "OUT_HEAD=" + head, *extra], capture_output=True, text=True, timeout=600)
+def run(binary, fq1, fq2, head, *extra, device=False):
+    host = ["HOST=True"] if binary == OURS and not device else []
+    return subprocess.run([binary, "FASTQS={" + fq1 + "," + fq2 + "}", "OUT_HEAD=" + head, *extra, *host], capture_output=True, text=True, timeout=600)
 
 
 def same_files(a, b):
@@ -108,6 +110,17 @@ def test_refuses_an_input_that_does_not_fit_max_mem_gb(tmp_path):
     not with the OOM killer."""
     from tests.fastq_synth import make_fastq
     make_fastq(f"{tmp_path}/a_1.fq.gz", f"{tmp_path}/a_2.fq.gz", 3000, 5, n_bc=6)
-    r = subprocess.run([OURS, "FASTQS={" + f"{tmp_path}/a_1.fq.gz,{tmp_path}/a_2.fq.gz" + "}", f"OUT_HEAD={tmp_path}/o", "NUM_BUCKETS=2", "MAX_MEM_GB=0.0005"],
+    r = subprocess.run([OURS, "FASTQS={" + f"{tmp_path}/a_1.fq.gz,{tmp_path}/a_2.fq.gz" + "}", f"OUT_HEAD={tmp_path}/o", "NUM_BUCKETS=2", "MAX_MEM_GB=0.0005", "HOST=True"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "MAX_MEM_GB" in r.stderr and not os.path.exists(f"{tmp_path}/o.fastb")
+
+
+def test_without_a_device_the_default_path_fails_loudly(tmp_path):
+    """The product path is the device's: where there is no GPU the program says so and writes nothing (HOST=True is explicit)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    fq1, fq2 = f"{tmp_path}/a_1.fq.gz", f"{tmp_path}/a_2.fq.gz"
+    make_fastq(fq1, fq2, 50, 3)
+    r = run(OURS, fq1, fq2, f"{tmp_path}/o/reads", device=True)
+    assert r.returncode != 0 and "HOST=True" in r.stderr and not os.path.exists(f"{tmp_path}/o/reads.fastb")
