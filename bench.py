@@ -271,6 +271,36 @@ def host_memory_limits():
     return out
 
 
+def pbf_leg(args, local):
+    """ParseBarcodedFastqs on `--pbf-pairs` synthetic stLFR pairs (2x100 bp over a 4.6 Mb genome: BASELINE configs[0]'s shape):
+    wall time of the device path and of the host path, the device's own times, and that the three files are identical."""
+    import re, shutil
+    root = tempfile.mkdtemp(prefix="dfk_pbf_", dir=args.df_dir if os.path.isdir(args.df_dir) else None)
+    try:
+        fq = [root + "/r_1.fq.gz", root + "/r_2.fq.gz"]
+        t0 = time.perf_counter()
+        synth.write_fastq_pair(fq[0], fq[1], args.pbf_pairs, SEED + 3, threads=args.df_threads)
+        t_gen = time.perf_counter() - t0
+        exe = os.path.join(ROOT, "superplus_amd", "ParseBarcodedFastqs")
+        res = {}
+        for name, extra_args in (("device", [f"DEVICE={local}"]), ("host", ["HOST=True"])):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "FASTQS={" + fq[0] + "," + fq[1] + "}", f"OUT_HEAD={root}/{name}/reads", f"NUM_THREADS={args.df_threads}", "NUM_BUCKETS=10", *extra_args],
+                               capture_output=True, text=True, timeout=1200)
+            res[name] = {"wall_s": round(time.perf_counter() - t0, 3)}
+            if r.returncode != 0:
+                return {"error": f"{name} path exited {r.returncode}: {r.stderr[-300:]}"}
+            m = re.search(r"device: pair order ([\d.]+) ms, packing \+ PQVec ([\d.]+) ms, with transfers ([\d.]+) ms", r.stderr)
+            if m: res[name]["device_ms"] = {"pair_order": float(m.group(1)), "pack_and_pqvec": float(m.group(2)), "with_transfers": float(m.group(3))}
+        same = all(open(f"{root}/device/reads.{e}", "rb").read() == open(f"{root}/host/reads.{e}", "rb").read() for e in ("fastb", "qualp", "bci"))
+        return {"pairs": args.pbf_pairs, "workload": f"{args.pbf_pairs} pairs 2x100 bp over a 4.6 Mb genome, fastq.gz, {max(1, args.pbf_pairs // 20)} barcodes, 10 % unbarcoded (BASELINE configs[0]'s shape)",
+                "device_path": res["device"], "host_path": dict(res["host"], threads=args.df_threads), "files_identical": same,
+                "note": "both walls include inflating and line-splitting the two .gz files (one host thread each) and writing the three files; device_ms is what the device path spends in dfk_pbf_run",
+                "fastq_written_in_s": round(t_gen, 1)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def df_stage_wall(args, dev, local):
     """BASELINE.json's other half: the DF stage's wall-clock, measured as SURVEY 8(d) defines it -- process start of
     `DF ROOT=... LR=...` (the unchanged runall.sh:127 command line) to its exit, with every output written.  With the
@@ -426,7 +456,8 @@ def main():
                     help="reads of the sample the CPU baseline (and the parity check) runs on (about 30 s of reference code on 32 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the reported-only legs (K sweep, repeat-rich genome, DF stage wall-clock)")
-    ap.add_argument("--legs", default="ksweep,repeat,rehearsal,df", help="which reported-only legs run (comma list of ksweep, repeat, rehearsal, df)")
+    ap.add_argument("--legs", default="ksweep,repeat,rehearsal,pbf,df", help="which reported-only legs run (comma list of ksweep, repeat, rehearsal, pbf, df)")
+    ap.add_argument("--pbf-pairs", type=int, default=2_000_000, help="pairs of the ParseBarcodedFastqs leg (configs[0] is ~5 M; 2 M keeps the default run short)")
     ap.add_argument("--extra-steps", type=int, default=3, help="timed steps of each reported-only leg")
     ap.add_argument("--family-copies", type=int, default=0,
                     help="plant this many diverged copies of one 300-bp element in the genome (hot minimizer buckets)")
@@ -700,6 +731,13 @@ def main():
             if reh:
                 extra["sharded_rehearsal"] = dict(reh, note="REHEARSAL on one GPU, not a multi-GPU measurement: rank 0 of G against replicas of "
                                                             "itself; the all-to-all is a device copy (a real run hides it under the counts, DESIGN.md section 6)")
+            # row f-3: ParseBarcodedFastqs (the stage in front of DF, runall.sh:125) on a synthetic fastq.gz pair of configs[0]'s shape:
+            # the program's default path (pair order, 2-bit packing, PQVec encoder on the device) beside its own HOST=True path
+            if "pbf" in legs:
+                try:
+                    extra["parse_barcoded_fastqs"] = pbf_leg(args, local)
+                except Exception as e:
+                    extra["parse_barcoded_fastqs"] = {"error": repr(e)}
             try:
                 if "df" not in legs:
                     raise RuntimeError("leg not selected")

@@ -443,6 +443,7 @@ int main(int argc, char** argv)
         auto fits = [&](uint64_t bases, uint64_t pairs) { return !g_mem_limit || 7 * bases / 2 + 200 * pairs + tables <= g_mem_limit; };
         auto pass = [&](const std::vector<uint8_t>& want, const std::vector<uint32_t>& held, size_t u0, size_t u1, bool first0, bool last0) {
             Fastq g1, g2;
+            g1.raw = g2.raw = ctx != nullptr;
             { std::thread t(read_fastq, fq[1], &g2, &want); read_fastq(fq[0], &g1, &want); t.join(); }
             if (!g1.error.empty()) die(g1.error);
             if (!g2.error.empty()) die(g2.error);

@@ -210,3 +210,59 @@ def make_reads(genome, n_pairs, seed, read_len=100, err=0.005, unbar_frac=0.10,
         base_off=torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * nb,
         read_len=torch.full((n_reads,), L, dtype=torch.int32, device=dev),
         pq_bytes=pq, pq_off=pq_off, bc=bc, bci=bci, n_reads=n_reads)
+
+
+def write_fastq_pair(path1, path2, n_pairs, seed, genome_size=4_600_000, read_len=100, err=0.005, unbar_frac=0.10,
+                     pairs_per_barcode=20, threads=8, chunk=100_000):
+    """Seeded synthetic stLFR fastq.gz pair at BASELINE configs[0]'s shape (names "@r<i>#<b1>_<b2>_<b3>/<mate>", barcode 0_0_0 =
+    unbarcoded: split_barcode_PEXXX_42_unsort_reads.pl's format), built as byte matrices in numpy and compressed in chunks by a
+    few threads (concatenated gzip members are one valid .gz).  The input of the ParseBarcodedFastqs legs; harness only."""
+    import gzip
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, genome_size, dtype=np.uint8)
+    L = read_len
+    n_bc = max(1, n_pairs // pairs_per_barcode)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+
+    def digits(v, width):                                               # [n] ints -> [n, width] ASCII digits, zero padded
+        out = np.empty((len(v), width), np.uint8)
+        for k in range(width):
+            out[:, width - 1 - k] = 48 + (v // 10 ** k) % 10
+        return out
+
+    def make_chunk(a):
+        b = min(n_pairs, a + chunk); n = b - a
+        r = np.random.default_rng([seed, a])
+        pos = r.integers(0, genome_size - 2 * L - 400, n)
+        ins = L + r.integers(0, 250, n)
+        bc = r.integers(1, n_bc + 1, n)
+        bc[r.random(n) < unbar_frac] = 0
+        b1, b2, b3 = bc % 1537, (bc // 1537) % 1537, (bc // (1537 * 1537)) % 1537
+        idx = np.arange(a, b)
+        outs = []
+        for mate in (1, 2):
+            start = pos if mate == 1 else pos + ins
+            codes = genome[start[:, None] + np.arange(L)[None, :]]
+            if mate == 2:
+                codes = 3 - codes[:, ::-1]
+            hit = r.random((n, L)) < err
+            codes = np.where(hit, (codes + r.integers(1, 4, (n, L))) & 3, codes).astype(np.uint8)
+            seq = letters[codes]
+            seq[r.random((n, L)) < 0.0005] = ord("N")
+            q = np.repeat(r.choice(np.array([30, 35, 37], np.uint8), n)[:, None], L, axis=1)
+            tail = r.choice(np.array([0, 0, 0, 5, 15]), n)
+            q[np.arange(L)[None, :] >= (L - tail)[:, None]] = 2
+            q[r.random((n, L)) < 0.01] = 20
+            name = np.concatenate([np.full((n, 2), ord("@"), np.uint8), digits(idx, 10), np.full((n, 1), ord("#"), np.uint8), digits(b3, 4),
+                                   np.full((n, 1), ord("_"), np.uint8), digits(b2, 4), np.full((n, 1), ord("_"), np.uint8), digits(b1, 4),
+                                   np.full((n, 1), ord("/"), np.uint8), np.full((n, 1), 48 + mate, np.uint8), np.full((n, 1), 10, np.uint8)], axis=1)
+            name[:, 1] = ord("r")
+            rec = np.concatenate([name, seq, np.full((n, 1), 10, np.uint8), np.full((n, 1), ord("+"), np.uint8), np.full((n, 1), 10, np.uint8),
+                                  (q + 33).astype(np.uint8), np.full((n, 1), 10, np.uint8)], axis=1)
+            outs.append(gzip.compress(rec.tobytes(), compresslevel=1))
+        return outs
+
+    with ThreadPoolExecutor(threads) as ex, open(path1, "wb") as f1, open(path2, "wb") as f2:
+        for o1, o2 in ex.map(make_chunk, range(0, n_pairs, chunk)):
+            f1.write(o1); f2.write(o2)
