@@ -409,6 +409,30 @@ int dfk_shard_dict_share(dfk_ctx* ctx, const void** d_entries, uint64_t* n_entri
 int dfk_shard_dict_adopt(dfk_ctx* ctx, uint64_t n_entries, void** d_room);
 int dfk_shard_dict_whole(dfk_ctx* ctx);
 
+/* ---- rows f-2 / f-4 of a multi-GPU run: every rank holds the whole dictionary (dfk_shard_dict_adopt on every rank) and has built
+ * the same graph; the reads stay sharded by pair range as for the count.  The reference's pathReads is a parallelFor over the reads
+ * (paths/long/BuildReadQGraph48.cc:1420-1442), writePathsIndex a sort of (edge, read) pairs (10X/PathsIndex.cc:23-146), MarkDups a
+ * group-by (10X/SecretOps.cc:410-566); the caller owns the exchanges (csrc/df_shard.h):
+ *   dfk_paths_build(ctx, NULL...)   paths the pair range dfk_shard_begin_host staged (kept under DFK_F_KEEP_INPUTS)
+ *   dfk_paths_var_bytes             this rank's share of a.paths' variable data  <caller: all-gather>
+ *   dfk_paths_write_part            its elements and offset-table entries at their place in the file (rank of read 0: the control block)
+ *   dfk_shard_pidx_pairs            its (edge << 32 | whole-set read id) pairs sorted by edge; send_counts[r] = pairs on the edges
+ *                                   rank r owns (edges [r n / world, (r+1) n / world)); counts_host[n_edges] = its reads per edge
+ *   <caller: all-to-all of the 8-byte pairs; sum of counts_host over the ranks>
+ *   dfk_shard_pidx_write            merges what arrived (stable by edge: sources hold ascending read ranges) and writes this rank's
+ *                                   range of a.paths.inv; rank 0 also a.countsb
+ *   dfk_shard_dup_keys              {key, score} of every placed read grouped by owner rank = hash(key) % world (16 bytes each)
+ *   <caller: all-to-all>            dfk_shard_dup_answer: a byte per received item (1 = not its group's best)  <caller: back>
+ *   dfk_shard_dup_write             marks this rank's pairs and writes their bytes of a.dup (rank of pair 0: the header)
+ * dfk_paths_digest then returns THIS rank's share of the digests: sums add and xors xor over the ranks. */
+int dfk_paths_var_bytes(dfk_ctx* ctx, uint64_t* bytes);
+int dfk_paths_write_part(dfk_ctx* ctx, const char* path, uint64_t first_read, uint64_t total_reads, uint64_t var_before, uint64_t var_total);
+int dfk_shard_pidx_pairs(dfk_ctx* ctx, uint32_t world, const void** d_pairs, uint64_t* send_counts /* [world] */, uint64_t* counts_host /* [n_edges] */);
+int dfk_shard_pidx_write(dfk_ctx* ctx, uint32_t world, uint32_t rank, const void* d_pairs_in, uint64_t n_in, const uint64_t* counts_global /* [n_edges] */, const char* dir);
+int dfk_shard_dup_keys(dfk_ctx* ctx, uint32_t world, const void** d_items, uint64_t* send_counts /* [world], 16-byte items */);
+int dfk_shard_dup_answer(dfk_ctx* ctx, const void* d_items_in, uint64_t n_in, void* d_answers /* u8[n_in] */);
+int dfk_shard_dup_write(dfk_ctx* ctx, const void* d_answers_back, uint64_t n, const char* path, uint64_t first_pair, uint64_t total_pairs, uint64_t* n_marked);
+
 #ifdef __cplusplus
 }
 #endif

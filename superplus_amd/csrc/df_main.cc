@@ -320,10 +320,11 @@ void bind_to_gpu_node(int device)
 // One machine-readable line with the content digests of a.paths / a.paths.inv / a.countsb / a.dup and the graph's identities
 // (dfk_paths_digest): what two runs of a stage this size are compared by (the reference prints hbv.CheckSum() for the same
 // purpose, 10X/DF.cc:598).
-void print_digests(dfk_ctx* ctx)
+void print_digests(dfk_ctx* ctx, const uint64_t* whole_run = nullptr)
 {
     uint64_t w[DFK_CHECK_WORDS] = {};
-    if (dfk_paths_digest(ctx, w)) return;
+    if (whole_run) memcpy(w, whole_run, sizeof w);
+    else if (dfk_paths_digest(ctx, w)) return;
     printf("DF_DIGESTS {\"a.paths\": \"%016llx%016llx\", \"a.paths.inv\": \"%016llx%016llx%016llx\", \"a.countsb\": \"%016llx\", \"a.dup\": \"%016llx\", "
            "\"reads\": %llu, \"placed\": %llu, \"path_edges\": %llu, \"index_entries\": %llu, \"countsb_sum\": %llu, \"self_inverse_entries\": %llu, \"dup_pairs\": %llu, "
            "\"edge_kmers\": %llu, \"solid\": %llu, \"involution_violations\": %llu, \"hbv_edges\": %llu}\n",
@@ -365,6 +366,7 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
         if (!hub) bind_to_gpu_node(cfg.device);
         cfg.minimizer_len = (uint32_t)atoi(a["MINIMIZER"].c_str());
         cfg.hbm_budget_bytes = (uint64_t)(atof(a["HBM_GB"].c_str()) * 1073741824.0);
+        if (truthy(a["GRAPH"]) && truthy(a["PATHS"])) cfg.flags |= DFK_F_KEEP_INPUTS;      // the rank's staged reads stay for pathReads
         if (hub && !cfg.hbm_budget_bytes) { size_t fr = 0, tot = 0; (void)hipSetDevice(cfg.device); (void)hipMemGetInfo(&fr, &tot); cfg.hbm_budget_bytes = (uint64_t)(0.8 * (double)fr / world); }   // ranks sharing one GPU
         dfk_ctx* ctx = nullptr;
         if (dfk_create(&cfg, &ctx)) throw std::runtime_error(dfk_last_error());
@@ -408,31 +410,41 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
         //      1636,1664): the shares go to rank 0, which builds a.<K>/ as the single-GPU run does
         double t_gather = 0, t_graph = 0, t_paths = 0;
         uint64_t g_e = 0, g_v = 0, p_placed = 0;
+        dfkx::ShardPathTimes pt;
         if (truthy(a["GRAPH"])) {
+            // Every rank receives the whole dictionary and builds the same graph (1.4 s at configs[1], deterministic); then the
+            // stage stays sharded: a rank paths ITS pair range, the paths index and the duplicate marks are one all-to-all each
+            // (df_shard.h).  Rank 0 writes the graph's files meanwhile.
             t0 = now_s();
-            dfkx::shard_gather_dict(ctx, *T, 0, piece);
+            dfkx::shard_allgather_dict(ctx, *T, piece);
             t_gather = now_s() - t0;
-            if (rank == 0) {
+            t0 = now_s();
+            if (rank == 0) printf("%s: finding edge sequences.\n", date().c_str());
+            int grc = dfk_graph_build(ctx);
+            const std::string gerr = grc ? dfk_last_error() : "";
+            { uint64_t worst = grc ? (uint64_t)(-grc) : 0; T->all_reduce(&worst, 1, true); if (grc) throw dfkx::ShardError(grc, gerr); if (worst) throw dfkx::ShardError(-(int)worst, "another rank failed building the graph; this rank stops with it"); }
+            const std::string dir = work_dir + "/a." + std::to_string(K);
+            std::string bg_fail;
+            std::thread graph_writer;
+            if (rank == 0) { mkpath(dir); graph_writer = std::thread([&] { if (dfk_graph_write(ctx, dir.c_str())) bg_fail = dfk_last_error(); }); }
+            struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_graph{graph_writer};
+            dfk_graph_stats(ctx, nullptr, &g_v, &g_e);
+            { uint64_t made = 1; T->all_reduce(&made, 1, false); }                             // (the directory exists before anybody writes into it)
+            t_graph = now_s() - t0;
+            if (truthy(a["PATHS"])) {
                 t0 = now_s();
-                printf("%s: finding edge sequences.\n", date().c_str());
-                if (dfk_graph_build(ctx)) throw std::runtime_error(dfk_last_error());
-                const std::string dir = work_dir + "/a." + std::to_string(K);
-                mkpath(dir);
-                if (dfk_graph_write(ctx, dir.c_str())) throw std::runtime_error(dfk_last_error());
-                dfk_graph_stats(ctx, nullptr, &g_v, &g_e);
-                t_graph = now_s() - t0;
-                if (truthy(a["PATHS"])) {
-                    t0 = now_s();
-                    printf("%s: pathing reads\n", date().c_str());
-                    if (dfk_paths_build(ctx, fb.m.p, (const uint64_t*)fb.off_table(), (const uint32_t*)fb.fixed(), qp.m.p, (const uint64_t*)qp.off_table(), fb.n))
-                        throw std::runtime_error(dfk_last_error());
-                    if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());
-                    dfk_paths_stats(ctx, nullptr, &p_placed, nullptr);
-                    if (dfk_paths_index_write(ctx, dir.c_str()) || dfk_dups_write(ctx, (dir + "/a.dup").c_str(), nullptr)) throw std::runtime_error(dfk_last_error());
-                    print_digests(ctx);
-                    t_paths = now_s() - t0;
+                if (rank == 0) printf("%s: pathing reads\n", date().c_str());
+                uint64_t words[DFK_CHECK_WORDS] = {};
+                dfkx::shard_paths_index_dups(ctx, *T, dir, lo, fb.n, piece, &pt, words);
+                p_placed = pt.placed;
+                t_paths = now_s() - t0;
+                if (rank == 0) {
+                    printf("%.2f%% of pairs appear to be duplicates\n", fb.n ? 100.0 * (double)pt.dup_pairs / (double)(fb.n / 2) : 0.0);
+                    print_digests(ctx, words);
                 }
             }
+            if (graph_writer.joinable()) graph_writer.join();
+            if (!bg_fail.empty()) throw std::runtime_error(bg_fail);
         }
         T.reset();
         dfk_destroy(ctx);
@@ -440,9 +452,10 @@ int rank_main(std::map<std::string, std::string>& a, unsigned K, const std::stri
             printf("%s: dictionary covers %llu kmers\n", date().c_str(), (unsigned long long)total);
             printf("DF_TIMING {\"ranks\": %d, \"reads\": %llu, \"kmer_instances\": %llu, \"solid\": %llu, \"rank0\": {\"upload_trim_s\": %.3f, \"plan_s\": %.3f, "
                    "\"partition_s\": %.3f, \"exchange_wait_s\": %.3f, \"count_s\": %.3f, \"adjacency_s\": %.3f, \"create_dict_s\": %.3f, \"spectrum_kvec_write_s\": %.3f, "
-                   "\"bytes_sent_to_peers\": %llu, \"passes\": %u, \"gather_dict_s\": %.3f, \"graph_s\": %.3f, \"paths_s\": %.3f, \"graph_edges\": %llu, \"reads_placed\": %llu, \"rank_total_s\": %.3f}}\n", world, (unsigned long long)fb.n, (unsigned long long)inst,
+                   "\"bytes_sent_to_peers\": %llu, \"passes\": %u, \"gather_dict_s\": %.3f, \"graph_s\": %.3f, \"paths_s\": %.3f, \"path_reads_s\": %.3f, \"paths_write_s\": %.3f, \"paths_index_s\": %.3f, \"mark_dups_s\": %.3f, "
+                   "\"graph_edges\": %llu, \"reads_placed\": %llu, \"rank_total_s\": %.3f}}\n", world, (unsigned long long)fb.n, (unsigned long long)inst,
                    (unsigned long long)total, t_begin, tm.plan, tm.partition, tm.exchange_wait, tm.count, tm.adjacency, tm.total, t_write,
-                   (unsigned long long)tm.bytes_sent, tm.n_passes, t_gather, t_graph, t_paths, (unsigned long long)g_e, (unsigned long long)p_placed, now_s() - t_start);
+                   (unsigned long long)tm.bytes_sent, tm.n_passes, t_gather, t_graph, t_paths, pt.paths, pt.paths_write, pt.index, pt.dups, (unsigned long long)g_e, (unsigned long long)p_placed, now_s() - t_start);
         }
         return 0;
     } catch (const dfkx::ShardError& e) {

@@ -213,4 +213,151 @@ inline uint64_t shard_gather_dict(dfk_ctx* ctx, Transport& T, int root, uint64_t
     return total;
 }
 
+// After shard_create_dict: every rank's share of the dictionary to EVERY rank (world - 1 point-to-point transfers per rank, the
+// same pieces as shard_gather_dict sends to one): each rank then holds the whole dictionary and answers as after a single-GPU
+// count.  What the reference does with the dictionary next -- buildEdges, buildHBVFromEdges -- is 1.4 s of device and host
+// work at configs[1] and deterministic (the HyperBasevector's numbering is canonical, HBVFromEdges.cc:106-111,170-238), so every
+// rank builds the same graph and then paths ITS reads: nothing of the stage is left to one GPU.  99 GB at configs[2] beside a
+// rank's 11 GB of reads.  Returns the number of solid k-mers of the whole run.
+inline uint64_t shard_allgather_dict(dfk_ctx* ctx, Transport& T, uint64_t piece)
+{
+    const int w = T.world, r = T.rank;
+    const void* mine = nullptr; uint64_t n_mine = 0;
+    int pending = dfk_shard_dict_share(ctx, &mine, &n_mine);
+    std::string pending_msg = pending ? dfk_last_error() : "";
+    std::vector<uint64_t> all(w);
+    T.all_gather(&n_mine, 1, all.data());
+    uint64_t total = 0, incoming = 0;
+    std::vector<uint64_t> at(w + 1, 0);                                   // where each source's share lands in the room (sources in rank order, this rank left out)
+    for (int s = 0; s < w; ++s) { total += all[s]; at[s + 1] = at[s] + (s == r ? 0 : all[s]); }
+    incoming = at[w];
+    void* roomp = nullptr;
+    if (!pending) { pending = dfk_shard_dict_adopt(ctx, incoming, &roomp); if (pending) pending_msg = dfk_last_error(); }
+    uint64_t worst = pending ? (uint64_t)(-pending) : 0;
+    T.all_reduce(&worst, 1, true);
+    if (pending) throw ShardError(pending, pending_msg);
+    if (worst) throw ShardError(-(int)worst, "another rank failed gathering the dictionary; this rank stops with it");
+    const uint64_t unit = 32;
+    piece = std::max<uint64_t>(unit, piece / unit * unit);
+    uint64_t largest = 0;
+    for (int s = 0; s < w; ++s) largest = std::max(largest, all[s] * unit);
+    for (uint64_t lo = 0; lo < largest; lo += piece) {
+        T.group_begin();
+        for (int d = 1; d < w; ++d) {
+            const int to = (r + d) % w, from = (r - d + w) % w;
+            const uint64_t sb = n_mine * unit, rb = all[from] * unit;
+            if (lo < sb) T.send((const char*)mine + lo, std::min(piece, sb - lo), to);
+            if (lo < rb) T.recv((char*)roomp + at[from] * unit + lo, std::min(piece, rb - lo), from);
+        }
+        T.group_end();
+    }
+    T.wait();
+    if (dfk_shard_dict_whole(ctx)) throw ShardError(DFK_E_STATE, dfk_last_error());
+    return total;
+}
+
+struct ShardPathTimes { double paths = 0, paths_write = 0, index = 0, dups = 0; uint64_t placed = 0, path_edges = 0, dup_pairs = 0; };
+
+// Rows f-2 and f-4 on every rank (dfk.h, "rows f-2 / f-4 of a multi-GPU run"): the rank's pair range pathed and written into its
+// place in a.paths; the paths index by one all-to-all of (edge, read) pairs to the owners of the edge ranges; the duplicate marks
+// by one all-to-all of keys to the owners of their hash and one of answers back.  first_read / total_reads: this rank's pair
+// range in the whole set.  digest[DFK_CHECK_WORDS]: the whole run's words (sums added, xors xored over the ranks).
+inline void shard_paths_index_dups(dfk_ctx* ctx, Transport& T, const std::string& dir, uint64_t first_read, uint64_t total_reads, uint64_t piece,
+                                   ShardPathTimes* tm, uint64_t* digest)
+{
+    using clock = std::chrono::steady_clock;
+    auto secs = [](clock::time_point a) { return std::chrono::duration<double>(clock::now() - a).count(); };
+    const int w = T.world, r = T.rank;
+    int pending = 0; std::string pending_msg;
+    auto note = [&](int rc) { if (rc && !pending) { pending = rc; pending_msg = dfk_last_error(); } };
+    auto agree = [&](const char* what) {
+        uint64_t worst = pending ? (uint64_t)(-pending) : 0;
+        T.all_reduce(&worst, 1, true);
+        if (pending) throw ShardError(pending, pending_msg);
+        if (worst) throw ShardError(-(int)worst, std::string("another rank failed in ") + what + "; this rank stops with it");
+    };
+    // ---- pathReads on this rank's reads, a.paths in parts
+    auto t0 = clock::now();
+    note(dfk_paths_build(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0));
+    agree("dfk_paths_build");
+    tm->paths = secs(t0);
+    t0 = clock::now();
+    uint64_t mine[3] = {0, 0, 0};
+    note(dfk_paths_var_bytes(ctx, &mine[0]));
+    if (!pending) note(dfk_paths_stats(ctx, nullptr, &mine[1], &mine[2]));
+    std::vector<uint64_t> all(3 * (size_t)w);
+    T.all_gather(mine, 3, all.data());
+    uint64_t var_before = 0, var_total = 0;
+    for (int s = 0; s < w; ++s) { if (s < r) var_before += all[3 * s]; var_total += all[3 * s]; tm->placed += all[3 * s + 1]; tm->path_edges += all[3 * s + 2]; }
+    if (!pending) note(dfk_paths_write_part(ctx, (dir + "/a.paths").c_str(), first_read, total_reads, var_before, var_total));
+    agree("dfk_paths_write_part");
+    tm->paths_write = secs(t0);
+    // ---- writePathsIndex
+    t0 = clock::now();
+    uint64_t n_c = 0, n_v = 0, n_he = 0;
+    note(dfk_graph_stats(ctx, &n_c, &n_v, &n_he));
+    agree("dfk_graph_stats");
+    std::vector<uint64_t> sc(w, 0), rc(w, 0), cnt(n_he, 0), sq((size_t)w * w);
+    const void* pairs = nullptr;
+    note(dfk_shard_pidx_pairs(ctx, (uint32_t)w, &pairs, sc.data(), cnt.data()));
+    agree("dfk_shard_pidx_pairs");
+    T.all_gather(sc.data(), w, sq.data());
+    uint64_t n_in = 0;
+    for (int s = 0; s < w; ++s) { rc[s] = sq[(size_t)s * w + r]; n_in += rc[s]; }
+    if (n_he) T.all_reduce(cnt.data(), (int)n_he, false);                 // reads per edge over all ranks
+    void* d_in = nullptr;
+    if (hipMalloc(&d_in, 8 * n_in + 16) != hipSuccess) { (void)hipGetLastError(); d_in = nullptr; pending = DFK_E_NOMEM; pending_msg = "no room on the device for " + std::to_string(8 * n_in) + " bytes of index pairs"; }
+    try {
+        agree("the paths index's receive buffer");
+        all_to_all_v(T, pairs, sc.data(), d_in, rc.data(), 8, piece);
+        note(dfk_shard_pidx_write(ctx, (uint32_t)w, (uint32_t)r, d_in, n_in, cnt.data(), dir.c_str()));
+        agree("dfk_shard_pidx_write");
+    } catch (...) { (void)hipFree(d_in); throw; }
+    (void)hipFree(d_in);
+    tm->index = secs(t0);
+    // ---- MarkDups
+    t0 = clock::now();
+    const void* items = nullptr;
+    note(dfk_shard_dup_keys(ctx, (uint32_t)w, &items, sc.data()));
+    agree("dfk_shard_dup_keys");
+    T.all_gather(sc.data(), w, sq.data());
+    uint64_t n_q = 0; n_in = 0;
+    for (int s = 0; s < w; ++s) { rc[s] = sq[(size_t)s * w + r]; n_in += rc[s]; n_q += sc[s]; }
+    void *d_items = nullptr, *d_ans = nullptr, *d_back = nullptr;
+    auto room = [&](void** p, uint64_t bytes) {
+        if (pending) return;
+        if (hipMalloc(p, bytes + 16) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; pending = DFK_E_NOMEM; pending_msg = "no room on the device for " + std::to_string(bytes) + " bytes of duplicate keys"; }
+    };
+    room(&d_items, 16 * n_in); room(&d_ans, n_in); room(&d_back, n_q);
+    try {
+        agree("the duplicate marks' buffers");
+        all_to_all_v(T, items, sc.data(), d_items, rc.data(), 16, piece);
+        note(dfk_shard_dup_answer(ctx, d_items, n_in, d_ans));
+        agree("dfk_shard_dup_answer");
+        all_to_all_v(T, d_ans, rc.data(), d_back, sc.data(), 1, piece);
+        uint64_t marked = 0;
+        note(dfk_shard_dup_write(ctx, d_back, n_q, (dir + "/a.dup").c_str(), first_read / 2, total_reads / 2, &marked));
+        agree("dfk_shard_dup_write");
+        T.all_reduce(&marked, 1, false);
+        tm->dup_pairs = marked;
+    } catch (...) { (void)hipFree(d_items); (void)hipFree(d_ans); (void)hipFree(d_back); throw; }
+    (void)hipFree(d_items); (void)hipFree(d_ans); (void)hipFree(d_back);
+    tm->dups = secs(t0);
+    // ---- the run's digests: every rank's share, sums added and xors xored
+    uint64_t wds[DFK_CHECK_WORDS] = {};
+    note(dfk_paths_digest(ctx, wds));
+    agree("dfk_paths_digest");
+    std::vector<uint64_t> every((size_t)DFK_CHECK_WORDS * w);
+    T.all_gather(wds, DFK_CHECK_WORDS, every.data());
+    for (int i = 0; i < DFK_CHECK_WORDS; ++i) digest[i] = 0;
+    for (int s = 0; s < w; ++s) {
+        const uint64_t* x = &every[(size_t)DFK_CHECK_WORDS * s];
+        for (int i : {DFK_CK_PATHS_SUM, DFK_CK_N_READS, DFK_CK_N_PLACED, DFK_CK_N_PATH_EDGES, DFK_CK_INV_SUM, DFK_CK_INV_STARTS, DFK_CK_INV_ENTRIES, DFK_CK_COUNTSB_DIGEST,
+                      DFK_CK_COUNTSB_SUM, DFK_CK_SELF_INVERSE, DFK_CK_DUP_DIGEST, DFK_CK_DUP_MARKED}) digest[i] += x[i];
+        for (int i : {DFK_CK_PATHS_XOR, DFK_CK_INV_XOR}) digest[i] ^= x[i];
+        for (int i : {DFK_CK_EDGE_KMERS, DFK_CK_N_SOLID, DFK_CK_INV_VIOLATIONS, DFK_CK_N_EDGES}) { if (s && digest[i] != x[i]) throw ShardError(DFK_E_STATE, "the ranks built different graphs from one dictionary"); digest[i] = x[i]; }
+        digest[DFK_CK_VALID] = s ? (digest[DFK_CK_VALID] & x[DFK_CK_VALID]) : x[DFK_CK_VALID];
+    }
+}
+
 } // namespace dfkx

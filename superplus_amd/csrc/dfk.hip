@@ -119,6 +119,7 @@ struct dfk_ctx {
     unsigned shard_recv_seq = 0;              //   counted and the one being received under it alternate between the two
     uint64_t budget_taken = 0;                //   ... and the part of the budget they stand for
     void* sh_staged[6] = {};                  // dfk_shard_begin_host: this rank's inputs on the device (hipMalloc, outside the arena)
+    uint64_t sh_b0 = 0, sh_b1 = 0, sh_q0 = 0, sh_q1 = 0, sh_staged_reads = 0;   //   the byte ranges of the whole set's arrays they hold, and how many reads
     DevBuf adj_keys, adj_src; uint64_t adj_n = 0;
     DevBuf set; uint64_t set_mask = 0;
     uint32_t shard_world = 1, shard_log2_nb = 0;
@@ -2226,4 +2227,5 @@ int dfk_get_stats(dfk_ctx* c, dfk_stats* out)
 #include "dfk_shard.inc"
 #include "dfk_graph.inc"
 #include "dfk_paths.inc"
+#include "dfk_paths_shard.inc"
 #include "dfk_pbf.inc"

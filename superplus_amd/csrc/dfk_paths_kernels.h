@@ -706,8 +706,8 @@ constexpr int32_t DUP_OFF_BIAS = 1 << 16;
 __device__ __forceinline__ uint64_t dup_hash(uint64_t k) { k ^= k >> 31; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 29; k *= 0xBF58476D1CE4E5B9ull; return k ^ (k >> 32); }
 // key of read r of the batch, or DUP_EMPTY if it has no path; *score = what atomicMax compares
 __device__ __forceinline__ uint64_t dup_key(const uint32_t* __restrict__ var, const uint32_t* __restrict__ elem_off, uint64_t i, uint64_t nb, uint64_t r0,
-                                            uint64_t var_bytes, const uint32_t* __restrict__ digest, uint64_t* score, unsigned int* bad)
-{
+                                            uint64_t var_bytes, const uint32_t* __restrict__ digest, uint64_t* score, unsigned int* bad, uint64_t id_bias = 0)
+{   // (id_bias: a rank of a sharded run numbers its reads from 0; the tie among equal quality sums goes to the lowest id of the WHOLE set)
     const uint64_t w0 = elem_off[i] >> 2, w1 = (i + 1 < nb ? (uint64_t)elem_off[i + 1] : var_bytes) >> 2;
     if (w1 - w0 <= 2) return DUP_EMPTY;
     const int32_t off = (int32_t)var[w0];
@@ -715,7 +715,7 @@ __device__ __forceinline__ uint64_t dup_key(const uint32_t* __restrict__ var, co
     const uint64_t id = r0 + i, mate = id ^ 1ull;
     if (e >= (1u << 29) || off < -DUP_OFF_BIAS || off >= (1 << 25) - DUP_OFF_BIAS) { atomicOr(bad, 1u); return DUP_EMPTY; }
     const uint32_t dm = digest[mate], ds = digest[id];
-    *score = ((uint64_t)((ds >> 10) + (dm >> 10)) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)id);
+    *score = ((uint64_t)((ds >> 10) + (dm >> 10)) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(id + id_bias));
     return ((uint64_t)e << 35) | ((uint64_t)(uint32_t)(off + DUP_OFF_BIAS) << 10) | (uint64_t)(dm & 1023u);
 }
 template <bool MARK>

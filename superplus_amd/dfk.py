@@ -28,6 +28,7 @@ EXPORTS = [
     "dfk_shard_dict_share", "dfk_shard_dict_adopt", "dfk_shard_dict_whole",
     "dfk_paths_build", "dfk_paths_build_device", "dfk_paths_stats", "dfk_paths_write", "dfk_paths_fetch", "dfk_paths_index_write", "dfk_dups_write",
     "dfk_paths_digest", "dfk_paths_verify", "dfk_paths_verify_device", "dfk_pbf_run", "dfk_pbf_result", "dfk_pbf_free",
+    "dfk_paths_var_bytes", "dfk_paths_write_part", "dfk_shard_pidx_pairs", "dfk_shard_pidx_write", "dfk_shard_dup_keys", "dfk_shard_dup_answer", "dfk_shard_dup_write",
 ]
 
 # dfk_paths_digest's words (include/dfk.h, DFK_CK_*) and dfk_paths_verify's counters

@@ -277,9 +277,38 @@ def test_df_num_gpus_cpp_host(tmp_path, golden_dir, oracle, mode):
     for ext in ("fastb", "qualp", "bci"):
         assert rd(f"{w}/data/frag_reads_orig.{ext}") == rd(f"{golden_dir}/reads.{ext}"), ext
     assert "DF_TIMING {" in r.stdout and f"dictionary covers {len(exp['solid_post'])}" in r.stdout.replace(",", "")
-    # GRAPH defaults to True: the shares are gathered on rank 0, which builds a.48/ -- graph and read paths -- as a single-GPU run does
+    # GRAPH defaults to True: every rank receives the whole dictionary and builds the graph; the reads stay sharded -- each rank paths
+    # its pair range and writes its part of a.paths -- and the files are the single-GPU run's, byte for byte
     for f in ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right", "a.paths"):
         assert rd(f"{w}/a.48/{f}") == rd(f"{golden_dir}/graph_k48/{f}"), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rccl1", "loopback2", "loopback4"])
+def test_df_num_gpus_paths_index_and_dups_stay_sharded(tmp_path, golden_dir, mode):
+    """Rows f-2 and f-4 of `DF NUM_GPUS=N` on the fragmented fixture (1816 edges, PCR-duplicate pairs): every rank paths its own
+    pair range and writes its part of a.paths; the (edge, read) pairs travel to the owners of the edge ranges, each of which
+    writes its range of a.paths.inv; the duplicate keys travel to the owners of their hash and the marks come back -- all twelve
+    files as the reference's own writers wrote them, and the digests the ranks add up are the single-GPU run's."""
+    env = dict(os.environ)
+    if mode == "rccl1":
+        args, env["DF_FORCE_SHARDED"] = ["NUM_GPUS=1"], "1"
+    else:
+        args, env["DF_TRANSPORT"] = [f"NUM_GPUS={mode[-1]}"], "loopback"
+        env["DFK_A2A_PIECE_BYTES"] = "4096"
+    r = subprocess.run([DF, f"ROOT={tmp_path}/s", f"LR={golden_dir}/frag.fastb", "PIPELINE=cs", "ALIGN=False", "NUM_THREADS=8", "HBM_GB=8", *args],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rd = lambda p: open(p, "rb").read()
+    for f in sorted(os.listdir(f"{golden_dir}/graph_frag_k48")):
+        if f.startswith("a."):
+            assert rd(f"{tmp_path}/s/GapToy/1/a.48/{f}") == rd(f"{golden_dir}/graph_frag_k48/{f}"), f
+    one = subprocess.run([DF, f"ROOT={tmp_path}/o", f"LR={golden_dir}/frag.fastb", "PIPELINE=cs", "ALIGN=False", "NUM_THREADS=8", "HBM_GB=8"],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    dig = lambda out: [l for l in out.splitlines() if l.startswith("DF_DIGESTS ")]
+    assert dig(r.stdout) and dig(r.stdout) == dig(one.stdout)
+    assert '"path_reads_s"' in r.stdout                                   # rank 0's DF_TIMING carries the sharded phases
 
 
 def test_df_stops_every_rank_when_one_dies(tmp_path, golden_dir):
@@ -328,5 +357,12 @@ def test_df_num_gpus_larger_set_equals_single_gpu(tmp_path, oracle):
     util.assert_same_solid(_sorted_kvec(f"{tmp_path}/four/kmers.kvec"), _sorted_kvec(f"{tmp_path}/one/kmers.kvec"), "four ranks against one GPU")
     ref = oracle.run(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"], K=48)
     util.assert_same_solid(_sorted_kvec(f"{tmp_path}/four/kmers.kvec"), ref["solid"], "four ranks against the oracle")
+    # ... and a.48/: graph, read paths (each rank its pair range), paths index (each rank its edge range), duplicate marks
+    files = sorted(f for f in os.listdir(f"{tmp_path}/one/a.48") if f.startswith("a."))
+    assert {"a.hbv", "a.paths", "a.paths.inv", "a.countsb", "a.dup"} <= set(files)
+    for f in files:
+        assert open(f"{tmp_path}/one/a.48/{f}", "rb").read() == open(f"{tmp_path}/four/a.48/{f}", "rb").read(), f
+    dig = lambda out: [l for l in out.splitlines() if l.startswith("DF_DIGESTS ")]
+    assert dig(a.stdout) and dig(a.stdout) == dig(b.stdout)
     for f in ("a.k", "a.fastb", "a.hbv", "a.hbx", "a.kmers", "a.inv", "a.to_left", "a.to_right", "a.paths"):      # gathered on rank 0 = built on one GPU
         assert open(f"{tmp_path}/four/a.48/{f}", "rb").read() == open(f"{tmp_path}/one/a.48/{f}", "rb").read(), f
