@@ -675,6 +675,34 @@ def main():
                 except Exception as e:
                     sweep[str(K2)] = {"error": repr(e)}
             extra["k_sweep"] = sweep
+            # rows f-1 / f-2 / f-4 of a sharded run, rehearsed on one GPU: every rank builds the whole graph, then paths ITS pair range
+            # and sorts / groups ITS share of the pairs and keys (df_shard.h).  Here: the whole set counted, the graph built, then
+            # rank 0's share at G = 2 and 8 -- the first 1/G of the reads pathed over the whole graph, their index pairs sorted, their
+            # duplicates marked.  No exchange (a real run adds one all-to-all of 8-byte pairs and one of 16-byte keys).
+            if "rehearsal" in legs:
+                fr = {}
+                try:
+                    d4 = Dfk(**kw)
+                    d4.count_device(*shard)
+                    n_all = rs.n_reads
+                    for Gr in (1, 2, 8):
+                        t1 = time.perf_counter(); g4 = d4.graph_build(); torch.cuda.synchronize(); t_graph = time.perf_counter() - t1
+                        n = (n_all // 2 // Gr) * 2
+                        nb, nq = int(rs.base_off[n].item()), int(rs.pq_off[n].item())
+                        t1 = time.perf_counter()
+                        p4 = d4.paths_build_device(rs.packed[:nb + 8], rs.base_off[: n + 1], rs.read_len[:n], rs.pq_bytes[:nq + 8], rs.pq_off[: n + 1])
+                        t_paths = time.perf_counter() - t1
+                        t1 = time.perf_counter(); d4.paths_index_write(None); t_index = time.perf_counter() - t1
+                        t1 = time.perf_counter(); d4.dups_write(None); t_dups = time.perf_counter() - t1
+                        fr[str(Gr)] = {"reads_of_this_rank": n, "graph_s": round(t_graph, 3), "path_reads_s": round(t_paths, 3), "paths_index_s": round(t_index, 3),
+                                       "mark_dups_s": round(t_dups, 3), "reads_placed": p4["n_placed"], "graph_edges": g4["n_edges"]}
+                    d4.close()
+                    extra["f_rows_rehearsal"] = dict(fr, note="REHEARSAL on one GPU, not a multi-GPU measurement: the device time of rank 0's share of rows f-1 (whole graph, every rank), "
+                                                              "f-2 (its reads) and f-4 (its pairs and keys) at G ranks, no files written, no exchange; G = 1 is the whole set")
+                except Exception as e:
+                    extra["f_rows_rehearsal"] = dict(fr, error=repr(e))
+                    d4 = None
+                torch.cuda.synchronize(); torch.cuda.empty_cache()
             del shard, rs
             torch.cuda.empty_cache()
             # a genome with repeats: ~10 % in one diverged 300-bp family, 1 % microsatellites; a quarter of the reads
