@@ -188,6 +188,26 @@ def make_pathy(seed, G=9000, n_pairs=2600):
     return reads, quals, bci
 
 
+def make_pathy2(seed, n_blocks=9, G1=9000, pairs_per_block=1300):
+    """The pather's second input: n_blocks independent genomes of make_pathy's kind (each with its own SNP bubbles, repeat family,
+    tandem repeat and K-1 repeat with its eight switching reads), and in every block a ninth of the reads with a tail of 25-45
+    random bases of HIGH quality -- the path ends before the tail, the overhang is long and no edge at the end vertex explains
+    it.  Made so that every one of the 16 rules of algorithmTwo / the extensions fires at least 50 times (pathy2_rules.txt)."""
+    rng = np.random.default_rng(seed)
+    reads, quals = [], []
+    for b in range(n_blocks):
+        r, q, _ = make_pathy(seed * 100 + b, G1, pairs_per_block)
+        for i in range(60, len(r), 9):
+            L = len(r[i]); t = int(rng.integers(25, 46))
+            r[i] = r[i].copy(); r[i][L - t:] = rng.integers(0, 4, t); q[i] = q[i].copy(); q[i][L - t:] = 37
+        reads += r; quals += q
+    n_pairs = len(reads) // 2
+    n_unbar = n_pairs // 10
+    bcs = np.sort(np.concatenate([np.zeros(n_unbar, int), rng.integers(1, 60, n_pairs - n_unbar)]))
+    bci = np.concatenate([[0], np.cumsum(np.bincount(bcs, minlength=60) * 2)]).astype(np.int64)
+    return reads, quals, bci
+
+
 def make_frag(seed, G=26000, n_pairs=3000):
     """A fragmented graph (a SNP every ~70 bases of a diploid genome: more than 870 HBV edges, below which the reference's
     writePathsIndex overruns) read by PAIRS of 100 bases with inserts of 250-400, a tenth of the pairs PCR duplicates of an
@@ -355,6 +375,23 @@ def main():
     post, ne = run_graph(pa, os.path.join(HERE, "tmp_gpa"), 48, 1, 2, 3, os.path.join(HERE, "graph_pathy_k48"))
     np.savez_compressed(os.path.join(HERE, "expect_pathy_k48.npz"), solid_post=post)
     print("graph pathy: solid", len(post), "HBV edges", ne)
+    # ... and a second, larger one on which every rule fires at least 50 times (the round-3 review: three rules fired < 10 times on
+    # pathy); with the files of row f-4 as well
+    reads, quals, bci = make_pathy2(7)
+    raw = os.path.join(HERE, "pathy2.raw")
+    write_raw(raw, reads, quals)
+    pa2 = os.path.join(HERE, "pathy2")
+    subprocess.check_call([REFDRV, "mkreads", raw, pa2], stdout=subprocess.DEVNULL)
+    os.remove(raw)
+    feudal.write_bci(pa2 + ".bci", bci)
+    os.makedirs(os.path.join(HERE, "tmp_rules"), exist_ok=True)
+    rules = [l for l in refdrv("graph", 48, pa2, os.path.join(HERE, "tmp_rules"), 7, 3, 2, 1, 4, 0).splitlines() if l.startswith(("paths:", "graph:"))]
+    open(os.path.join(HERE, "pathy2_rules.txt"), "w").write("".join(l + "\n" for l in rules))
+    assert all(int(l.rsplit(None, 1)[1]) >= 50 for l in rules if l.startswith("paths:   ")), rules
+    subprocess.check_call(["rm", "-rf", os.path.join(HERE, "tmp_rules")])
+    post, ne = run_graph(pa2, os.path.join(HERE, "tmp_gpa2"), 48, 1, 2, 3, os.path.join(HERE, "graph_pathy2_k48"), extra=("a.paths.inv", "a.countsb", "a.dup"))
+    np.savez_compressed(os.path.join(HERE, "expect_pathy2_k48.npz"), solid_post=post)
+    print("graph pathy2: solid", len(post), "HBV edges", ne)
     # Row f-4: a fragmented graph (more than 870 edges: below that the reference's writePathsIndex overruns, SURVEY 8c caveat 1)
     # read by pairs with PCR duplicates: a.paths.inv, a.countsb, a.dup
     reads, quals, bci = make_frag(9, 26000, 3000)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 KW = {"graph_k48": dict(min_bc=2), "graph_k40_nobc": dict(min_bc=0, nobc=True), "graph_k60_nobc": dict(min_bc=0, nobc=True),
       "graph_hot_k48_minfreq2": dict(min_freq=2), "graph_special_k48": dict(min_bc=0, nobc=True), "graph_pathy_k48": dict(min_bc=2),
-      "graph_frag_k48": dict(min_bc=2)}
+      "graph_frag_k48": dict(min_bc=2), "graph_pathy2_k48": dict(min_bc=2)}
 
 
 def explain(got, exp):

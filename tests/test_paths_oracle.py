@@ -15,7 +15,7 @@ from tests.test_oracle_golden import load_hot, load_inputs
 CASES = [("graph_k48", 48, "expect_k48.npz", "reads"), ("graph_k40_nobc", 40, "expect_k40_nobc.npz", "reads"),
          ("graph_k60_nobc", 60, "expect_k60_nobc.npz", "reads"), ("graph_hot_k48_minfreq2", 48, "expect_hot_k48_minfreq2.npz", "hot"),
          ("graph_special_k48", 48, "expect_special_k48_nobc.npz", "special"), ("graph_pathy_k48", 48, "expect_pathy_k48.npz", "pathy"),
-         ("graph_frag_k48", 48, "expect_frag_k48.npz", "frag")]
+         ("graph_frag_k48", 48, "expect_frag_k48.npz", "frag"), ("graph_pathy2_k48", 48, "expect_pathy2_k48.npz", "pathy2")]
 
 
 def load_named(golden_dir, name):
@@ -64,6 +64,13 @@ def test_pathy_fixture_reaches_every_rule(golden_dir):
             name, n = line[9:].rsplit(None, 1)
             rules[name.strip()] = int(n)
     assert len(rules) == 16 and all(v > 0 for v in rules.values()), rules
+    # ... and on the larger pathy2 input at least 50 times each (three of them fired fewer than ten times on pathy)
+    rules2 = {}
+    for line in open(os.path.join(golden_dir, "pathy2_rules.txt")):
+        if line.startswith("paths:   "):
+            name, n = line[9:].rsplit(None, 1)
+            rules2[name.strip()] = int(n)
+    assert set(rules2) == set(rules) and all(v >= 50 for v in rules2.values()), rules2
 
 
 def test_score_truncates_like_unsigned_minus_double():
@@ -79,6 +86,18 @@ def test_score_truncates_like_unsigned_minus_double():
         edge2 = bytes([1, 0, 1] + [0] * 60)
         q2 = np.array([q0, 30, 10] + [30] * 17, np.uint8)
         assert paths_oracle.Pather.score(read, q2, 20, edge2, 1, False) == q0 + after + 10
+
+
+def test_paths_index_and_dups_of_the_larger_pather_input(golden_dir):
+    """The same three files for pathy2 (3184 edges, 30995 path entries, reads that cross an edge twice)."""
+    solid = np.load(os.path.join(golden_dir, "expect_pathy2_k48.npz"))["solid_post"]
+    g = graph_oracle.run(solid, 48)
+    reads, quals = paths_oracle.unpack_reads(load_reads(golden_dir, "pathy2"))
+    r = paths_oracle.run(reads, quals, g, 48)
+    files = paths_oracle.paths_index(r["paths"], g["hbv"].involution())
+    files["a.dup"] = paths_oracle.mark_dups(r["paths"], reads, quals)
+    for f, b in files.items():
+        assert b == open(os.path.join(golden_dir, "graph_pathy2_k48", f), "rb").read(), f
 
 
 def test_paths_index_and_dups_match_reference_files(golden_dir):

@@ -19,6 +19,7 @@ EXPECT = {
     "graph_special_k48": [700, 0, 37036, 37036, 0, 700, 0, 64],
     "graph_pathy_k48": [3357, 0, 146851, 146029, 0, 3302, 0, 1947],
     "graph_frag_k48": [5634, 0, 232037, 223901, 0, 5277, 0, 15832],
+    "graph_pathy2_k48": [18556, 0, 772254, 757058, 0, 17781, 0, 27569],
 }
 
 
