@@ -685,7 +685,7 @@ def main():
                     d4 = Dfk(**kw)
                     d4.count_device(*shard)
                     n_all = rs.n_reads
-                    for Gr in (1, 2, 8):
+                    for Gr in (8, 2):
                         t1 = time.perf_counter(); g4 = d4.graph_build(); torch.cuda.synchronize(); t_graph = time.perf_counter() - t1
                         n = (n_all // 2 // Gr) * 2
                         nb, nq = int(rs.base_off[n].item()), int(rs.pq_off[n].item())
@@ -698,7 +698,7 @@ def main():
                                        "mark_dups_s": round(t_dups, 3), "reads_placed": p4["n_placed"], "graph_edges": g4["n_edges"]}
                     d4.close()
                     extra["f_rows_rehearsal"] = dict(fr, note="REHEARSAL on one GPU, not a multi-GPU measurement: the device time of rank 0's share of rows f-1 (whole graph, every rank), "
-                                                              "f-2 (its reads) and f-4 (its pairs and keys) at G ranks, no files written, no exchange; G = 1 is the whole set")
+                                                              "f-2 (its reads) and f-4 (its pairs and keys) at G ranks, no files written, no exchange (G = 1, the whole set, is what df_stage times)")
                 except Exception as e:
                     extra["f_rows_rehearsal"] = dict(fr, error=repr(e))
                     d4 = None
