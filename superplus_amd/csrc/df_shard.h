@@ -228,30 +228,14 @@ inline uint64_t shard_allgather_dict(dfk_ctx* ctx, Transport& T, uint64_t piece)
     std::vector<uint64_t> all(w);
     T.all_gather(&n_mine, 1, all.data());
     uint64_t total = 0, incoming = 0;
-    std::vector<uint64_t> at(w + 1, 0);                                   // where each source's share lands in the room (sources in rank order, this rank left out)
-    for (int s = 0; s < w; ++s) { total += all[s]; at[s + 1] = at[s] + (s == r ? 0 : all[s]); }
-    incoming = at[w];
+    for (int s = 0; s < w; ++s) { total += all[s]; if (s != r) incoming += all[s]; }
     void* roomp = nullptr;
     if (!pending) { pending = dfk_shard_dict_adopt(ctx, incoming, &roomp); if (pending) pending_msg = dfk_last_error(); }
     uint64_t worst = pending ? (uint64_t)(-pending) : 0;
     T.all_reduce(&worst, 1, true);
     if (pending) throw ShardError(pending, pending_msg);
     if (worst) throw ShardError(-(int)worst, "another rank failed gathering the dictionary; this rank stops with it");
-    const uint64_t unit = 32;
-    piece = std::max<uint64_t>(unit, piece / unit * unit);
-    uint64_t largest = 0;
-    for (int s = 0; s < w; ++s) largest = std::max(largest, all[s] * unit);
-    for (uint64_t lo = 0; lo < largest; lo += piece) {
-        T.group_begin();
-        for (int d = 1; d < w; ++d) {
-            const int to = (r + d) % w, from = (r - d + w) % w;
-            const uint64_t sb = n_mine * unit, rb = all[from] * unit;
-            if (lo < sb) T.send((const char*)mine + lo, std::min(piece, sb - lo), to);
-            if (lo < rb) T.recv((char*)roomp + at[from] * unit + lo, std::min(piece, rb - lo), from);
-        }
-        T.group_end();
-    }
-    T.wait();
+    all_gather_v(T, mine, all.data(), roomp, 32, piece);
     if (dfk_shard_dict_whole(ctx)) throw ShardError(DFK_E_STATE, dfk_last_error());
     return total;
 }

@@ -431,7 +431,7 @@ int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2
     // and K = 60, whose window of 45 hashes and 45 positions the compiler keeps in scratch, not in registers: 593 ms
     // against the LDS version's ~400 (k_sweep of the bench; K = 40: 510 ms at 165 VGPRs, as fast as the LDS version)
     static const bool old_scan = getenv("DFK_OLD_SCAN") != nullptr;
-    constexpr bool window_fits_registers = K - 16 + 1 <= 33;
+    constexpr bool window_fits_registers = K - 16 + 1 <= 45;           // (all three K since the positions are packed four to a register)
     if (grid && pp.M == 16 && window_fits_registers && !old_scan) {
         const size_t lds_r = sizeof(uint32_t) * (PART_RING + SUMMARY_RUNS) * PART_THREADS + (by_class ? n_bins * 4 : 0);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_count<(window_fits_registers ? K : 48), 16>), dim3(grid), dim3(PART_THREADS), lds_r, c->stream,

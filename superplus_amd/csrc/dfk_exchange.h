@@ -69,6 +69,30 @@ inline void all_to_all_v(Transport& T, const void* send, const uint64_t* send_co
     if (wait) T.wait();
 }
 
+// Every rank's `mine` (counts[rank] units) to every other rank: what arrives is laid out by source rank, THIS rank's own share
+// left out (the caller already holds it), in `recv` -- the dictionary of a sharded run going to every rank (df_shard.h).  The same
+// rounds of point-to-point pieces as all_to_all_v; counts[] is what every rank holds (exchange it with all_gather first).
+inline void all_gather_v(Transport& T, const void* mine, const uint64_t* counts, void* recv, uint64_t unit, uint64_t piece, bool wait = true)
+{
+    const int w = T.world, r = T.rank;
+    std::vector<uint64_t> at(w + 1, 0);
+    for (int s = 0; s < w; ++s) at[s + 1] = at[s] + (s == r ? 0 : counts[s] * unit);
+    piece = std::max<uint64_t>(unit, piece / unit * unit);
+    uint64_t largest = 0;
+    for (int s = 0; s < w; ++s) largest = std::max(largest, counts[s] * unit);
+    for (uint64_t lo = 0; lo < largest; lo += piece) {
+        T.group_begin();
+        for (int d = 1; d < w; ++d) {
+            const int to = (r + d) % w, from = (r - d + w) % w;
+            const uint64_t sb = counts[r] * unit, rb = counts[from] * unit;
+            if (lo < sb) T.send((const char*)mine + lo, std::min(piece, sb - lo), to);
+            if (lo < rb) T.recv((char*)recv + at[from] + lo, std::min(piece, rb - lo), from);
+        }
+        T.group_end();
+    }
+    if (wait) T.wait();
+}
+
 // ---- all ranks as threads of one process: the messages are memory copies made by the receiver once both sides have
 // posted.  `copy` moves the bytes (memcpy for host memory; a device-to-device copy when the ranks share a GPU).
 struct LoopbackHub {

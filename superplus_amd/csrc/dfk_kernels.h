@@ -2,6 +2,7 @@
 // Integer/hash work only: no MFMA anywhere.  See DESIGN.md for the data layout in HBM and
 // the roofline of each kernel.
 #pragma once
+#include <type_traits>
 #include "dfk_device.h"
 
 namespace dfk {
@@ -447,6 +448,12 @@ k_partition(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uin
 // a run is closed by two register moves and an LDS store -- its bucket counter is bumped after the read's last base, in
 // a loop all lanes walk together -- where the per-base version paid the whole close (atomic, class mask, summary field)
 // as a divergent block in almost every step: among 64 reads some run ends nearly everywhere.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 template <int K, int M>
 __global__ void __launch_bounds__(PART_THREADS)
 k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
@@ -501,7 +508,15 @@ k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const ui
             uint32_t f = 0, rc = 0;
             for (int j = 0; j < M - 1; ++j) { const uint32_t b = next_base(); f = ((f << 2) | b) & mmask; rc = (rc >> 2) | ((3u - b) << rsh); }
             const uint32_t n_mmers = gl - M + 1;                         // m-mer positions t = 0 .. n_mmers-1; k-mer s = t-W+1 is complete at t >= W-1
-            uint32_t arr[W], sidx[W];                                    // suffix minima of the previous block (and where they sit), overwritten by the hashes of this one
+            // suffix minima of the previous block, overwritten by the hashes of this one -- and where they sit, a BYTE each, four
+            // to a register (every index is a constant once the block loop is unrolled: a field extract / insert).  With a word
+            // per position the two arrays are 2W registers: 66 at K=48, and 90 at K=60, which the compiler kept in scratch --
+            // 593 ms against the LDS-window scan's 430 (round 3); packed they are W + W/4 = 57.
+            uint32_t arr[W], sidxw[(W + 3) / 4];
+            auto sidx_get = [&](int i) -> uint32_t { return (sidxw[i >> 2] >> (8 * (i & 3))) & 255u; };
+            auto sidx_set = [&](int i, uint32_t v) { const uint32_t sh = 8u * (uint32_t)(i & 3); sidxw[i >> 2] = (sidxw[i >> 2] & ~(255u << sh)) | (v << sh); };
+#pragma unroll
+            for (int i = 0; i < (W + 3) / 4; ++i) sidxw[i] = 0;
             uint32_t P = 0, Pi = 0;
             uint32_t cur_b = 0, cur_nk = 0, cur_rel = 0;
             auto close_run = [&]() {                                     // (cheap on purpose: see the head of this kernel)
@@ -520,9 +535,11 @@ k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const ui
                 ++qn;
             };
             for (uint32_t t0 = 0; t0 < n_mmers; t0 += W) {              // one block of W m-mer positions; t = t0 + bi
-#pragma unroll
-                for (int bi = 0; bi < W; ++bi) {
-                    if (t0 + (uint32_t)bi < n_mmers) {                       // (no break: the loop must unroll for arr[] / sidx[] to be registers)
+                // (expanded by template recursion, not `#pragma unroll`: at W = 45 the optimizer declines the pragma and arr[] goes
+                // to scratch; every index below must be a constant for arr[] / sidxw[] to be registers)
+                static_for<0, W>([&](auto bi_c) {
+                    constexpr int bi = decltype(bi_c)::value;
+                    if (t0 + (uint32_t)bi < n_mmers) {
                         const uint32_t b = next_base();
                         f = ((f << 2) | b) & mmask;
                         rc = (rc >> 2) | ((3u - b) << rsh);
@@ -534,24 +551,26 @@ k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const ui
                         if (!first || bi == W - 1) {                      // a k-mer ends here
                             uint32_t mv = P;
                             bool older = false;
-                            if (bi != W - 1) { older = arr[bi + 1] < mv; mv = older ? arr[bi + 1] : mv; }
+                            if constexpr (bi != W - 1) { older = arr[bi + 1] < mv; mv = older ? arr[bi + 1] : mv; }
                             const uint32_t bucket = bucket_of(mv, pp);
                             const bool open = first || bucket != cur_b || cur_nk == (uint32_t)KTraits<K>::NK_MAX;
                             if (open) {
                                 if (!first) close_run();
                                 cur_b = bucket; cur_nk = 1;
-                                cur_rel = (bi != W - 1 && older) ? sidx[bi + 1] - (uint32_t)bi - 1u : (uint32_t)(W - 1 - bi) + Pi;
+                                cur_rel = (bi != W - 1 && older) ? sidx_get(bi + 1 < W ? bi + 1 : 0) - (uint32_t)bi - 1u : (uint32_t)(W - 1 - bi) + Pi;
                             } else ++cur_nk;
                         }
                         arr[bi] = h;
                         if (bi == W - 1) {                                // block complete: its hashes become suffix minima
                             uint32_t run = h, ri = W - 1;
-                            sidx[W - 1] = W - 1;
-#pragma unroll
-                            for (int i = W - 2; i >= 0; --i) { const bool lt = arr[i] < run; run = lt ? arr[i] : run; arr[i] = run; ri = lt ? (uint32_t)i : ri; sidx[i] = ri; }
+                            sidx_set(W - 1, W - 1);
+                            static_for<0, W - 1>([&](auto j_c) {
+                                constexpr int i = W - 2 - decltype(j_c)::value;
+                                const bool lt = arr[i] < run; run = lt ? arr[i] : run; arr[i] = run; ri = lt ? (uint32_t)i : ri; sidx_set(i, ri);
+                            });
                         }
                     }
-                }
+                });
             }
             close_run();
         }

@@ -51,9 +51,45 @@ static int run(int world, uint64_t unit, uint64_t piece, unsigned seed)
     return fails;
 }
 
+// all_gather_v: every rank's share arrives at every other rank at its place (sources in rank order, the receiver's own left out)
+static int run_gather(int world, uint64_t unit, uint64_t piece, unsigned seed)
+{
+    dfkx::LoopbackHub hub(world);
+    std::mt19937 rng(seed);
+    std::vector<uint64_t> counts(world);
+    for (int r = 0; r < world; ++r) counts[r] = rng() % 50;
+    if (world > 1) counts[world - 1] = 0;                                              // a rank with nothing to give
+    std::vector<int> bad(world, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r)
+        th.emplace_back([&, r] {
+            dfkx::LoopbackTransport T(hub, r);
+            std::vector<uint8_t> mine(counts[r] * unit + 1, 0);
+            for (uint64_t s = 0; s < counts[r]; ++s) for (uint64_t k = 0; k < unit; ++k) mine[s * unit + k] = (uint8_t)(r * 37 + s * 3 + k);
+            std::vector<uint64_t> all(world);
+            T.all_gather(&counts[r], 1, all.data());
+            uint64_t incoming = 0; for (int s = 0; s < world; ++s) { if (all[s] != counts[s]) ++bad[r]; if (s != r) incoming += counts[s]; }
+            std::vector<uint8_t> room(incoming * unit + 1, 0xEE);
+            dfkx::all_gather_v(T, mine.data(), all.data(), room.data(), unit, piece);
+            uint64_t at = 0;
+            for (int s = 0; s < world; ++s) {
+                if (s == r) continue;
+                for (uint64_t k = 0; k < counts[s]; ++k, ++at) for (uint64_t j = 0; j < unit; ++j) if (room[at * unit + j] != (uint8_t)(s * 37 + k * 3 + j)) { ++bad[r]; break; }
+            }
+            if (room[incoming * unit] != 0xEE) ++bad[r];
+        });
+    for (auto& t : th) t.join();
+    int fails = 0; for (int b : bad) fails += b;
+    printf("gather: world %d unit %llu piece %llu: %s\n", world, (unsigned long long)unit, (unsigned long long)piece, fails ? "FAILED" : "ok");
+    return fails;
+}
+
 int main()
 {
     int fails = 0;
+    for (int world : {1, 2, 3, 4, 8})
+        for (uint64_t piece : {(uint64_t)1 << 30, (uint64_t)64, (uint64_t)32})
+            fails += run_gather(world, 32, piece, 300 + world);
     for (int world : {1, 2, 3, 4, 8})
         for (uint64_t piece : {(uint64_t)1 << 30, (uint64_t)96, (uint64_t)40, (uint64_t)32})
             fails += run(world, 32, piece, 100 + world);

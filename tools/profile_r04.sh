@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 tools/profile_gpu.sh r04
 python3 tools/summarize_prof.py r04 > gpurun_out/prof_r04/summary.txt
 T=$(ls -t gpurun_out/prof_r04/trace/*/*_kernel_trace.csv 2>/dev/null | head -1)
-[ -n "$T" ] && python3 tools/timeline.py "$T" > profiles/r04_timeline.txt || echo "no kernel trace kept" > profiles/r04_timeline.txt
+[ -n "$T" ] && python3 tools/timeline.py gpurun_out/prof_r04/trace > profiles/r04_timeline.txt || echo "no kernel trace kept" > profiles/r04_timeline.txt
 mkdir -p gpurun_out/pbf_prof
 python3 -c "
 from superplus_amd import synth
