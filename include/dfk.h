@@ -261,9 +261,10 @@ int dfk_paths_fetch(dfk_ctx* ctx, int32_t* offsets, uint64_t* first_edge, int32_
  * dfk_dups_write         MarkDups (10X/SecretOps.cc:410-566): a.dup, one byte per PAIR -- reads with the same first edge, offset
  *                        and first five bases of their mate are duplicates; the one whose pair has the highest quality sum (the
  *                        lowest read id among equals) stays.  Grouped in a hash table on the device instead of sorted. */
-/* Limits, refused loudly (DFK_E_ARG) rather than wrapped: fewer than 2^32 path entries over all reads (the index sorts pairs of
- * 32-bit words; the reference's PathsIndex.cc is 64-bit throughout), fewer than 2^29 HBV edges and offsets within +-2^24 (the
- * duplicate key).  dir / path NULL: everything but the files (dfk_paths_digest). */
+/* The index is built one range of edges at a time when the room is short or the paths hold 2^31 entries or more (the
+ * reference's 30 chunk files, PathsIndex.cc:32-99, are the same idea): no limit on the number of path entries.  Limits, refused
+ * loudly (DFK_E_ARG) rather than wrapped: fewer than 2^32 reads on any ONE edge, fewer than 2^29 HBV edges and offsets within
+ * +-2^24 (the duplicate key).  dir / path NULL: everything but the files (dfk_paths_digest). */
 int dfk_paths_index_write(dfk_ctx* ctx, const char* dir);
 int dfk_dups_write(dfk_ctx* ctx, const char* path, uint64_t* n_marked_pairs);
 

@@ -617,6 +617,42 @@ k_pidx_pairs(const uint32_t* __restrict__ var, const uint32_t* __restrict__ elem
     }
 }
 
+// the same per edge RANGE [e0, e1) (the index is built range by range when the whole would not fit, or holds 2^32 entries or
+// more): how many of a read's entries lie in the range, then -- at the exclusive scan of those counts, so that the reads stay
+// in order -- the pairs themselves, keyed by edge - e0
+__global__ void __launch_bounds__(256)
+k_pidx_count(const uint32_t* __restrict__ var, const uint32_t* __restrict__ elem_off, uint64_t nb, uint64_t var_bytes, uint32_t* __restrict__ counts)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t w0 = elem_off[i] >> 2, w1 = (i + 1 < nb ? (uint64_t)elem_off[i + 1] : var_bytes) >> 2;
+        for (uint64_t w = w0 + 2; w < w1; ++w) atomicAdd(&counts[var[w]], 1u);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_pidx_range_count(const uint32_t* __restrict__ var, const uint32_t* __restrict__ elem_off, uint64_t nb, uint64_t var_bytes, uint32_t e0, uint32_t e1, uint64_t* __restrict__ n_in /* [nb + 1] */)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i <= nb; i += (uint64_t)gridDim.x * 256) {
+        uint64_t n = 0;
+        if (i < nb) {
+            const uint64_t w0 = elem_off[i] >> 2, w1 = (i + 1 < nb ? (uint64_t)elem_off[i + 1] : var_bytes) >> 2;
+            for (uint64_t w = w0 + 2; w < w1; ++w) { const uint32_t e = var[w]; n += e >= e0 && e < e1; }
+        }
+        n_in[i] = n;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_pidx_range_pairs(const uint32_t* __restrict__ var, const uint32_t* __restrict__ elem_off, uint64_t nb, uint64_t r0, uint64_t var_bytes, uint32_t e0, uint32_t e1,
+                   const uint64_t* __restrict__ at_of /* exclusive scan of n_in */, uint64_t pair_base, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t w0 = elem_off[i] >> 2, w1 = (i + 1 < nb ? (uint64_t)elem_off[i + 1] : var_bytes) >> 2;
+        // (at_of == nullptr: the range is every edge -- the read's first entry is entry w0 - 2 i of the batch, every element before it
+        // having spent two words on offset and lastSkip)
+        uint64_t at = pair_base + (at_of ? at_of[i] : w0 - 2 * i);
+        for (uint64_t w = w0 + 2; w < w1; ++w) { const uint32_t e = var[w]; if (e >= e0 && e < e1) { keys[at] = e - e0; vals[at] = (uint32_t)(r0 + i); ++at; } }
+    }
+}
+
 // Stable LSD radix sort of (edge, read) pairs by edge, eight bits a pass.  A tile is RS_ROUNDS x 64 consecutive pairs and
 // belongs to ONE wave, which takes it round by round: the lanes with the same digit find each other by eight ballots, rank
 // themselves by lane, and a counter per digit in the wave's own LDS carries the rank from round to round -- index order is

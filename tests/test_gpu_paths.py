@@ -91,6 +91,29 @@ def test_paths_need_a_graph(oracle):
     d.close()
 
 
+@pytest.mark.parametrize("case,which", [("graph_frag_k48", "frag"), ("graph_pathy2_k48", "pathy2")])
+def test_paths_index_built_in_ranges_of_edges(golden_dir, tmp_path, monkeypatch, case, which):
+    """The paths index built a range of edges at a time (what a set with 2^31 path entries or more, or short room, makes it do):
+    forced here with ranges of a few hundred entries -- dozens of ranges, some of one heavy edge -- the same two files, the same
+    digests as in one piece."""
+    from superplus_amd.dfk import Dfk
+    rs = load_reads(golden_dir, which)
+    words = []
+    for cap in (None, "700", "40"):
+        if cap: monkeypatch.setenv("DFK_PIDX_RANGE_PAIRS", cap)
+        d = Dfk(K=48, keep_inputs=True)
+        d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+        d.graph_build(); d.paths_build()
+        out = os.path.join(tmp_path, cap or "whole"); os.makedirs(out)
+        d.paths_index_write(out)
+        for f in ("a.paths.inv", "a.countsb"):
+            assert open(os.path.join(out, f), "rb").read() == open(os.path.join(golden_dir, case, f), "rb").read(), f"{f} ranges of {cap}"
+        ck = d.paths_digest()
+        words.append({k: ck[k] for k in ("INV_SUM", "INV_XOR", "INV_STARTS", "INV_ENTRIES", "COUNTSB_DIGEST", "COUNTSB_SUM", "SELF_INVERSE")})
+        d.close()
+    assert words[0] == words[1] == words[2]
+
+
 def test_paths_index_and_dups_match_reference_fixture(golden_dir, tmp_path):
     """Row f-4 through the ABI on the fragmented fixture (1816 edges, PCR-duplicate pairs): a.paths.inv and a.countsb
     (writePathsIndex, written on the reference side by IncrementalWriter<ULongVec> / BinaryWriter) and a.dup (MarkDups)."""
