@@ -43,10 +43,16 @@ def _run(shard, passes=0):
 
 
 def test_graph_paths_index_dups_at_bench_size(monkeypatch):
+    import gc, time
     dev = torch.device("cuda", 0)
-    free, _ = torch.cuda.mem_get_info(dev)
-    if free < 240e9:
-        pytest.skip("needs a whole MI355X (%.0f GB free)" % (free / 1e9))
+    # (what an earlier test of this process held goes back to the driver first, and the driver wipes released memory before it
+    # hands it out again -- tens of GB a second: wait for it rather than skip)
+    gc.collect(); torch.cuda.empty_cache()
+    for _ in range(60):
+        free, _ = torch.cuda.mem_get_info(dev)
+        if free >= 200e9: break
+        time.sleep(1.0); torch.cuda.empty_cache()
+    assert free >= 200e9, "needs most of an MI355X (%.0f GB free)" % (free / 1e9)
     genome = synth.make_genome(G, 20261104, device=dev)
     rs = synth.make_reads(genome, PAIRS, 20261121)
     del genome
