@@ -125,6 +125,10 @@ struct dfk_ctx {
     uint32_t shard_world = 1, shard_log2_nb = 0;
     void* shard_state = nullptr;              // bucket table + count state kept between the passes of a sharded run
     void (*shard_state_free)(void*) = nullptr;
+    // transfer lanes (pinned double buffers + a stream each) are kept between transfers: a streamed a.paths is 184 batches, each a
+    // transfer of its own, and pinning 8 x 4 MiB and making streams for every one of them cost more than moving the bytes
+    void* lane_pool = nullptr; void (*lane_pool_free)(void*) = nullptr;
+    std::mutex lane_mu;
     void* graph_state = nullptr;              // the graph built from the last count (dfk_graph.inc)
     void (*graph_state_free)(void*) = nullptr;
     // DFK_F_KEEP_INPUTS: the device copies dfk_count made of the caller's reads (hipMalloc, outside the arena), kept for
@@ -1704,19 +1708,38 @@ struct XferLane { void* pin[2] = {nullptr, nullptr}; hipStream_t st = nullptr; h
 // fin(t, lane) once per thread when the chunks have run out.  The first non-zero return stops the rest.
 using XferBody = std::function<int(unsigned, XferLane&, uint64_t)>;
 using XferFin = std::function<int(unsigned, XferLane&)>;
+struct LanePool { std::vector<XferLane> idle; };
+void lane_destroy(XferLane& l)
+{
+    for (int k = 0; k < 2; ++k) { if (l.pin[k]) (void)hipHostFree(l.pin[k]); if (l.ev[k]) (void)hipEventDestroy(l.ev[k]); }
+    if (l.st) (void)hipStreamDestroy(l.st);
+    l = XferLane{};
+}
+void lane_pool_delete(void* p) { LanePool* P = (LanePool*)p; for (XferLane& l : P->idle) lane_destroy(l); delete P; }
+int lane_create(XferLane& l)
+{
+    for (int k = 0; k < 2; ++k) {
+        if (hipHostMalloc(&l.pin[k], XFER_CHUNK, hipHostMallocDefault) != hipSuccess) return fail(DFK_E_NOMEM, "cannot pin %zu bytes of host memory for transfers", XFER_CHUNK);
+        if (hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming) != hipSuccess) return fail(DFK_E_HIP, "hipEventCreate failed");
+    }
+    if (hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess) return fail(DFK_E_HIP, "hipStreamCreate failed");
+    return 0;
+}
+
 int xfer_run(dfk_ctx* c, uint64_t n_chunks, const XferBody& body, const XferFin& fin = nullptr)
 {
     const unsigned T = (unsigned)std::min<uint64_t>(n_chunks, xfer_threads());
     if (!T) return 0;
+    // lanes: from the context's pool (several transfers may run side by side, each with lanes of its own), made when it has none
     std::vector<XferLane> lanes(T);
     int rc = 0;
-    for (XferLane& l : lanes) {
-        for (int k = 0; k < 2 && !rc; ++k) {
-            if (hipHostMalloc(&l.pin[k], XFER_CHUNK, hipHostMallocDefault) != hipSuccess) rc = fail(DFK_E_NOMEM, "cannot pin %zu bytes of host memory for transfers", XFER_CHUNK);
-            else if (hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming) != hipSuccess) rc = fail(DFK_E_HIP, "hipEventCreate failed");
-        }
-        if (!rc && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess) rc = fail(DFK_E_HIP, "hipStreamCreate failed");
+    {
+        std::lock_guard<std::mutex> g(c->lane_mu);
+        if (!c->lane_pool) { c->lane_pool = new LanePool; c->lane_pool_free = lane_pool_delete; }
+        LanePool* P = (LanePool*)c->lane_pool;
+        for (XferLane& l : lanes) if (!P->idle.empty()) { l = P->idle.back(); P->idle.pop_back(); }
     }
+    for (XferLane& l : lanes) if (!rc && !l.st) rc = lane_create(l);
     std::atomic<uint64_t> next{0};
     std::atomic<int> err{0};
     std::string err_msg;
@@ -1734,9 +1757,14 @@ int xfer_run(dfk_ctx* c, uint64_t n_chunks, const XferBody& body, const XferFin&
         for (std::thread& x : th) x.join();
         if (err.load()) { rc = err.load(); g_err = err_msg; }
     }
-    for (XferLane& l : lanes) {
-        for (int k = 0; k < 2; ++k) { if (l.pin[k]) (void)hipHostFree(l.pin[k]); if (l.ev[k]) (void)hipEventDestroy(l.ev[k]); }
-        if (l.st) (void)hipStreamDestroy(l.st);
+    {   // idle again (every lane's stream has been waited for): back to the pool, which keeps a few
+        std::lock_guard<std::mutex> g(c->lane_mu);
+        LanePool* P = (LanePool*)c->lane_pool;
+        for (XferLane& l : lanes) {
+            if (!l.st || !l.pin[0] || !l.pin[1] || !l.ev[0] || !l.ev[1] || P->idle.size() >= 24) { lane_destroy(l); continue; }
+            l.turn = 0;
+            P->idle.push_back(l);
+        }
     }
     return rc;
 }
@@ -1921,6 +1949,7 @@ void dfk_destroy(dfk_ctx* c)
     c->release_all();
     c->drop_kept();
     c->drop_pool();
+    if (c->lane_pool) { c->lane_pool_free(c->lane_pool); c->lane_pool = nullptr; }
     if (c->d_resident) (void)hipFree(c->d_resident);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
