@@ -301,6 +301,18 @@ def pbf_leg(args, local):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def cgroup_cpu_stat():
+    """/sys/fs/cgroup/cpu.stat of this process's cgroup as {name: int} ({} where there is none)."""
+    try:
+        rel = open("/proc/self/cgroup").read().strip().split("::", 1)[1].strip()
+        for d in ("/sys/fs/cgroup" + rel, "/sys/fs/cgroup"):
+            if os.path.exists(d + "/cpu.stat"):
+                return {a: int(b) for a, b in (l.split() for l in open(d + "/cpu.stat"))}
+    except Exception:
+        pass
+    return {}
+
+
 def df_stage_wall(args, dev, local):
     """BASELINE.json's other half: the DF stage's wall-clock, measured as SURVEY 8(d) defines it -- process start of
     `DF ROOT=... LR=...` (the unchanged runall.sh:127 command line) to its exit, with every output written.  With the
@@ -365,9 +377,11 @@ def df_stage_wall(args, dev, local):
                 elif args.df_gpus <= 1: env["DF_FORCE_SHARDED"] = "1"
             if os.environ.get("DF_TASKSET"): cmd = ["taskset", "-c", os.environ["DF_TASKSET"]] + cmd      # (an experiment's switch: bind the stage's threads)
             time.sleep(wait_s)
+            cpu0 = cgroup_cpu_stat()
             t0 = time.perf_counter(); e0 = time.time()
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
             wall = time.perf_counter() - t0; e1 = time.time()
+            cpu1 = cgroup_cpu_stat()
             if os.environ.get("DFK_TRACE") and os.path.isdir(os.path.join(ROOT, "gpurun_out")):      # the child's trace, for whoever asked for it
                 with open(os.path.join(ROOT, "gpurun_out", "df_child_trace.txt"), "a") as f: f.write(r.stderr)
             w = root + "/GapToy/1"
@@ -389,7 +403,9 @@ def df_stage_wall(args, dev, local):
             out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(w) for f in fs
                             if not (linked and os.stat(os.path.join(dp, f)).st_nlink > 1))
             shutil.rmtree(root + "/GapToy", ignore_errors=True)
-            return {"wall_s": round(wall, 3), "waited_before_s": round(wait_s, 1), "pairs": n_pairs, "timing": timing, "digests": digests, "output_bytes": out_bytes,
+            # the CPU time the run took in all its threads, and how long the cgroup's CPU quota held them back (cpu.stat deltas)
+            cpu = {k[:-5] + "_s": round((cpu1[k] - cpu0[k]) / 1e6, 3) for k in ("usage_usec", "user_usec", "system_usec", "throttled_usec") if k in cpu0 and k in cpu1}
+            return {"wall_s": round(wall, 3), "waited_before_s": round(wait_s, 1), "pairs": n_pairs, "timing": timing, "digests": digests, "output_bytes": out_bytes, "cpu": cpu,
                     "frag_reads_orig": "hard links to the inputs (LINK_READS=True: byte-identical files, no second copy in RAM)" if linked else "copies of the inputs (the reference's default)"}
 
         cold = run_stage(root + "/reads", pairs, link, 0.0)                              # started at once, behind the harness's own release
@@ -397,6 +413,14 @@ def df_stage_wall(args, dev, local):
         # (the child has just released its own ~270 GB: the same wait again before the run that is the headline)
         main = run_stage(root + "/reads", pairs, link, quiesce)
         if "error" in main: return main
+        # an experiment's switch: more runs on the same files, each with its own environment ("A=1,B=2;C=3"), to gpurun_out/df_variants.txt
+        for spec in filter(None, os.environ.get("DF_VARIANTS", "").split(";")):
+            saved = dict(env)
+            env.update(kv.split("=", 1) for kv in spec.split(",") if "=" in kv)
+            v = run_stage(root + "/reads", pairs, link, quiesce)
+            env.clear(); env.update(saved)
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                with open(os.path.join(ROOT, "gpurun_out", "df_variants.txt"), "a") as f: f.write(json.dumps({"env": spec, "wall_s": v.get("wall_s"), "cpu": v.get("cpu"), "timing": v.get("timing"), "error": v.get("error")}) + "\n")
         for e in (".fastb", ".qualp", ".bci"): os.unlink(root + "/reads" + e)
         copies = run_stage(root + "/half", pairs_c, False, quiesce) if have_c else None
         wall, timing = main["wall_s"], main["timing"]
@@ -417,6 +441,7 @@ def df_stage_wall(args, dev, local):
                 "device_quiesce_s": round(quiesce, 1),   # waited before the stage started: the driver wiping what the previous process had released
                 "host_memory": dict(mem, estimated_need=int(2 * pairs * (per_read_link if link else per_read_copy))),
                 "kmers_per_s_whole_stage": (timing.get("kmer_instances", 0) / wall) if wall > 0 else None,
+                "cpu_time": main.get("cpu"),             # CPU seconds over all threads / seconds the cgroup's CPU quota held them back
                 "breakdown_s": {k: timing.get(k) for k in ("spawn_to_main_s", "open_validate_s", "ingest_outputs_s", "upload_s", "count_s",
                                                            "spectrum_kvec_write_s", "qual_hist_s", "destroy_s", "background_join_s", "total_s", "exit_to_reaped_s")},
                 "graph": ({"graph_s": timing.get("graph_s"), "device_s": timing.get("graph_device_s"), "host_s": timing.get("graph_host_s"),

@@ -87,7 +87,7 @@ typedef struct dfk_stats {
      * context's stream */
     float ms_upload, ms_trim, ms_part_count, ms_part_scatter, ms_count, ms_fallback, ms_adjacency, ms_total;
     uint64_t hbm_bytes_peak;    /* peak device bytes held by the context */
-    uint64_t reserved[8];       /* [0] = passes used */
+    uint64_t reserved[8];       /* [0] = passes used, [1..3] = microseconds (graph device, graph host, pathing), [4] = gate timeouts, [5] = device bytes held now */
 } dfk_stats;
 
 typedef struct dfk_ctx dfk_ctx;

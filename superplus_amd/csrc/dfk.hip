@@ -15,6 +15,7 @@
 #include <new>
 #include <string>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <condition_variable>
 #include <memory>
@@ -55,6 +56,7 @@ struct DevBuf {
 
 bool g_trace = getenv("DFK_TRACE") != nullptr;
 #define TRACE(...) do { if (g_trace) { fprintf(stderr, "[dfk] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+inline double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // LDS table geometry per K (DESIGN.md "count kernel"): slots and waves per workgroup
 template <int K> struct CountCfg;
@@ -2247,6 +2249,7 @@ int dfk_get_stats(dfk_ctx* c, dfk_stats* out)
         unsigned int t = 0;
         if (hipMemcpy(&t, c->d_resident + 1, 4, hipMemcpyDeviceToHost) == hipSuccess) c->st.reserved[4] = t;
     }
+    c->st.reserved[5] = c->held;                                             // device bytes the context holds right now
     *out = c->st;
     return 0;
 }

@@ -66,6 +66,7 @@ class Stats(C.Structure):
         d["n_passes"] = int(self.reserved[0])
         d["us_graph_device"], d["us_graph_host"], d["us_paths"] = int(self.reserved[1]), int(self.reserved[2]), int(self.reserved[3])
         d["gate_timeouts"] = int(self.reserved[4])
+        d["hbm_held"] = int(self.reserved[5])
         return d
 
 
