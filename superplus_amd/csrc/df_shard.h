@@ -230,7 +230,18 @@ inline uint64_t shard_allgather_dict(dfk_ctx* ctx, Transport& T, uint64_t piece)
     uint64_t total = 0, incoming = 0;
     for (int s = 0; s < w; ++s) { total += all[s]; if (s != r) incoming += all[s]; }
     void* roomp = nullptr;
-    if (!pending) { pending = dfk_shard_dict_adopt(ctx, incoming, &roomp); if (pending) pending_msg = dfk_last_error(); }
+    if (!pending) {
+        pending = dfk_shard_dict_adopt(ctx, incoming, &roomp);
+        if (pending) {
+            pending_msg = dfk_last_error();
+            // (graph, paths, index and duplicate marks need the whole dictionary on every rank: say what the way out is)
+            if (pending == DFK_E_NOMEM) {
+                char more[256];
+                snprintf(more, sizeof more, " -- the whole dictionary (%.1f GB) does not fit beside this rank's reads: GRAPH=False KVEC=True leaves the sharded kmers.kvec instead", 32e-9 * (double)total);
+                pending_msg += more;
+            }
+        }
+    }
     uint64_t worst = pending ? (uint64_t)(-pending) : 0;
     T.all_reduce(&worst, 1, true);
     if (pending) throw ShardError(pending, pending_msg);

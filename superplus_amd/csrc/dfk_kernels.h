@@ -2214,7 +2214,7 @@ k_set_insert_list(const uint4* __restrict__ entries, const uint32_t* __restrict_
     const uint4 a = entries[2 * (uint64_t)list[t]];
     const uint64_t w0 = (uint64_t)a.x | ((uint64_t)a.y << 32), w1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
     uint64_t s = set_hash(w0, w1) & mask;
-    for (;;) {
+    for (uint64_t step = 0; step <= mask; ++step) {                      // (the host sizes the set at load <= 0.6; a full one must still let every wave end)
         unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&set[s].w0), ~0ull, (unsigned long long)w0);
         if (old == ~0ull) { set[s].w1 = w1; return; }
         s = (s + 1) & mask;
