@@ -87,7 +87,7 @@ typedef struct dfk_stats {
      * context's stream */
     float ms_upload, ms_trim, ms_part_count, ms_part_scatter, ms_count, ms_fallback, ms_adjacency, ms_total;
     uint64_t hbm_bytes_peak;    /* peak device bytes held by the context */
-    uint64_t reserved[8];       /* [0] = passes used, [1..3] = microseconds (graph device, graph host, pathing), [4] = gate timeouts, [5] = device bytes held now */
+    uint64_t reserved[8];       /* [0] = passes used, [1..3] = microseconds (graph device, graph host, pathing), [4] = gate timeouts, [5] = device bytes held now, [6] = launches of the counting scan */
 } dfk_stats;
 
 typedef struct dfk_ctx dfk_ctx;
@@ -133,7 +133,10 @@ int dfk_hint_file_range(dfk_ctx* ctx, const void* base, uint64_t bytes, int fd, 
  * (monotone, last offset <= the array size, base_off[r+1]-base_off[r] >= ceil(read_len[r]/4)) and a violation is
  * DFK_E_INPUT.  packed_bases need not start at the first read (a mapped .fastb file with its absolute offset table
  * is a valid input).  Device arrays: packed_bases 4-byte aligned and readable up to 3 bytes past packed_bytes (the
- * 2-bit stream is read as aligned 32-bit words); the offset tables 8-byte aligned. */
+ * 2-bit stream is read as aligned 32-bit words); the offset tables 8-byte aligned.
+ * From host buffers the qualities and tables are uploaded first and the bases last, in pieces (from 1 GB of bases on): the
+ * trim runs beside the first piece and the counting scan follows the pieces, so that upload and count overlap by what the
+ * two take (0.4 s at configs[1]); the result does not depend on it (dfk_stats.reserved[6]: launches of the scan). */
 int dfk_count(dfk_ctx* ctx,
               const uint8_t* packed_bases, const uint64_t* base_off, const uint32_t* read_len,
               const uint8_t* pq_bytes, const uint64_t* pq_off, const int32_t* bc,

@@ -124,6 +124,7 @@ struct dfk_ctx {
     uint64_t sh_b0 = 0, sh_b1 = 0, sh_q0 = 0, sh_q1 = 0, sh_staged_reads = 0;   //   the byte ranges of the whole set's arrays they hold, and how many reads
     DevBuf adj_keys, adj_src; uint64_t adj_n = 0;
     DevBuf set; uint64_t set_mask = 0;
+    double t_upload_done = 0;                 // wall_now() when the last piece of the bases had arrived (run_under_upload)
     uint32_t shard_world = 1, shard_log2_nb = 0;
     void* shard_state = nullptr;              // bucket table + count state kept between the passes of a sharded run
     void (*shard_state_free)(void*) = nullptr;
@@ -407,87 +408,133 @@ int table_totals(dfk_ctx* c, const DevBuf& acc, uint64_t nb, uint64_t* n_records
     return 0;
 }
 
-template <int K>
-int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, BucketTable* T, bool by_class = false)
+// The counting scan in three steps, so that a caller whose reads are still arriving (count_host: the scan runs under the upload
+// of the bases) can run it a range of reads at a time: begin (tables, zeroed), range (a launch over reads [r0, r1)), end (the
+// overflow list, the totals, the check against the trim's instance count).  partition_count is all three over every read.
+struct ScanJob {
+    PartParams pp; uint64_t nb = 0, n_bins = 0, ovf_cap = 0; bool by_class = false, ranged = false;
+    DevBuf ovf_tmp, d_n;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;                  // a pair per launch: ms_part_count is their sum
+    ~ScanJob() { for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
+};
+
+// (the register scan takes ranges; the general scan -- other minimizer lengths, DFK_OLD_SCAN -- only everything at once)
+template <int K> bool scan_takes_ranges(const dfk_ctx* c)
 {
-    const PartParams pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 1u << (T->log2_nb - log2_world));
-    const uint64_t nb = 1ull << T->log2_nb;
+    static const bool old_scan = getenv("DFK_OLD_SCAN") != nullptr;
+    return c->cfg.minimizer_len == 16 && !old_scan;
+}
+
+template <int K>
+int scan_begin(dfk_ctx* c, const Inputs& in, uint32_t log2_world, int64_t read_id0, BucketTable* T, bool by_class, ScanJob* J)
+{
+    J->pp = part_params<K>(c, T->log2_nb, log2_world, read_id0, 0, 1u << (T->log2_nb - log2_world));
+    J->nb = 1ull << T->log2_nb; J->by_class = by_class;
     int rc = 0;
-    const uint64_t n_bins = 2ull * (PART_CLASSES << log2_world);
-    if (by_class) { rc = c->alloc(T->class_hist, n_bins * 8, "class counters", true); if (rc) return rc; HIP_TRY(hipMemsetAsync(T->class_hist.p, 0, n_bins * 8, c->stream)); }
-    else { rc = c->alloc(T->acc, nb * 8, "bucket counters", true); if (rc) return rc; }
+    J->n_bins = 2ull * (PART_CLASSES << log2_world);
+    if (by_class) { rc = c->alloc(T->class_hist, J->n_bins * 8, "class counters", true); if (rc) return rc; HIP_TRY(hipMemsetAsync(T->class_hist.p, 0, J->n_bins * 8, c->stream)); }
+    else { rc = c->alloc(T->acc, J->nb * 8, "bucket counters", true); if (rc) return rc; }
     rc = c->alloc(T->summ, std::max<uint64_t>(1, in.n_reads) * 16, "run summaries", true); if (rc) return rc;
     rc = c->alloc(T->classes, read_classes_bytes(std::max<uint64_t>(1, in.n_reads)), "read bucket classes", true); if (rc) return rc;
-    if (!by_class) HIP_TRY(hipMemsetAsync(T->acc.p, 0, nb * 8, c->stream));
-    unsigned grid = (unsigned)((in.n_reads + PART_THREADS - 1) / PART_THREADS);
+    if (!by_class) HIP_TRY(hipMemsetAsync(T->acc.p, 0, J->nb * 8, c->stream));
+    // reads whose runs do not fit a summary are listed by the scan itself (two in 10^5 at 2x100 bp); if the list
+    // outgrows the room set aside for it the summaries are searched instead
+    J->ovf_cap = in.n_reads / 16 + 1024;
+    rc = c->alloc(J->ovf_tmp, J->ovf_cap * 4, "overflow read list (scratch)"); if (rc) return rc;
+    rc = c->alloc(J->d_n, 16, "overflow read count"); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(J->d_n.p, 0, 16, c->stream));
+    return 0;
+}
+
+template <int K>
+int scan_range(dfk_ctx* c, const Inputs& in, BucketTable* T, ScanJob* J, uint64_t r0, uint64_t r1)
+{
+    if (r1 <= r0) return 0;
+    const PartParams& pp = J->pp;
+    const bool by_class = J->by_class;
+    unsigned grid = (unsigned)((r1 - r0 + PART_THREADS - 1) / PART_THREADS);
     static const unsigned scan_blocks = getenv("DFK_SCAN_BLOCKS") ? (unsigned)atoi(getenv("DFK_SCAN_BLOCKS")) : 0;
     if (by_class) grid = std::min<unsigned>(grid, (scan_blocks ? scan_blocks : 128u) * (unsigned)c->prop.multiProcessorCount);   // grid-stride: class counts are flushed once per block (12 blocks per CU: 57 ms per 225 M reads, 128: 47 ms)
     else if (scan_blocks) grid = std::min<unsigned>(grid, scan_blocks * (unsigned)c->prop.multiProcessorCount);
-    const size_t lds_a = (sizeof(uint32_t) + 1) * pp.W * PART_THREADS + sizeof(uint32_t) * PART_RING * PART_THREADS + (by_class ? n_bins * 4 : 0);
-    Timer t(c->stream);
-    t.start();
-    // reads whose runs do not fit a summary are listed by the scan itself (two in 10^5 at 2x100 bp); if the list
-    // outgrows the room set aside for it the summaries are searched instead
-    DevBuf ovf_tmp, d_n;
-    const uint64_t ovf_cap = in.n_reads / 16 + 1024;
-    rc = c->alloc(ovf_tmp, ovf_cap * 4, "overflow read list (scratch)"); if (rc) return rc;
-    rc = c->alloc(d_n, 16, "overflow read count"); if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
-    // the minimizer length everybody uses gets the scan whose window lives in registers; other lengths the general one --
-    // and K = 60, whose window of 45 hashes and 45 positions the compiler keeps in scratch, not in registers: 593 ms
-    // against the LDS version's ~400 (k_sweep of the bench; K = 40: 510 ms at 165 VGPRs, as fast as the LDS version)
-    static const bool old_scan = getenv("DFK_OLD_SCAN") != nullptr;
-    constexpr bool window_fits_registers = K - 16 + 1 <= 45;           // (all three K since the positions are packed four to a register)
-    if (grid && pp.M == 16 && window_fits_registers && !old_scan) {
-        const size_t lds_r = sizeof(uint32_t) * (PART_RING + SUMMARY_RUNS) * PART_THREADS + (by_class ? n_bins * 4 : 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_count<(window_fits_registers ? K : 48), 16>), dim3(grid), dim3(PART_THREADS), lds_r, c->stream,
-                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.n_reads, pp,
-                           (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p, (unsigned long long*)d_n.p, ovf_cap,
-                           (uint32_t*)ovf_tmp.p, (uint4*)T->summ.p, (uint32_t*)T->classes.p);
-    } else if (grid)
+    const size_t lds_a = (sizeof(uint32_t) + 1) * pp.W * PART_THREADS + sizeof(uint32_t) * PART_RING * PART_THREADS + (by_class ? J->n_bins * 4 : 0);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    J->ev.emplace_back(e0, e1);
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    // the minimizer length everybody uses gets the scan whose window lives in registers (all three K since the positions are
+    // packed four to a register); other lengths the general one
+    if (scan_takes_ranges<K>(c)) {
+        const size_t lds_r = sizeof(uint32_t) * (PART_RING + SUMMARY_RUNS) * PART_THREADS + (by_class ? J->n_bins * 4 : 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_count<K, 16>), dim3(grid), dim3(PART_THREADS), lds_r, c->stream,
+                           in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, r0, r1, pp,
+                           (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p, (unsigned long long*)J->d_n.p, J->ovf_cap,
+                           (uint32_t*)J->ovf_tmp.p, (uint4*)T->summ.p, (uint32_t*)T->classes.p);
+    } else {
+        if (r0 != 0 || r1 != in.n_reads) return fail(DFK_E_STATE, "the general scan takes every read at once");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_partition<K, false>), dim3(grid), dim3(PART_THREADS), lds_a, c->stream,
                            in.packed, in.packed_bytes, in.base_off, (const uint32_t*)c->good_len.p, in.bc,
                            (int64_t)c->cfg.ign_bc_below, in.n_reads, pp, (unsigned long long*)T->acc.p, (unsigned long long*)T->class_hist.p,
-                           (unsigned long long*)d_n.p, ovf_cap, (uint4*)ovf_tmp.p, (uint4*)T->summ.p,
+                           (unsigned long long*)J->d_n.p, J->ovf_cap, (uint4*)J->ovf_tmp.p, (uint4*)T->summ.p,
                            (const uint32_t*)nullptr, (uint64_t)0, (const uint64_t*)nullptr, (uint32_t*)T->classes.p);
+    }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    return 0;
+}
+
+template <int K>
+int scan_end(dfk_ctx* c, const Inputs& in, uint64_t n_inst, BucketTable* T, ScanJob* J)
+{
+    int rc = 0;
     T->n_ovf = 0;
     if (in.n_reads) {
-        HIP_TRY(hipMemcpyAsync(&T->n_ovf, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&T->n_ovf, J->d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (T->n_ovf > ovf_cap) {                                       // long reads: most summaries overflow
-            c->release(ovf_tmp);
-            rc = c->alloc(ovf_tmp, in.n_reads * 4, "overflow read list (scratch)"); if (rc) return rc;
-            HIP_TRY(hipMemsetAsync(d_n.p, 0, 16, c->stream));
+        if (T->n_ovf > J->ovf_cap) {                                    // long reads: most summaries overflow
+            c->release(J->ovf_tmp);
+            rc = c->alloc(J->ovf_tmp, in.n_reads * 4, "overflow read list (scratch)"); if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(J->d_n.p, 0, 16, c->stream));
             hipLaunchKernelGGL(k_select_overflow, dim3((unsigned)std::min<uint64_t>((in.n_reads + 255) / 256, 8192)), dim3(256), 0, c->stream,
-                               (const uint4*)T->summ.p, in.n_reads, (uint32_t*)ovf_tmp.p, (unsigned long long*)d_n.p);
+                               (const uint4*)T->summ.p, in.n_reads, (uint32_t*)J->ovf_tmp.p, (unsigned long long*)J->d_n.p);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(&T->n_ovf, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(&T->n_ovf, J->d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
         if (T->n_ovf) {
             rc = c->alloc(T->ovf_list, T->n_ovf * 4, "overflow read list", true); if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(T->ovf_list.p, ovf_tmp.p, T->n_ovf * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(T->ovf_list.p, J->ovf_tmp.p, T->n_ovf * 4, hipMemcpyDeviceToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
     }
-    c->release(ovf_tmp); c->release(d_n);
-    c->st.ms_part_count = t.stop();
+    c->release(J->ovf_tmp); c->release(J->d_n);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    for (auto& e : J->ev) { float m = 0; if (hipEventElapsedTime(&m, e.first, e.second) == hipSuccess) ms += m; }
+    c->st.ms_part_count = ms; c->st.reserved[6] = J->ev.size();          // (launches of the counting scan: 1, or the pieces of run_under_upload)
     TRACE("%llu of %llu reads have more than %d runs", (unsigned long long)T->n_ovf, (unsigned long long)in.n_reads, SUMMARY_RUNS);
-    if (by_class) {
-        T->h_class.assign(n_bins, 0);
-        HIP_TRY(hipMemcpyAsync(T->h_class.data(), T->class_hist.p, n_bins * 8, hipMemcpyDeviceToHost, c->stream));
+    if (J->by_class) {
+        T->h_class.assign(J->n_bins, 0);
+        HIP_TRY(hipMemcpyAsync(T->h_class.data(), T->class_hist.p, J->n_bins * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         T->n_records = T->n_inst = 0;
-        for (uint64_t i = 0; i < n_bins / 2; ++i) { T->n_records += T->h_class[i]; T->n_inst += T->h_class[n_bins / 2 + i]; }
-    } else { rc = table_totals(c, T->acc, nb, &T->n_records, &T->n_inst); if (rc) return rc; }
-    TRACE("partition count pass done (%llu buckets, %llu records)", (unsigned long long)nb, (unsigned long long)T->n_records);
+        for (uint64_t i = 0; i < J->n_bins / 2; ++i) { T->n_records += T->h_class[i]; T->n_inst += T->h_class[J->n_bins / 2 + i]; }
+    } else { rc = table_totals(c, T->acc, J->nb, &T->n_records, &T->n_inst); if (rc) return rc; }
+    TRACE("partition count pass done (%llu buckets, %llu records%s)", (unsigned long long)J->nb, (unsigned long long)T->n_records, J->ev.size() > 1 ? ", in ranges under the upload" : "");
     if (T->n_inst != n_inst)
         return fail(DFK_E_HIP, "partition count pass saw %llu instances, trim saw %llu%s",
                     (unsigned long long)T->n_inst, (unsigned long long)n_inst,
                     (n_inst - T->n_inst) % (1ull << 32) == 0 ? " (a fine bucket with 2^32 or more instances: its counter keeps 32 bits)" : "");
-    c->st.n_records = T->n_records; c->st.n_buckets = nb;
+    c->st.n_records = T->n_records; c->st.n_buckets = J->nb;
     return 0;
+}
+
+template <int K>
+int partition_count(dfk_ctx* c, const Inputs& in, uint64_t n_inst, uint32_t log2_world, int64_t read_id0, BucketTable* T, bool by_class = false)
+{
+    ScanJob J;
+    int rc = scan_begin<K>(c, in, log2_world, read_id0, T, by_class, &J); if (rc) return rc;
+    rc = scan_range<K>(c, in, T, &J, 0, in.n_reads); if (rc) return rc;
+    return scan_end<K>(c, in, n_inst, T, &J);
 }
 
 // base[], ipre[] and the work items of one pass, all on the device
@@ -1498,21 +1545,31 @@ struct StreamSwap {                                    // run a stretch of host 
     ~StreamSwap() { c->stream = keep; }
 };
 
+// trim and counting scan done ahead of run_typed, while the reads' bases were still crossing PCIe (count_host)
+struct Prescan { BucketTable T; uint64_t n_inst = 0; float ms_trim = 0; };
+
 template <int K>
-int run_typed(dfk_ctx* c, const Inputs& in)
+int run_typed(dfk_ctx* c, const Inputs& in, Prescan* pre = nullptr)
 {
     Timer total(c->stream);
     total.start();
     Timer t(c->stream);
     uint64_t n_inst = 0;
-    t.start();
-    TRACE("trim: %llu reads", (unsigned long long)in.n_reads);
-    int rc = stage_trim<K>(c, in, &n_inst); if (rc) return rc;
-    c->st.ms_trim = t.stop();
-    TRACE("trim done: %llu instances", (unsigned long long)n_inst);
+    int rc = 0;
+    BucketTable T;
+    if (pre) { n_inst = pre->n_inst; c->st.ms_trim = pre->ms_trim; T = std::move(pre->T); }
+    else {
+        t.start();
+        TRACE("trim: %llu reads", (unsigned long long)in.n_reads);
+        rc = stage_trim<K>(c, in, &n_inst); if (rc) return rc;
+        c->st.ms_trim = t.stop();
+        TRACE("trim done: %llu instances", (unsigned long long)n_inst);
+    }
     c->st.n_reads = in.n_reads; c->st.n_inst = n_inst; c->n_reads = in.n_reads;
-    BucketTable T; T.log2_nb = pick_log2_nb(n_inst, 0);
-    rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
+    if (!pre) {
+        T.log2_nb = pick_log2_nb(n_inst, 0);
+        rc = partition_count<K>(c, in, n_inst, 0, 0, &T); if (rc) return rc;
+    }
     CountRun R;
     rc = count_run_begin(c, &R); if (rc) return rc;
     c->want_blist = true; c->pending_blist = -1;
@@ -1640,7 +1697,7 @@ int run_typed(dfk_ctx* c, const Inputs& in)
     c->st.reserved[0] = n_passes;
     rc = count_run_end(c, &R); if (rc) return rc;
     rc = stage_adjacency<K>(c); if (rc) return rc;
-    c->st.ms_total = total.stop();
+    c->st.ms_total = total.stop() + (pre ? c->st.ms_trim + c->st.ms_part_count : 0.0f);   // (device time: what ran under the upload counts too)
     c->st.hbm_bytes_peak = c->peak;
     c->have = true;
     return 0;
@@ -1656,6 +1713,92 @@ int run(dfk_ctx* c, const Inputs& in)
     default: return fail(DFK_E_ARG, "K must be 40, 48 or 60");
     }
     return rc == E_SEGMENT_FULL ? DFK_E_NOMEM : rc;
+}
+
+int upload(dfk_ctx* c, void* d, const void* h, uint64_t bytes);
+
+// count_host's way through a run: everything but the bases is on the device (in.packed is allocated and empty), the bases
+// are at `h_packed` on the host.  The trim needs no bases and runs beside the first piece of their upload; the counting scan
+// -- a fifth of the count, serial, nothing else can start before it -- takes the reads of every piece as soon as the piece
+// has arrived, so that only the last piece's scan is left when the upload ends (the reads a piece completes: from every
+// stride-th entry of the offset table, read back once).  Then the passes as in any run.
+template <int K>
+int run_under_upload(dfk_ctx* c, const Inputs& in, const uint8_t* h_packed)
+{
+    const uint64_t n = in.n_reads, pb = in.packed_bytes;
+    const uint64_t seg_env = getenv("DFK_UPLOAD_SEGMENT") ? (uint64_t)atoll(getenv("DFK_UPLOAD_SEGMENT")) : 0;      // (tests: small pieces)
+    const uint64_t seg = seg_env ? std::max<uint64_t>(64, seg_env & ~63ull) : std::max<uint64_t>(256ull << 20, ((pb / 12) + (64ull << 20)) & ~((64ull << 20) - 1));
+    // where the reads end, coarsely
+    const uint64_t stride = std::max<uint64_t>(1, (n + 32767) / 32768), n_samp = n / stride + 2;
+    std::vector<uint64_t> samp(n_samp);
+    {
+        DevBuf d; int rc = c->alloc(d, n_samp * 8, "offset samples", true); if (rc) return rc;
+        hipLaunchKernelGGL(k_sample_u64, dim3((unsigned)((n_samp + 255) / 256)), dim3(256), 0, c->stream, in.base_off, stride, n, n_samp, (uint64_t*)d.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(samp.data(), d.p, n_samp * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->release(d);
+    }
+    auto reads_within = [&](uint64_t bytes) -> uint64_t {              // reads whose bases end at or before `bytes` (a multiple of the stride, or all)
+        const uint64_t i = (uint64_t)(std::upper_bound(samp.begin(), samp.end(), bytes) - samp.begin());   // samp[i-1] <= bytes < samp[i]
+        return i ? std::min<uint64_t>((i - 1) * stride, n) : 0;
+    };
+    Prescan pre;
+    // ---- the trim beside the first piece
+    int trim_rc = 0; std::string trim_err;
+    Timer tt(c->stream);
+    std::thread trim([&] {
+        (void)hipSetDevice(c->device);
+        TRACE("trim: %llu reads (the bases are still arriving)", (unsigned long long)n);
+        tt.start();
+        trim_rc = stage_trim<K>(c, in, &pre.n_inst);
+        if (trim_rc) trim_err = g_err; else pre.ms_trim = tt.stop();
+    });
+    uint64_t sent = std::min(seg, pb);
+    int rc = upload(c, (void*)in.packed, h_packed, sent);
+    if (sent >= pb) c->t_upload_done = wall_now();
+    trim.join();
+    if (trim_rc) return fail(trim_rc, "%s", trim_err.c_str());
+    if (rc) return rc;
+    TRACE("trim done: %llu instances", (unsigned long long)pre.n_inst);
+    // ---- the scan, a piece behind the upload
+    pre.T.log2_nb = pick_log2_nb(pre.n_inst, 0);
+    ScanJob J;
+    rc = scan_begin<K>(c, in, 0, 0, &pre.T, false, &J); if (rc) return rc;
+    uint64_t scanned = 0;
+    for (;;) {
+        const uint64_t r1 = sent >= pb ? n : reads_within(sent);
+        rc = scan_range<K>(c, in, &pre.T, &J, scanned, r1); if (rc) return rc;
+        scanned = std::max(scanned, r1);
+        if (sent >= pb) break;
+        const uint64_t m = std::min(seg, pb - sent);
+        rc = upload(c, (char*)in.packed + sent, h_packed + sent, m); if (rc) return rc;
+        sent += m;
+        if (sent >= pb) c->t_upload_done = wall_now();
+    }
+    rc = scan_end<K>(c, in, pre.n_inst, &pre.T, &J); if (rc) return rc;
+    return run_typed<K>(c, in, &pre);
+}
+
+int run_from_host_bases(dfk_ctx* c, const Inputs& in, const uint8_t* h_packed)
+{
+    int rc;
+    switch (c->cfg.K) {
+    case 40: rc = run_under_upload<40>(c, in, h_packed); break;
+    case 48: rc = run_under_upload<48>(c, in, h_packed); break;
+    case 60: rc = run_under_upload<60>(c, in, h_packed); break;
+    default: return fail(DFK_E_ARG, "K must be 40, 48 or 60");
+    }
+    return rc == E_SEGMENT_FULL ? DFK_E_NOMEM : rc;
+}
+bool scan_under_upload_applies(const dfk_ctx* c, uint64_t packed_bytes)
+{
+    // (read at every call: tests switch them within one process)
+    const bool off = getenv("DFK_NO_SCAN_UNDER_UPLOAD") != nullptr;
+    const uint64_t min_bytes = getenv("DFK_SCAN_UNDER_UPLOAD_MIN") ? (uint64_t)atoll(getenv("DFK_SCAN_UNDER_UPLOAD_MIN")) : (1ull << 30);
+    if (off || packed_bytes < min_bytes) return false;
+    switch (c->cfg.K) { case 40: return scan_takes_ranges<40>(c); case 48: return scan_takes_ranges<48>(c); case 60: return scan_takes_ranges<60>(c); }
+    return false;
 }
 
 // Ascending (w0, w1) on the host cores: one most-significant-digit pass (12 bits of w0) over per-thread slices,
@@ -2015,6 +2158,7 @@ static int count_host(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_of
     void *d_packed = nullptr, *d_boff = nullptr, *d_len = nullptr, *d_pq = nullptr, *d_poff = nullptr, *d_bc = nullptr, *d_bci = nullptr;
     Timer t(c->stream);
     t.start();
+    const double t_host0 = wall_now();
     int rc = 0;
     auto room = [&](void** d, size_t bytes) {
         if (rc) return;
@@ -2048,17 +2192,33 @@ static int count_host(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_of
     if (base_off) up(&d_boff, base_off, (n_reads + 1) * 8); else room(&d_boff, (n_reads + 1) * 8);
     if (bci) { up(&d_bci, bci, n_bci * 8); room(&d_bc, n_reads * 4); }
     if (!rc && (!base_off || bci)) { rc = derive(); c->drop_empty_chunks(); }     // (the scan's scratch came from the arena: the run's first chunk is still to be sized)
-    up(&d_packed, packed, pb);
+    // (the bases last: the trim reads the qualities only, and the counting scan follows the bases piece by piece -- run_under_upload)
+    const bool under = n_reads && scan_under_upload_applies(c, pb);
     up(&d_pq, pq, qb);
     up(&d_poff, pq_off, (n_reads + 1) * 8);
     if (bc && !bci) up(&d_bc, bc, n_reads * 4);
-    float ms_up = t.stop();
+    if (under) room(&d_packed, pb); else up(&d_packed, packed, pb);
+    float ms_up = under ? 0.0f : t.stop();
     if (d_bci) { (void)hipFree(d_bci); d_bci = nullptr; }
     if (!rc) {
         uint64_t staged = pb + qb + (n_reads + 1) * 16 + n_reads * 8 + 6 * 64;
         uint64_t saved = c->budget;
         c->budget = c->budget > staged ? c->budget - staged : 0;
-        rc = dfk_count_device(c, d_packed, pb, d_boff, d_len, d_pq, qb, d_poff, d_bc, n_reads);
+        if (!under) rc = dfk_count_device(c, d_packed, pb, d_boff, d_len, d_pq, qb, d_poff, d_bc, n_reads);
+        else {
+            // (what dfk_count_device does before its run; the arena is empty: release_all above, the derived arrays' scratch dropped)
+            c->st = dfk_stats{}; c->peak = 0;
+            if (c->d_resident) HIP_TRY(hipMemset(c->d_resident + 1, 0, 4));
+            c->first_chunk_hint = 8 * (pb + qb + 28 * n_reads) + (1ull << 30);
+            const Inputs in{(const uint8_t*)d_packed, pb, (const uint64_t*)d_boff, (const uint32_t*)d_len, (const uint8_t*)d_pq, qb, (const uint64_t*)d_poff,
+                            (const int32_t*)d_bc, n_reads};
+            c->t_upload_done = 0;
+            rc = run_from_host_bases(c, in, packed);
+            if (rc) c->release_all();
+            (void)t.stop();
+            ms_up = c->t_upload_done > t_host0 ? (float)(1e3 * (c->t_upload_done - t_host0)) : 0.0f;     // (to the arrival of the last base; trim and most of the scan are inside it)
+            TRACE("inputs on the device %.3f s after the call, counted %.3f s after it", 1e-3 * ms_up, wall_now() - t_host0);
+        }
         c->st.ms_upload = ms_up;
         if (!rc && (c->cfg.flags & DFK_F_KEEP_INPUTS)) {
             // the reads stay on the device for dfk_paths_build, and the arena's budget stays reduced by them

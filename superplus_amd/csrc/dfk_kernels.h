@@ -457,7 +457,7 @@ __device__ __forceinline__ void static_for(F&& f)
 template <int K, int M>
 __global__ void __launch_bounds__(PART_THREADS)
 k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const uint64_t* __restrict__ base_off,
-             const uint32_t* __restrict__ good_len, uint64_t n_reads, PartParams pp,
+             const uint32_t* __restrict__ good_len, uint64_t r_first, uint64_t n_reads /* reads [r_first, n_reads) */, PartParams pp,
              unsigned long long* __restrict__ bucket_acc, unsigned long long* __restrict__ class_hist,
              unsigned long long* __restrict__ ovf_count, uint64_t ovf_cap, uint32_t* __restrict__ ovf_list,
              uint4* __restrict__ summaries, uint32_t* __restrict__ read_classes)
@@ -480,7 +480,7 @@ k_scan_count(const uint8_t* __restrict__ packed, uint64_t packed_bytes, const ui
     const uint32_t* words = reinterpret_cast<const uint32_t*>(packed);
     const uint64_t n_words = (packed_bytes + 3) >> 2;
     const uint32_t log2_local = pp.log2_nb - pp.log2_world;
-    for (uint64_t r0 = (uint64_t)blockIdx.x * PART_THREADS; r0 < n_reads; r0 += (uint64_t)gridDim.x * PART_THREADS) {
+    for (uint64_t r0 = r_first + (uint64_t)blockIdx.x * PART_THREADS; r0 < n_reads; r0 += (uint64_t)gridDim.x * PART_THREADS) {
         const uint64_t r = r0 + tid;
         const uint32_t gl = r < n_reads ? good_len[r] : 0;
         const bool live = gl >= (uint32_t)K + 1;                         // Kmerizer::map: len < K+1 emits nothing (:153)
@@ -2724,6 +2724,14 @@ k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx,
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];
+}
+
+// every stride-th value of a table of n + 1 (and the last): out[i] = src[min(i * stride, n)], i < n_out
+__global__ void __launch_bounds__(256)
+k_sample_u64(const uint64_t* __restrict__ src, uint64_t stride, uint64_t n, uint64_t n_out, uint64_t* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_out) out[i] = src[min(i * stride, n)];
 }
 
 // ============================================================================ small utilities

@@ -67,6 +67,7 @@ class Stats(C.Structure):
         d["us_graph_device"], d["us_graph_host"], d["us_paths"] = int(self.reserved[1]), int(self.reserved[2]), int(self.reserved[3])
         d["gate_timeouts"] = int(self.reserved[4])
         d["hbm_held"] = int(self.reserved[5])
+        d["n_scan_launches"] = int(self.reserved[6])
         return d
 
 

@@ -148,6 +148,15 @@ def test_ragged_and_degenerate_reads(oracle):
     for K in (40, 48, 60):
         ref, d = util.run_both(oracle, rs, K=K)
         util.check_parity(ref, d)
+    # ... and with the bases uploaded in pieces of a few reads, the scan following them (run_under_upload)
+    import os
+    os.environ["DFK_SCAN_UNDER_UPLOAD_MIN"] = "0"; os.environ["DFK_UPLOAD_SEGMENT"] = "256"
+    try:
+        for K in (40, 48, 60):
+            ref, d = util.run_both(oracle, rs, K=K)
+            util.check_parity(ref, d)
+    finally:
+        del os.environ["DFK_SCAN_UNDER_UPLOAD_MIN"], os.environ["DFK_UPLOAD_SEGMENT"]
 
 
 @pytest.mark.parametrize("nbits", [1, 2, 3, 4, 5, 6])
@@ -286,6 +295,28 @@ def test_hash_slice_passes(oracle, passes):
     ref, d = util.run_both(oracle, rs, K=48, passes=passes)
     st = util.check_parity(ref, d)
     assert st["n_passes"] == passes
+
+
+@pytest.mark.parametrize("K,segment", [(48, 4096), (48, 1 << 20), (40, 50000), (60, 50000)])
+def test_counting_scan_under_the_upload_of_the_bases(oracle, monkeypatch, K, segment):
+    """dfk_count from host arrays (what DF calls): the bases go to the device in pieces, the trim runs beside the first one and
+    the counting scan takes the reads of every piece as it arrives (run_under_upload) -- the default from 1 GB of bases on,
+    forced here on a small ragged set with pieces of a few reads up to all of them.  Same dictionary as the oracle's, same
+    digest as the run that uploads first and counts afterwards."""
+    monkeypatch.setenv("DFK_SCAN_UNDER_UPLOAD_MIN", "0")
+    monkeypatch.setenv("DFK_UPLOAD_SEGMENT", str(segment))
+    monkeypatch.setenv("DFK_TRACE", "1")
+    rs = util.make_set(91 + K, 120000, 30000)
+    ref, d = util.run_both(oracle, rs, K=K, passes=2)
+    st = util.check_parity(ref, d)
+    under = d.digest()
+    assert st["ms_part_count"] > 0 and st["n_records"] > 0
+    assert st["n_scan_launches"] >= (2 if segment < len(rs["packed"]) else 1)
+    del d
+    monkeypatch.setenv("DFK_NO_SCAN_UNDER_UPLOAD", "1")
+    ref, d = util.run_both(oracle, rs, K=K, passes=2)
+    st2 = util.check_parity(ref, d)
+    assert st2["n_records"] == st["n_records"] and d.digest() == under and st2["n_scan_launches"] == 1
 
 
 def test_repeat_family_hot_minimizers(oracle):
