@@ -361,7 +361,9 @@ def df_stage_wall(args, dev, local):
         quiesce = float(os.environ.get("BENCH_QUIESCE_S", min(15.0, held / 25e9)))
         # transfer lanes per copy: four (each keeps a DMA in flight and spins on it; three copies run side by side in the stage's last
         # phase, and the box gives the command 16 CPUs -- measured at full size: 16 lanes 17.1 s, 8: 16.7, 6: 17.0, 4: 15.6-16.2)
-        env = dict(os.environ, DFK_HOST_THREADS=os.environ.get("DFK_HOST_THREADS", str(min(args.df_threads, 4))))
+        # ... the upload runs alone and is bound by its lanes' copies out of the page cache: eight (4 lanes 2.05-2.08 s, 6: 1.90-1.96, 8: 1.85-1.92)
+        env = dict(os.environ, DFK_HOST_THREADS=os.environ.get("DFK_HOST_THREADS", str(min(args.df_threads, 4))),
+                   DFK_UPLOAD_THREADS=os.environ.get("DFK_UPLOAD_THREADS", str(min(args.df_threads, 8))))
 
         def run_stage(head, n_pairs, linked, wait_s):
             """one run of the child process on the files `head`.*; the work directory is removed afterwards"""

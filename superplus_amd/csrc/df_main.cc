@@ -516,6 +516,9 @@ int main(int argc, char** argv)
 {
     { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); printf("DF_MAIN_EPOCH %.3f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
     const double t_start = now_s();
+    // the library's host transfers as this program was measured, unless the caller says otherwise: four lanes
+    // per transfer (three writers run side by side in the last phase), eight for the uploads (which run alone)
+    (void)setenv("DFK_HOST_THREADS", "4", 0); (void)setenv("DFK_UPLOAD_THREADS", "8", 0);
     std::map<std::string, std::string> a = {
         {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
         {"OUT_DIR", ""}, {"LR", ""}, {"LR_SELECT_FRAC", "1.0"}, {"EXIT_LOAD", "False"}, {"DEVICE", "0"}, {"MAX_MEM_GB", "0"},

@@ -1871,9 +1871,9 @@ int lane_create(XferLane& l)
     return 0;
 }
 
-int xfer_run(dfk_ctx* c, uint64_t n_chunks, const XferBody& body, const XferFin& fin = nullptr)
+int xfer_run(dfk_ctx* c, uint64_t n_chunks, const XferBody& body, const XferFin& fin = nullptr, unsigned n_lanes = 0)
 {
-    const unsigned T = (unsigned)std::min<uint64_t>(n_chunks, xfer_threads());
+    const unsigned T = (unsigned)std::min<uint64_t>(n_chunks, n_lanes ? n_lanes : xfer_threads());
     if (!T) return 0;
     // lanes: from the context's pool (several transfers may run side by side, each with lanes of its own), made when it has none
     std::vector<XferLane> lanes(T);
@@ -1949,6 +1949,9 @@ int upload(dfk_ctx* c, void* d, const void* h, uint64_t bytes)
         HIP_TRY(hipMemcpy(d, tmp.data(), bytes, hipMemcpyHostToDevice));
         return 0;
     }
+    // (uploads run alone -- the writers of the stage's last phase run three at a time -- and are bound by the lanes' copies out of
+    // the page cache, not by PCIe: they may take more lanes than xfer_threads(); DFK_UPLOAD_THREADS)
+    static const unsigned up_lanes = getenv("DFK_UPLOAD_THREADS") ? (unsigned)std::max(1, atoi(getenv("DFK_UPLOAD_THREADS"))) : 0;
     return xfer_run(c, (bytes + XFER_CHUNK - 1) / XFER_CHUNK, [&](unsigned, XferLane& l, uint64_t i) -> int {
         const int k = l.turn++ & 1;                                  // the lane's two buffers alternate; the one about to be
         HIP_TRY(hipEventSynchronize(l.ev[k]));                       // overwritten must have left the host
@@ -1957,7 +1960,7 @@ int upload(dfk_ctx* c, void* d, const void* h, uint64_t bytes)
         HIP_TRY(hipMemcpyAsync((char*)d + off, l.pin[k], n, hipMemcpyHostToDevice, l.st));
         HIP_TRY(hipEventRecord(l.ev[k], l.st));
         return 0;
-    });
+    }, nullptr, up_lanes);
 }
 
 // The dictionary as the device holds it (pass after pass, no order inside a pass), streamed into a kmers.kvec image:
