@@ -229,7 +229,7 @@ def test_lds_table_overflow_falls_back(oracle):
     assert st["n_overflow_items"] > 0
 
 
-def test_no_good_bases_is_an_error(oracle):
+def test_no_good_bases_is_an_error(oracle, upload_mode):
     from superplus_amd.dfk import Dfk, DfkError
     rs = _custom([np.zeros(100, np.uint8)] * 10, [np.full(100, 2, np.uint8)] * 10)
     d = Dfk(K=48)
@@ -241,7 +241,16 @@ def test_no_good_bases_is_an_error(oracle):
                 np.zeros(1, np.uint64), None)
 
 
-def test_malformed_pqvec_is_an_error():
+@pytest.fixture(params=["upload_then_count", "scan_under_the_upload"])
+def upload_mode(request, monkeypatch):
+    """dfk_count from host arrays both ways: everything uploaded first, or the bases in pieces with the scan behind them
+    (the default from 1 GB of bases on; forced here with pieces of 512 bytes)."""
+    if request.param == "scan_under_the_upload":
+        monkeypatch.setenv("DFK_SCAN_UNDER_UPLOAD_MIN", "0"); monkeypatch.setenv("DFK_UPLOAD_SEGMENT", "512")
+    return request.param
+
+
+def test_malformed_pqvec_is_an_error(upload_mode):
     from superplus_amd.dfk import Dfk, DfkError
     rs = _custom([np.zeros(100, np.uint8)] * 4, [np.full(100, 30, np.uint8)] * 4)
     rs["read_len"][2] = 99
@@ -394,7 +403,7 @@ def test_count_saturates_at_2_pow_24_in_an_lds_table(oracle):
     assert st["n_inst"] > (1 << 24) and len(d.spectrum()) == 1 << 24
 
 
-def test_malformed_offset_tables_are_an_error():
+def test_malformed_offset_tables_are_an_error(upload_mode):
     """The offset tables are checked on the device before anything is read through them (DFK_E_INPUT, no stray read)."""
     from superplus_amd.dfk import Dfk, DfkError
     base = _custom([np.zeros(100, np.uint8)] * 64, [np.full(100, 30, np.uint8)] * 64)
