@@ -228,6 +228,9 @@ int dfk_graph_write(dfk_ctx* ctx, const char* dir);
  * what one writer gives (9 GB/s): this starts the 37 GB of configs[1] two seconds earlier.  path = NULL: back to
  * dfk_paths_write writing everything.  A build that fails removes the file.  (ReadPathVec::WriteAll, 10X/WriteFiles.cc:78-82,
  * writes after pathReads has returned.) */
+/* A file that exists at `path` is not truncated when the build starts (dfk_paths_write sets its size): a caller that has made it
+ * about as large as a.paths will be (fallocate of 20-odd bytes a read, while the GPU counts) saves the writer the allocation
+ * of every page under the file's lock.  The same holds for dir/a.paths.inv of dfk_paths_index_write. */
 int dfk_paths_sink(dfk_ctx* ctx, const char* path);
 
 /* ---- read pathing ("correction by pathing") on the graph dfk_graph_build left in the context ----

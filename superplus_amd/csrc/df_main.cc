@@ -522,7 +522,7 @@ int main(int argc, char** argv)
     std::map<std::string, std::string> a = {
         {"K", "48"}, {"MIN_FREQ", "3"}, {"MIN_BC", "2"}, {"MIN_QUAL", "7"}, {"ROOT", "/mnt/assembly"}, {"INSTANCE", "1"},
         {"OUT_DIR", ""}, {"LR", ""}, {"LR_SELECT_FRAC", "1.0"}, {"EXIT_LOAD", "False"}, {"DEVICE", "0"}, {"MAX_MEM_GB", "0"},
-        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "Auto"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}, {"PATHS", "True"}, {"LINK_READS", "False"}, {"NUM_GPUS", "1"}};
+        {"HBM_GB", "0"}, {"NUM_THREADS", "-1"}, {"MINIMIZER", "0"}, {"KVEC", "Auto"}, {"KVEC_SORTED", "False"}, {"GRAPH", "True"}, {"PATHS", "True"}, {"LINK_READS", "False"}, {"NUM_GPUS", "1"}, {"PATHS_RESERVE", "20"}};
     std::string command = "DF";
     for (int i = 1; i < argc; ++i) {
         std::string s = argv[i]; command += " " + s;
@@ -738,6 +738,28 @@ int main(int argc, char** argv)
         // GRAPH=False, where it is the one way the dictionary leaves this process
         const bool want_kvec = a["KVEC"] == "Auto" ? (!truthy(a["GRAPH"]) || truthy(a["KVEC_SORTED"])) : truthy(a["KVEC"]);
         if (want_paths) cfg.flags |= DFK_F_KEEP_INPUTS;                          // the reads stay on the device for pathReads
+        // a.<K>/a.paths and a.paths.inv are the stage's largest outputs (20-odd and 8 bytes a read: 37 and 14 GB at configs[1]) and
+        // their sizes are known only once the reads are pathed.  Pages for them are made NOW (PATHS_RESERVE bytes a read for
+        // a.paths -- 16 fixed and one path entry -- and 8 for every entry that leaves for a.paths.inv; 0 = don't), by threads nobody
+        // waits for until the files are written: a pwrite into pages that exist does not allocate them under the file's lock.
+        // The library sets the sizes; what was reserved beyond them is freed again (paid for twice, so the guess is a low one).
+        std::thread reserve_thread, reserve_inv_thread;
+        struct JoinReserve { std::thread& t; ~JoinReserve() { if (t.joinable()) t.join(); } } reserve_joiner{reserve_thread}, reserve_inv_joiner{reserve_inv_thread};
+        const double reserve_per_read = atof(a["PATHS_RESERVE"].c_str());
+        if (fast && !sharded && want_paths && !truthy(a["EXIT_LOAD"]) && reserve_per_read > 0 && n_reads) {
+            const std::string dir = work_dir + "/a." + std::to_string(K);
+            mkpath(dir);
+            const uint64_t bytes = 24 + (uint64_t)((double)n_reads * reserve_per_read);
+            auto reserve = [](const std::string& path, uint64_t n) {
+                const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);
+                if (fd < 0) return;                                             // (the writer will say what is wrong with the path)
+                if (fallocate(fd, 0, 0, (off_t)n) != 0) (void)!ftruncate(fd, 0);            // no room, or a file system without it: the file grows as it is written
+                close(fd);
+            };
+            const uint64_t inv_bytes = 24 + (uint64_t)((double)n_reads * std::max(0.0, reserve_per_read - 16.0) * 2.0);
+            reserve_thread = std::thread([=] { reserve(dir + "/a.paths", bytes); });
+            reserve_inv_thread = std::thread([=] { if (inv_bytes > 24) reserve(dir + "/a.paths.inv", inv_bytes); });
+        }
         dfk_ctx* ctx = nullptr;
         int count_rc = 0; bool create_failed = false; std::string count_err; double t_count = 0;
         // frag_reads_orig.qhist: counted on the device from the reads the count keeps there (the pathing wants them), behind the
@@ -903,6 +925,7 @@ int main(int argc, char** argv)
                 // pathReads (BuildReadQGraph48.cc:1664-1665) and a.<K>/a.paths (10X/WriteFiles.cc:78-82)
                 t0 = now_s();
                 printf("%s: pathing reads\n", date().c_str());
+                if (reserve_thread.joinable()) reserve_thread.join();
                 if (dfk_paths_sink(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());      // (its data goes to the file batch by batch)
                 if (dfk_paths_build(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) throw std::runtime_error(dfk_last_error());
                 { dfk_stats ps{}; dfk_get_stats(ctx, &ps); t_p_dev = 1e-6 * (double)ps.reserved[3]; }
@@ -914,6 +937,7 @@ int main(int argc, char** argv)
                 // writePathsIndex and MarkDups, the two steps DF takes right after StageBuildGraph (10X/DF.cc:550,560)
                 const double ti = now_s();
                 printf("%s: inverting paths index\n", date().c_str());
+                if (reserve_inv_thread.joinable()) reserve_inv_thread.join();
                 if (dfk_paths_index_write(ctx, dir.c_str())) throw std::runtime_error(dfk_last_error());
                 t_index = now_s() - ti;
                 const double td = now_s();
@@ -931,7 +955,10 @@ int main(int argc, char** argv)
             t_g_write = tw_graph;
         }
         const double t_d0 = now_s();
-        dfk_destroy(ctx);
+        // (the context is not taken apart when the process is about to leave by _exit, below: handing 270 GB back to the driver
+        // buffer by buffer takes 1.5 s, the operating system's own teardown of the process a fraction of that)
+        const bool quick_exit = !sharded && !getenv("DF_SLOW_EXIT");
+        if (!quick_exit) dfk_destroy(ctx);
         const double t_destroy = now_s() - t_d0;
         join_background();
         const double t_joined = now_s() - t_d0 - t_destroy;
@@ -950,7 +977,7 @@ int main(int argc, char** argv)
         // Everything is written and closed, the context destroyed, the ranks reaped: what is left is giving gigabytes of vectors
         // back to the allocator one by one and the HIP runtime's own teardown, none of which the operating system needs done
         // before it takes the process apart anyway.  (DF_SLOW_EXIT=1: the long way, for leak checkers.)
-        if (!sharded && !getenv("DF_SLOW_EXIT")) { fflush(nullptr); _exit(0); }
+        if (quick_exit) { fflush(nullptr); _exit(0); }
     } catch (const std::exception& e) {
         fprintf(stderr, "DF: %s\n", e.what());
         watch.kill_all();

@@ -146,7 +146,7 @@ struct dfk_ctx {
     // by first-fit free lists with coalescing.  hipMalloc/hipFree of multi-GB blocks cost milliseconds to
     // seconds each (and hipFree synchronises the device); a 30x human run moves hundreds of GB per pass.
     struct Free { uint64_t off, bytes; };
-    struct Chunk { char* p; uint64_t bytes; std::vector<Free> free_list; };     // free_list sorted by offset
+    struct Chunk { char* p; uint64_t bytes; std::vector<Free> free_list; bool adopted = false; };     // free_list sorted by offset; adopted: see adopt_kept
     std::vector<Chunk> chunks;
     uint64_t reserved = 0;                           // sum of chunk sizes
 
@@ -286,6 +286,8 @@ struct dfk_ctx {
         parts.clear();
         // anything an aborted run left behind: the arena is simply declared empty again
         owned.clear(); held = 0;
+        for (size_t i = 0; i < chunks.size();)                                // (what adopt_kept brought in goes back to the driver: a run plans with ONE large chunk)
+            if (chunks[i].adopted) { (void)hipFree(chunks[i].p); reserved -= chunks[i].bytes; chunks.erase(chunks.begin() + i); } else ++i;
         for (Chunk& k : chunks) k.free_list.assign(1, Free{0, k.bytes});
         good_len = shard_send[0] = shard_send[1] = shard_recv[0] = shard_recv[1] = adj_keys = adj_src = set = DevBuf{};
         shard_send_pass[0] = shard_send_pass[1] = ~0u;
@@ -299,6 +301,21 @@ struct dfk_ctx {
     void drop_kept()
     {
         for (void*& p : kept) if (p) { (void)hipFree(p); p = nullptr; }
+        budget += kept_budget; kept_budget = 0; kept_n_reads = 0;
+    }
+    // The kept reads' buffers become chunks of the arena instead of going back to the driver: memory that is freed is wiped
+    // before anybody gets it again, at ~33 GB/s (tools/vram_alloc_cost.hip), and the step that follows the pathing (MarkDups'
+    // table, 34 GB at configs[1]) asked for a new chunk right behind the release of these 91 GB -- and waited 1.5 s for it.
+    void adopt_kept()
+    {
+        const uint64_t bytes[6] = {kept_packed_bytes + 64, (kept_n_reads + 1) * 8 + 64, kept_n_reads * 4 + 64, kept_pq_bytes + 64, (kept_n_reads + 1) * 8 + 64, 0};
+        for (int i = 0; i < 6; ++i) {
+            if (!kept[i]) continue;
+            const uint64_t b = bytes[i] & ~(uint64_t)0xFFF;
+            if (i < 5 && b >= (64ull << 20) && ((uintptr_t)kept[i] & 0xFFF) == 0) { chunks.push_back(Chunk{(char*)kept[i], b, {Free{0, b}}, true}); reserved += b; }
+            else (void)hipFree(kept[i]);
+            kept[i] = nullptr;
+        }
         budget += kept_budget; kept_budget = 0; kept_n_reads = 0;
     }
 };

@@ -152,6 +152,21 @@ def test_df_writes_paths_index_and_dups(tmp_path, golden_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("reserve,set_name", [("0", "frag"), ("7", "frag"), ("18", "pathy2"), ("400", "frag"), ("20", "pathy2"), ("0", "pathy2"), ("19.3", "pathy2")])
+def test_df_paths_file_is_the_same_however_much_was_reserved_for_it(tmp_path, golden_dir, reserve, set_name):
+    """The pages of a.paths and a.paths.inv are made ahead of the pathing (PATHS_RESERVE bytes a read, default 20) and the
+    writers do not truncate what they find; what the guess was -- nothing, too little, a little short, far too much (cut at
+    the end) -- and stale larger files in the way change nothing in the bytes."""
+    os.makedirs(f"{tmp_path}/w/a.48")
+    for f in ("a.paths", "a.paths.inv"):
+        open(f"{tmp_path}/w/a.48/{f}", "wb").write(b"\xee" * (3 << 20))          # (left by an earlier run)
+    r = run_df(f"LR={golden_dir}/{set_name}.fastb", f"OUT_DIR={tmp_path}/w", "K=48", "HBM_GB=8", f"PATHS_RESERVE={reserve}")
+    assert r.returncode == 0, r.stdout + r.stderr
+    for f in ("a.paths", "a.paths.inv", "a.dup"):
+        assert open(f"{tmp_path}/w/a.48/{f}", "rb").read() == open(f"{golden_dir}/graph_{set_name}_k48/{f}", "rb").read(), f
+
+
+@pytest.mark.gpu
 def test_df_leaves_what_the_reference_resumes_from(tmp_path, golden_dir):
     """Seam B2 as a pipeline: `superplus_amd/DF ROOT=... LR=...` then the reference's `DF ROOT=... START=patch ...` on the same
     ROOT.  That branch of the reference loads exactly these files (10X/DF.cc:304-341 for START != "",
