@@ -273,6 +273,10 @@ int dfk_paths_fetch(dfk_ctx* ctx, int32_t* offsets, uint64_t* first_edge, int32_
  * +-2^24 (the duplicate key).  dir / path NULL: everything but the files (dfk_paths_digest). */
 int dfk_paths_index_write(dfk_ctx* ctx, const char* dir);
 int dfk_dups_write(dfk_ctx* ctx, const char* path, uint64_t* n_marked_pairs);
+/* Both steps, as DF takes them one after the other (10X/DF.cc:550,560): the same files, with the lists of a.paths.inv leaving
+ * the device and entering the file while the duplicates are marked (when the index is built in one range; otherwise exactly the
+ * two calls above). */
+int dfk_paths_index_dups_write(dfk_ctx* ctx, const char* dir, const char* dup_path, uint64_t* n_marked_pairs);
 
 /* ---- rows f-1 / f-2 / f-4 checked where no oracle runs (tests/test_gpu_fullsize_graph.py; DF prints the digests) ----
  * Replaces nothing in the reference (its nearest thing is hbv.CheckSum() / Validate(hbv, paths), 10X/DF.cc:597-598).

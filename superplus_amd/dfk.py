@@ -26,7 +26,7 @@ EXPORTS = [
     "dfk_write_kvec", "dfk_write_kvec_part", "dfk_get_stats", "dfk_shard_begin", "dfk_shard_begin_host", "dfk_shard_plan", "dfk_shard_partition", "dfk_shard_partition_begin", "dfk_shard_partition_end", "dfk_shard_recv_buffer", "dfk_shard_count", "dfk_shard_adj_queries",
     "dfk_shard_adj_answer", "dfk_shard_adj_apply", "dfk_graph_build", "dfk_graph_stats", "dfk_graph_write",
     "dfk_shard_dict_share", "dfk_shard_dict_adopt", "dfk_shard_dict_whole",
-    "dfk_paths_build", "dfk_paths_build_device", "dfk_paths_stats", "dfk_paths_write", "dfk_paths_fetch", "dfk_paths_index_write", "dfk_dups_write",
+    "dfk_paths_build", "dfk_paths_build_device", "dfk_paths_stats", "dfk_paths_write", "dfk_paths_fetch", "dfk_paths_index_write", "dfk_dups_write", "dfk_paths_index_dups_write",
     "dfk_paths_digest", "dfk_paths_verify", "dfk_paths_verify_device", "dfk_pbf_run", "dfk_pbf_result", "dfk_pbf_free",
     "dfk_paths_var_bytes", "dfk_paths_write_part", "dfk_shard_pidx_pairs", "dfk_shard_pidx_write", "dfk_shard_dup_keys", "dfk_shard_dup_answer", "dfk_shard_dup_write",
 ]
@@ -265,6 +265,12 @@ class Dfk:
         """a.dup (MarkDups); returns the number of pairs marked.  None = no file."""
         n = C.c_uint64()
         _check(lib().dfk_dups_write(self._ctx, None if path is None else path.encode(), C.byref(n)))
+        return n.value
+
+    def paths_index_dups_write(self, directory, path):
+        """dfk_paths_index_dups_write: both steps, a.paths.inv's lists written under the duplicate marking; returns the pairs marked."""
+        n = C.c_uint64()
+        _check(lib().dfk_paths_index_dups_write(self._ctx, None if directory is None else directory.encode(), None if path is None else path.encode(), C.byref(n)))
         return n.value
 
     def paths_digest(self):

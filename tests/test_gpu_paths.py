@@ -131,6 +131,38 @@ def test_paths_index_and_dups_match_reference_fixture(golden_dir, tmp_path):
         d.close()
 
 
+@pytest.mark.parametrize("which,case", [("frag", "graph_frag_k48"), ("pathy2", "graph_pathy2_k48")])
+def test_index_and_dups_in_one_call_write_the_same_files(golden_dir, tmp_path, monkeypatch, which, case):
+    """dfk_paths_index_dups_write (what DF calls): a.paths.inv's lists are written by a thread of their own while the duplicates
+    are marked -- or, with the index built in several ranges, the two steps simply follow each other.  Same bytes, same digests
+    as the two calls; the context holds nothing more afterwards and goes on working."""
+    from superplus_amd.dfk import Dfk
+    rs = load_reads(golden_dir, which)
+    d = Dfk(K=48, keep_inputs=True)
+    d.count(rs["packed"], rs["base_off"], rs["read_len"], rs["pq_bytes"], rs["pq_off"], rs["bc"])
+    d.graph_build(); d.paths_build()
+    d.paths_index_write(None)                                             # (gives the k-mer index back, as either call does first)
+    held = d.stats()["hbm_held"]
+    words = []
+    for cap in (None, "900"):
+        if cap: monkeypatch.setenv("DFK_PIDX_RANGE_PAIRS", cap)
+        out = os.path.join(tmp_path, cap or "whole"); os.makedirs(out)
+        marked = d.paths_index_dups_write(out, os.path.join(out, "a.dup"))
+        for f in ("a.paths.inv", "a.countsb", "a.dup"):
+            assert open(os.path.join(out, f), "rb").read() == open(os.path.join(golden_dir, case, f), "rb").read(), f"{f} ranges of {cap}"
+        assert marked == int(np.frombuffer(open(os.path.join(golden_dir, case, "a.dup"), "rb").read(), np.uint8, offset=16).sum())
+        words.append(d.paths_digest())
+    monkeypatch.delenv("DFK_PIDX_RANGE_PAIRS")
+    d.paths_index_write(None); d.dups_write(None)
+    words.append(d.paths_digest())
+    assert words[0] == words[1] == words[2]
+    assert d.stats()["hbm_held"] == held
+    with pytest.raises(Exception):
+        d.paths_index_dups_write(os.path.join(tmp_path, "no", "such", "dir"), None)
+    assert d.stats()["hbm_held"] == held
+    d.close()
+
+
 @pytest.mark.parametrize("seed,G,pairs", [(421, 20000, 8000), (422, 60000, 12000)])
 def test_paths_index_and_dups_match_oracle(oracle, tmp_path, seed, G, pairs):
     """Seeded reads with duplicated pairs: the product's three files against the Python oracle's (which is pinned by the fixture)."""
