@@ -46,6 +46,7 @@
 #include <signal.h>
 #include <sys/wait.h>
 #include <thread>
+#include <type_traits>
 #include <unistd.h>
 
 namespace {
@@ -157,7 +158,7 @@ struct Mapped {
 // a mapped feudal file: control block, var data, absolute offset table, fixed data (feudal_io.h has the layout)
 struct FeudalMap {
     Mapped m; std::string path; uint64_t n = 0, varTab = 0, fixedOff = 0;
-    void open(const std::string& pth)
+    void open(const std::string& pth, bool check_table = true)
     {
         path = pth; m.open(pth);
         if (m.n < 24) throw std::runtime_error(path + ": too short for a feudal file");
@@ -167,13 +168,30 @@ struct FeudalMap {
             throw std::runtime_error(path + ": inconsistent feudal control block");
         n = (h.fixedOff - h.varTab) / 8 - 1; varTab = h.varTab; fixedOff = h.fixedOff;
         if ((uint32_t)n != h.n) throw std::runtime_error(path + ": element count mismatch");
-        // offsets: absolute, inside the var data, ascending
-        std::atomic<bool> bad{false};
+        if (check_table) check_offsets();
+    }
+    // offsets: absolute, inside the var data, ascending.  `sizes` (optional): element i must take exactly sizes(i) bytes -- the
+    // .fastb check that a read's bytes are ceil(len/4), in the same pass.
+    struct NoSizes { static constexpr bool given = false; uint64_t operator()(uint64_t) const { return 0; } };
+    void check_offsets() const { check_offsets(NoSizes{}, nullptr); }
+    template <class Sizes>                                               // (a functor the loop inlines: it runs 1.8e9 times)
+    void check_offsets(const Sizes& sizes, const char* what_else) const
+    {
+        constexpr bool with_sizes = !std::is_same<Sizes, NoSizes>::value;
+        std::atomic<int> bad{0};
+        // (entering a range's pages into the page table in one call first -- MADV_POPULATE_READ -- made the pass SLOWER here: 0.45 s
+        // against 0.29 at configs[1])
         parallel_ranges(n + 1, [&](unsigned, uint64_t lo, uint64_t hi) {
             uint64_t prev = lo ? off(lo - 1) : 24;
-            for (uint64_t i = lo; i < hi; ++i) { const uint64_t o = off(i); if (o < prev || o > varTab) { bad = true; return; } prev = o; }
+            for (uint64_t i = lo; i < hi; ++i) {
+                const uint64_t o = off(i);
+                if (o < prev || o > varTab) { bad = 1; return; }
+                if (with_sizes && i && o - prev != sizes(i - 1)) { bad = 2; return; }
+                prev = o;
+            }
         });
-        if (bad) throw std::runtime_error(path + ": offset table is not ascending or runs past the data");
+        if (bad == 1) throw std::runtime_error(path + ": offset table is not ascending or runs past the data");
+        if (bad == 2) throw std::runtime_error(path + (what_else ? what_else : ": an element has not the size it should"));
     }
     uint64_t off(uint64_t i) const { return ld64(m.p + varTab + 8 * i); }       // absolute file offset of element i
     const uint8_t* off_table() const { return m.p + varTab; }
@@ -602,10 +620,21 @@ int main(int argc, char** argv)
         double t0 = now_s();
         struct In { FeudalMap fb, qp; std::vector<int64_t> bci; };
         std::vector<In> ins(heads.size());
+        std::vector<std::thread> background;              // output files written while the GPU counts; checks nothing waits for
+        std::exception_ptr bg_err; std::atomic<bool> bg_failed{false};
+        struct Joiner { std::vector<std::thread>& v; ~Joiner() { for (auto& t : v) if (t.joinable()) t.join(); } } joiner{background};
+        auto in_background = [&](std::function<void()> fn) {
+            background.emplace_back([&, fn] { try { fn(); } catch (...) { if (!bg_failed.exchange(true)) bg_err = std::current_exception(); } });
+        };
+        auto join_background = [&] {
+            for (auto& x : background) x.join();
+            background.clear();
+            if (bg_failed) std::rethrow_exception(bg_err);
+        };
         for (size_t i = 0; i < heads.size(); ++i) {
             In& x = ins[i];
-            x.fb.open(heads[i] + ".fastb");
-            x.qp.open(heads[i] + ".qualp");
+            x.fb.open(heads[i] + ".fastb", false);
+            x.qp.open(heads[i] + ".qualp", false);
             x.bci = feudal::read_bci(heads[i] + ".bci");
             if (x.qp.n != x.fb.n) throw std::runtime_error(heads[i] + ": .fastb and .qualp disagree on the number of reads");
             if (x.fb.m.n - x.fb.fixedOff < 4 * x.fb.n) throw std::runtime_error(heads[i] + ".fastb: fixed data too short");
@@ -614,12 +643,14 @@ int main(int argc, char** argv)
                 throw std::runtime_error(heads[i] + ": .bci does not describe these reads");
             for (size_t b = 0; b + 1 < x.bci.size(); ++b)
                 if (x.bci[b] > x.bci[b + 1]) throw std::runtime_error(heads[i] + ": .bci is not ascending");
-            std::atomic<bool> bad{false};
-            parallel_ranges(x.fb.n, [&](unsigned, uint64_t lo, uint64_t hi) {
-                for (uint64_t r = lo; r < hi; ++r)
-                    if (x.fb.off(r + 1) - x.fb.off(r) != ((uint64_t)ld32(x.fb.fixed() + 4 * r) + 3) / 4) { bad = true; return; }
-            });
-            if (bad) throw std::runtime_error(heads[i] + ".fastb: read length disagrees with its byte count");
+            // .fastb's offset table in ONE pass: ascending, inside the data, and every read ceil(len/4) bytes -- what lets the count
+            // derive the table on the device from the lengths.  .qualp's table is checked beside what follows: the device checks
+            // it again before it reads anything through it (k_trim), the host's readers of it (the general path) wait for this one.
+            const uint8_t* lens = x.fb.fixed();
+            struct DenseSize { const uint8_t* lens; uint64_t operator()(uint64_t r) const { return ((uint64_t)ld32(lens + 4 * r) + 3) / 4; } };
+            x.fb.check_offsets(DenseSize{lens}, ".fastb: read length disagrees with its byte count");
+            FeudalMap* qp = &x.qp;
+            in_background([qp] { qp->check_offsets(); });
         }
         if (select_frac.size() == 1 && heads.size() > 1) select_frac.assign(heads.size(), select_frac[0]);
         if (select_frac.size() != heads.size()) throw std::runtime_error("LR_SELECT_FRAC needs one value per LR input");   // DfTools.cc:96
@@ -631,6 +662,7 @@ int main(int argc, char** argv)
         bool fast = heads.size() == 1 && select_frac[0] >= 1.0;
         if (fast) for (size_t b = 0; b + 1 < ins[0].bci.size(); ++b) if ((ins[0].bci[b + 1] - ins[0].bci[b]) % 2) { fast = false; break; }
         if (fast && (uint64_t)ins[0].bci.back() != ins[0].fb.n) fast = false;
+        if (!fast) join_background();                     // (the general path reads .qualp through its table on the host: checked first)
         feudal::Reads R;                                  // general path only
         std::vector<int64_t> bci;
         std::vector<DataSet> datasets;
@@ -638,12 +670,6 @@ int main(int argc, char** argv)
         const uint8_t *h_packed, *h_boff, *h_len, *h_pq, *h_qoff;   // (possibly unaligned: inside mapped files)
         const std::string rh = work_dir + "/data/frag_reads_orig";
         RefRandom rng;
-        std::vector<std::thread> background;              // output files written while the GPU counts
-        std::exception_ptr bg_err; std::atomic<bool> bg_failed{false};
-        struct Joiner { std::vector<std::thread>& v; ~Joiner() { for (auto& t : v) if (t.joinable()) t.join(); } } joiner{background};
-        auto in_background = [&](std::function<void()> fn) {
-            background.emplace_back([&, fn] { try { fn(); } catch (...) { if (!bg_failed.exchange(true)) bg_err = std::current_exception(); } });
-        };
         t0 = now_s();
         if (fast) {
             In& x = ins[0];
@@ -844,11 +870,6 @@ int main(int argc, char** argv)
         { feudal::BinWriter w(work_dir + "/subsam.names"); w.pod<uint64_t>(1); w.str("C"); }
         { feudal::BinWriter w(work_dir + "/subsam.starts"); w.vec(std::vector<int64_t>{0}); }
         T.ingest_out = now_s() - t0;
-        auto join_background = [&] {
-            for (auto& x : background) x.join();
-            background.clear();
-            if (bg_failed) std::rethrow_exception(bg_err);
-        };
         if (truthy(a["EXIT_LOAD"])) { join_background(); return 0; }             // DF.cc:483
         if (sharded) {
             // the ranks are counting (or, loopback, start now); this process has done the ingest
