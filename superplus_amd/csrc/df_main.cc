@@ -583,7 +583,10 @@ int main(int argc, char** argv)
     if (getenv("DF_RANK")) return rank_main(a, K, work_dir, heads[0], atoi(getenv("DF_RANK")), atoi(getenv("DF_WORLD")), nullptr);
     // EXIT_LOAD (DF.cc:483) stops after the ingest: no rank is spawned for it
     const bool sharded = (num_gpus > 1 || getenv("DF_FORCE_SHARDED")) && !truthy(a["EXIT_LOAD"]);
+    auto mark = [&](const char* what) { if (getenv("DFK_TRACE")) fprintf(stderr, "[DF] %.3f s: %s\n", now_s() - t_start, what); };
+    mark("arguments read");
     if (!sharded && !truthy(a["EXIT_LOAD"])) bind_to_gpu_node(atoi(a["DEVICE"].c_str()));      // (a parent of ranks must not touch the GPU before it forks)
+    mark("bound to the GPU's node");
     ChildWatch watch;
     std::vector<pid_t>& children = watch.live;
     if (sharded) {
@@ -655,6 +658,7 @@ int main(int argc, char** argv)
         if (select_frac.size() == 1 && heads.size() > 1) select_frac.assign(heads.size(), select_frac[0]);
         if (select_frac.size() != heads.size()) throw std::runtime_error("LR_SELECT_FRAC needs one value per LR input");   // DfTools.cc:96
         T.read = now_s() - t0;
+        mark("inputs mapped and checked");
 
         // The arrays createDict sees.  Fast path (one input, every pair kept, every barcode an even number of reads:
         // what ParseBarcodedFastqs writes and runall.sh:127 passes): LoadData's order IS the input's order, so the
@@ -673,15 +677,15 @@ int main(int argc, char** argv)
         t0 = now_s();
         if (fast) {
             In& x = ins[0];
-            n_reads = x.fb.n; bci = x.bci;
+            n_reads = x.fb.n; bci = std::move(x.bci);                          // (80 MB at configs[1]: not copied)
             DataSet d{}; d.dt = 2; d.start = 0; datasets.push_back(d);
-            d.dt = 3; d.start = x.bci[1]; datasets.push_back(d);
+            d.dt = 3; d.start = bci[1]; datasets.push_back(d);
             h_packed = x.fb.m.p; h_boff = x.fb.off_table(); h_len = x.fb.fixed();
             h_pq = x.qp.m.p; h_qoff = x.qp.off_table();
             const bool may_link = truthy(a["LINK_READS"]);
             if (!(may_link && link_feudal(x.fb, rh + ".fastb", 4, 16, 1))) in_background([&] { copy_feudal(x.fb, rh + ".fastb", 4, 16, 1); });      // (two files, two writers)
             if (!(may_link && link_feudal(x.qp, rh + ".qualp", 0, 8, 1))) in_background([&] { copy_feudal(x.qp, rh + ".qualp", 0, 8, 1); });
-            { feudal::BinWriter w(rh + ".bci"); w.vec(bci); }
+            in_background([&bci, rh] { feudal::BinWriter w(rh + ".bci"); w.vec(bci); });     // (the count thread, which reads bci too, is not kept waiting for it)
         } else {
             R.base_off.push_back(0); R.pq_off.push_back(0);
             bci.push_back(0);
@@ -831,6 +835,7 @@ int main(int argc, char** argv)
         std::thread count_thread;
         struct JoinAtExit { std::thread& t; ~JoinAtExit() { if (t.joinable()) t.join(); } } count_joiner{count_thread};   // (an exception below must not leave it running)
         struct LenAtExit { std::atomic<int>& v; ~LenAtExit() { if (v.load() < 0) v = 0; } } len_guard{max_len_known};   // (the count thread waits for it)
+        mark("count thread starts");
         if (fast && !sharded && !truthy(a["EXIT_LOAD"])) count_thread = std::thread(count_job);
 
         // ---- lens, quality histogram, datasets (DF.cc:50-68, DfTools.cc:172-238)
@@ -912,6 +917,7 @@ int main(int argc, char** argv)
             background.clear();
             background.emplace_back([&ins, earlier] { for (auto& x : *earlier) x.join(); for (In& x : ins) { x.fb.m.unmap(); x.qp.m.unmap(); } });
         }
+        mark("count joined");
         t0 = now_s();
         uint64_t need = 0; dfk_spectrum_json(ctx, nullptr, 0, &need);
         std::string js(need, '\0'); dfk_spectrum_json(ctx, &js[0], need, &need);
@@ -928,6 +934,7 @@ int main(int argc, char** argv)
         uint64_t g_ce = 0, g_v = 0, g_e = 0, p_placed = 0, p_edges = 0, n_dup = 0;
         if (truthy(a["GRAPH"])) {
             t0 = now_s();
+            mark("graph starts");
             printf("%s: finding edge sequences.\n", date().c_str());
             if (dfk_graph_build(ctx)) throw std::runtime_error(dfk_last_error());
             { dfk_stats gs{}; dfk_get_stats(ctx, &gs); t_g_dev = 1e-6 * (double)gs.reserved[1]; t_g_host = 1e-6 * (double)gs.reserved[2]; }
@@ -945,11 +952,13 @@ int main(int argc, char** argv)
             if (want_paths) {
                 // pathReads (BuildReadQGraph48.cc:1664-1665) and a.<K>/a.paths (10X/WriteFiles.cc:78-82)
                 t0 = now_s();
+                mark("pathing starts");
                 printf("%s: pathing reads\n", date().c_str());
                 if (reserve_thread.joinable()) reserve_thread.join();
                 if (dfk_paths_sink(ctx, (dir + "/a.paths").c_str())) throw std::runtime_error(dfk_last_error());      // (its data goes to the file batch by batch)
                 if (dfk_paths_build(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) throw std::runtime_error(dfk_last_error());
                 { dfk_stats ps{}; dfk_get_stats(ctx, &ps); t_p_dev = 1e-6 * (double)ps.reserved[3]; }
+                mark("pathing done");
                 printf("%s: writing paths\n", date().c_str());
                 std::string bg_fail2;
                 std::thread paths_writer([&] { const double t1 = now_s(); if (dfk_paths_write(ctx, (dir + "/a.paths").c_str())) bg_fail2 = dfk_last_error(); tw_paths = now_s() - t1; });
@@ -969,8 +978,11 @@ int main(int argc, char** argv)
                     if (dfk_paths_index_dups_write(ctx, dir.c_str(), (dir + "/a.dup").c_str(), &n_dup)) throw std::runtime_error(dfk_last_error());
                     t_index = now_s() - ti;                                     // (both: mark_dups_s stays 0)
                 }
+                mark("index and duplicate marks done");
                 paths_writer.join();
+                mark("a.paths written");
                 graph_writer.join();
+                mark("graph files written");
                 if (!bg_fail.empty()) throw std::runtime_error(bg_fail);
                 if (!bg_fail2.empty()) throw std::runtime_error(bg_fail2);
                 t_p_write = tw_paths;
@@ -987,6 +999,7 @@ int main(int argc, char** argv)
         if (!quick_exit) dfk_destroy(ctx);
         const double t_destroy = now_s() - t_d0;
         join_background();
+        mark("background joined");
         const double t_joined = now_s() - t_d0 - t_destroy;
         T.total = now_s() - t_start;
         printf("%s: dictionary covers %llu kmers\n", date().c_str(), (unsigned long long)nk);
