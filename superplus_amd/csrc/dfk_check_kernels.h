@@ -49,7 +49,25 @@ k_paths_digest(const uint32_t* __restrict__ var, const uint32_t* __restrict__ el
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d, 64); xr ^= __shfl_down(xr, d, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&digest[0], sum); atomicXor(&digest[1], xr); }
+    // One slot pair per BLOCK, added to by that block alone (the launches of a run follow each other on one stream): the kernel is
+    // launched once per batch -- 187 times at configs[1] -- and a wave's atomics on two shared words, six million of them on the
+    // same two addresses, took 0.14 s of a 1.6-s pathing.  k_paths_digest_fold adds the slots up.
+    __shared__ uint64_t part[2][4];
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = sum; part[1][threadIdx.x >> 6] = xr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        digest[2 * blockIdx.x] += part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        digest[2 * blockIdx.x + 1] ^= part[1][0] ^ part[1][1] ^ part[1][2] ^ part[1][3];
+    }
+}
+__global__ void __launch_bounds__(256)
+k_paths_digest_fold(const unsigned long long* __restrict__ slots, uint32_t n_blocks, unsigned long long* __restrict__ out)
+{
+    uint64_t sum = 0, xr = 0;
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += 256) { sum += slots[2 * b]; xr ^= slots[2 * b + 1]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d, 64); xr ^= __shfl_down(xr, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], sum); atomicXor(&out[1], xr); }
 }
 
 // entries of the paths index that sit on edges equal to their own involution (their reads are counted once in a.countsb)
