@@ -540,7 +540,14 @@ k_path_reads(PartTable pt_arg, const uint32_t* __restrict__ index, uint64_t n_sl
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { placed += __shfl_down(placed, d, 64); n_edges += __shfl_down(n_edges, d, 64); }
-    if ((threadIdx.x & 63) == 0 && (placed | n_edges)) { atomicAdd(&stats[0], placed); atomicAdd(&stats[1], n_edges); }
+    // (one pair of atomics a block, not a wave: the two words are the same for the whole grid, and the kernel runs once a batch)
+    __shared__ unsigned long long tally[2][4];
+    if ((threadIdx.x & 63) == 0) { tally[0][threadIdx.x >> 6] = placed; tally[1][threadIdx.x >> 6] = n_edges; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long p = tally[0][0] + tally[0][1] + tally[0][2] + tally[0][3], e = tally[1][0] + tally[1][1] + tally[1][2] + tally[1][3];
+        if (p | e) { atomicAdd(&stats[0], p); atomicAdd(&stats[1], e); }
+    }
 }
 
 // a.paths element sizes (ReadPath::writeFeudal, paths/long/ReadPath.h:56-58: i32 offset, u32 lastSkip, the edge ids)
