@@ -2234,7 +2234,7 @@ static int count_host(dfk_ctx* c, const uint8_t* packed, const uint64_t* base_of
                             (const int32_t*)d_bc, n_reads};
             c->t_upload_done = 0;
             rc = run_from_host_bases(c, in, packed);
-            if (rc) c->release_all();
+            if (rc) { (void)hipDeviceSynchronize(); c->release_all(); }         // (a piece's scan may still be running on what is about to be freed)
             (void)t.stop();
             ms_up = c->t_upload_done > t_host0 ? (float)(1e3 * (c->t_upload_done - t_host0)) : 0.0f;     // (to the arrival of the last base; trim and most of the scan are inside it)
             TRACE("inputs on the device %.3f s after the call, counted %.3f s after it", 1e-3 * ms_up, wall_now() - t_host0);
