@@ -1771,6 +1771,7 @@ int run_under_upload(dfk_ctx* c, const Inputs& in, const uint8_t* h_packed)
         trim_rc = stage_trim<K>(c, in, &pre.n_inst);
         if (trim_rc) trim_err = g_err; else pre.ms_trim = tt.stop();
     });
+    struct JoinTrim { std::thread& t; ~JoinTrim() { if (t.joinable()) t.join(); } } join_trim{trim};     // (whatever happens below)
     uint64_t sent = std::min(seg, pb);
     int rc = upload(c, (void*)in.packed, h_packed, sent);
     if (sent >= pb) c->t_upload_done = wall_now();
