@@ -378,6 +378,7 @@ def df_stage_wall(args, dev, local):
                 if args.df_transport == "loopback": env["DF_TRANSPORT"] = "loopback"
                 elif args.df_gpus <= 1: env["DF_FORCE_SHARDED"] = "1"
             if os.environ.get("DF_TASKSET"): cmd = ["taskset", "-c", os.environ["DF_TASKSET"]] + cmd      # (an experiment's switch: bind the stage's threads)
+            if env.get("DF_WRAP"): cmd = env["DF_WRAP"].split() + cmd          # (a DF_VARIANTS run under a profiler: "rocprofv3 --kernel-trace --stats -d dir --")
             time.sleep(wait_s)
             cpu0 = cgroup_cpu_stat()
             t0 = time.perf_counter(); e0 = time.time()
